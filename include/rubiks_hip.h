@@ -1,0 +1,162 @@
+/*
+ * rubiks_hip.h -- C ABI of librubiks_hip.so, the MI355X (gfx950) implementation of
+ * the RubiksShift hot path.  This is the drop-in boundary: these entry points are
+ * what the reference's extension module `rubiksnet_cuda`
+ * (cuda_src/rubiks.cpp:384-396, built by setup.py:41-52) binds, restated as plain C
+ * (raw device pointers + sizes, no torch types).  INTEGRATION.md shows the
+ * reference-side ctypes binding (`rubiksnet_cuda.py`) a maintainer would add.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer on the device that is current when the call
+ *     is made; `stream` is a hipStream_t of that device (NULL = the null stream).
+ *     The reference launches on the legacy default stream of whatever device is
+ *     current and reads device attributes from device 0 (rubiks3d_kernels.cu:975-998);
+ *     here the caller names the stream and the library caches nothing per device.
+ *   - tensors are dense/contiguous in the reference's layouts:
+ *       3D: x [N,T,C,H,W], y / gy [N,To,C,Ho,Wo], shift / gshift [3,C] rows = (T,H,W)
+ *           (rubiks.cpp:197-207, :243-244)
+ *       2D: x [N,C,H,W],  y / gy [N,C,Ho,Wo],     shift / gshift [2,C] rows = (H,W)
+ *           (rubiks.cpp:61-63)
+ *     out = (in + 2*pad - 1) / stride + 1   (rubiks.cpp:166 -- not the conv formula);
+ *     rk_out_len() exposes it.
+ *   - the caller owns every buffer including outputs and the workspace (the reference
+ *     allocates scratch inside, rubiks.cpp:127-132,295-299); nothing is allocated,
+ *     freed or synchronised inside the library, so calls are graph-capturable.
+ *   - 3D kernels write EVERY element of y / gx / gshift (no pre-zeroing needed).
+ *     2D with quantize != 0 reproduces the reference quirk of leaving out-of-range
+ *     elements of y / gx untouched (rubiks2d_kernels.cu:116-121, :294-309): pre-zero
+ *     those two buffers in that case, as rubiksnet/utils.py:26 does.
+ *   - return value: RK_OK (0) or a negative RK_ERR_* code; never exit()s
+ *     (the reference's gpuAssert does, rubiks3d_kernels.cu:963-971).  The reference's
+ *     Python asserts `ret == 0` (rubiks3d/primitive.py:79,139).
+ *   - re-entrant, no global mutable state; safe from autograd worker threads.
+ */
+#ifndef RUBIKS_HIP_H_
+#define RUBIKS_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rk_stream_t; /* hipStream_t */
+
+enum {
+    RK_OK = 0,
+    RK_ERR_NULL_POINTER = -1,  /* a required pointer is NULL */
+    RK_ERR_BAD_DIMS = -2,      /* a dimension is <= 0 or element count overflows int32 */
+    RK_ERR_BAD_STRIDE = -3,    /* stride <= 0 or padding < 0 (reference only prints, rubiks.cpp:162-164) */
+    RK_ERR_WORKSPACE = -4,     /* workspace NULL or smaller than *_workspace_bytes() */
+    RK_ERR_LAUNCH = -5,        /* hipGetLastError() after a launch was not hipSuccess */
+    RK_ERR_NO_DEVICE = -6      /* no usable HIP device */
+};
+
+int rk_version(void);                 /* 1000*major + minor */
+const char* rk_error_string(int code);
+int rk_out_len(int in, int stride, int pad); /* rubiks.cpp:14-30, :161-178 */
+int rk_device_count(void);            /* hipGetDeviceCount, 0 when none */
+
+/* ------------------------------------------------------------------------- 3D
+ * Replaces rubiks_shift_3d_forward<T>  (cuda_src/rubiks.cpp:181-253) + functor
+ * RubiksShift3DForward (cuda_src/rubiks3d.h:13-28) + K1 (rubiks3d_kernels.cu:15-205).
+ * pybind names: rubiks_shift_3d_forward_float / _double (rubiks.cpp:392-393). */
+int rk3d_forward_f32(const float* x, const float* shift, float* y,
+                     int N, int T, int C, int H, int W,
+                     int stride_T, int stride_H, int stride_W,
+                     int pad_T, int pad_H, int pad_W,
+                     int quantize, rk_stream_t stream);
+int rk3d_forward_f64(const double* x, const double* shift, double* y,
+                     int N, int T, int C, int H, int W,
+                     int stride_T, int stride_H, int stride_W,
+                     int pad_T, int pad_H, int pad_W,
+                     int quantize, rk_stream_t stream);
+
+/* Bytes of scratch rk3d_backward_* needs (elem_size = 4 or 8).  Replaces the
+ * zeros[3C,Ho,Wo] + ones[Ho,Wo] allocations of rubiks.cpp:294-299. */
+size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W,
+                                     int stride_T, int stride_H, int stride_W,
+                                     int pad_T, int pad_H, int pad_W, int elem_size);
+
+/* Replaces rubiks_shift_3d_backward<T> (cuda_src/rubiks.cpp:256-379): K2 partials +
+ * addmv row-sum (:344-345) + K5 normalise (:352-358) + K3/K4 input grad (:363-376),
+ * functors cuda_src/rubiks3d.h:31-81.  pybind names rubiks_shift_3d_backward_float /
+ * _double (rubiks.cpp:394-395).  Both gradients are always produced, as in the
+ * reference; gx or gshift may be NULL to skip that half (extension).
+ * `x` is read only for gshift (the reference passes it to K3/K4 but never reads it). */
+int rk3d_backward_f32(const float* x, const float* shift, const float* gy,
+                      float* gx, float* gshift,
+                      int N, int T, int C, int H, int W,
+                      int stride_T, int stride_H, int stride_W,
+                      int pad_T, int pad_H, int pad_W,
+                      int normalize_grad, float normalize_t_factor, int quantize,
+                      void* workspace, size_t workspace_bytes, rk_stream_t stream);
+int rk3d_backward_f64(const double* x, const double* shift, const double* gy,
+                      double* gx, double* gshift,
+                      int N, int T, int C, int H, int W,
+                      int stride_T, int stride_H, int stride_W,
+                      int pad_T, int pad_H, int pad_W,
+                      int normalize_grad, double normalize_t_factor, int quantize,
+                      void* workspace, size_t workspace_bytes, rk_stream_t stream);
+
+/* ------------------------------------------------------------------------- 2D
+ * Replaces rubiks2d_forward (cuda_src/rubiks.cpp:44-67) + rubiks2d_forward_cuda
+ * (rubiks2d_kernels.cu:408-432) + K6 (:94-145).  The reference dispatches
+ * float/double/half (AT_DISPATCH_FLOATING_TYPES_AND_HALF); bf16 is an addition.
+ * f16/bf16 compute in fp32 and round once on store. */
+#define RK_DECL_2D(SFX, TYPE)                                                              \
+    int rk2d_forward_##SFX(const TYPE* x, const TYPE* shift, TYPE* y,                      \
+                           int N, int C, int H, int W,                                     \
+                           int stride_H, int stride_W, int pad_H, int pad_W,               \
+                           int quantize, rk_stream_t stream);                              \
+    int rk2d_backward_##SFX(const TYPE* gy, const TYPE* x, const TYPE* shift,              \
+                            TYPE* gx, TYPE* gshift,                                        \
+                            int N, int C, int H, int W,                                    \
+                            int stride_H, int stride_W, int pad_H, int pad_W,              \
+                            int normalize_grad, int enable_shift_grad, int quantize,       \
+                            void* workspace, size_t workspace_bytes, rk_stream_t stream);
+
+/* rk2d_backward_* replaces rubiks2d_backward (cuda_src/rubiks.cpp:94-155): K7 partials
+ * (rubiks2d_kernels.cu:147-266) + addmv row-sum (rubiks.cpp:140-143) + K9 normalise
+ * (:381-397) when enable_shift_grad, then K8 (:269-379).  With enable_shift_grad == 0
+ * gshift is left untouched, as in the reference.  f16 / bf16 pointers are uint16_t
+ * bit patterns, passed as void*. */
+RK_DECL_2D(f32, float)
+RK_DECL_2D(f64, double)
+RK_DECL_2D(f16, void)
+RK_DECL_2D(bf16, void)
+#undef RK_DECL_2D
+
+size_t rk2d_backward_workspace_bytes(int N, int C, int H, int W,
+                                     int stride_H, int stride_W, int pad_H, int pad_W,
+                                     int elem_size);
+
+/* ------------------------------------------------------------ temporal 3-tap
+ * The device half of AttentionShift (rubiksnet/attention_shift.py:32-39): the
+ * per-channel 3-tap temporal filter the reference runs as transpose -> grouped
+ * conv1d(groups=C*H*W) -> transpose -> contiguous.  `taps` is the [C,3] fp32 tensor
+ * of already soft-maxed weights (attention_shift.py:29-30, computed on the host side
+ * in PyTorch so autograd owns std/softmax); x, y are [NT, C, H, W] with
+ * NT = n_batch * n_segment; zero padding in t.
+ *   y[n,t] = taps[c,0]*x[n,t-1] + taps[c,1]*x[n,t] + taps[c,2]*x[n,t+1]
+ * backward: gx = adjoint; gtaps[C,3] (fp32) = sum over n,t,h,w of gy * x[t-1+k]. */
+#define RK_DECL_TAP(SFX, TYPE)                                                             \
+    int rk_tshift3_forward_##SFX(const TYPE* x, const float* taps, TYPE* y,                \
+                                 int NT, int n_segment, int C, int HW, rk_stream_t stream);\
+    int rk_tshift3_backward_##SFX(const TYPE* gy, const TYPE* x, const float* taps,        \
+                                  TYPE* gx, float* gtaps,                                  \
+                                  int NT, int n_segment, int C, int HW,                    \
+                                  void* workspace, size_t workspace_bytes,                 \
+                                  rk_stream_t stream);
+RK_DECL_TAP(f32, float)
+RK_DECL_TAP(f64, double)
+RK_DECL_TAP(f16, void)
+RK_DECL_TAP(bf16, void)
+#undef RK_DECL_TAP
+
+size_t rk_tshift3_backward_workspace_bytes(int NT, int n_segment, int C, int HW);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUBIKS_HIP_H_ */

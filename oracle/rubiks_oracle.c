@@ -1,0 +1,61 @@
+/*
+ * rubiks_oracle.c -- CPU oracle for the RubiksShift hot path.
+ *
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg may load this library, and only as the
+ * checker / the reported CPU baseline.  Nothing under rubiksnet_amd/ imports it;
+ * the product path fails loudly when the HIP extension is missing.
+ *
+ * What it is: a plain-C restatement, element for element, of the arithmetic of the
+ * reference's device kernels and of the small amount of host glue around them:
+ *   K1  rubiks_shift_3d_forward_cuda            cuda_src/rubiks3d_kernels.cu:15-205
+ *   K2  rubiks_shift_3d_backward_cuda           cuda_src/rubiks3d_kernels.cu:218-452
+ *   K3  rubiks_shift_3d_backward_input_cuda     cuda_src/rubiks3d_kernels.cu:455-723
+ *   K4  ..._backward_input_s1p0_cuda            cuda_src/rubiks3d_kernels.cu:726-929
+ *   K5  normalize_shift_grad_3d_cuda            cuda_src/rubiks3d_kernels.cu:932-960
+ *   K6  rubiks2d_forward_kernel                 cuda_src/rubiks2d_kernels.cu:94-145
+ *   K7  rubiks2d_backward_shift_kernel          cuda_src/rubiks2d_kernels.cu:147-266
+ *   K8  rubiks2d_backward_input_kernel          cuda_src/rubiks2d_kernels.cu:269-379
+ *   K9  rubiks2d_normalize_shift_grad_kernel    cuda_src/rubiks2d_kernels.cu:381-397
+ *   B2  rubiks_shift_3d_backward (host)         cuda_src/rubiks.cpp:256-379
+ *   B4  rubiks2d_backward (host)                cuda_src/rubiks.cpp:94-155
+ * It is written as loops over (n, t, c, h, w) rather than over a flat thread index,
+ * and the float atomics of K2/K7 become serial adds (per address in increasing
+ * (n, t) order).  Compiled with -ffp-contract=off so that every multiply and add
+ * rounds separately, exactly as written.
+ *
+ * PARITY STATUS: **parity unpinned by reference execution** for K1-K9.
+ * The reference is a CUDA extension: it cannot be built in this image without
+ * writing stand-ins for cuda.h / cuda_runtime.h / THC headers, which the build
+ * rules forbid, and the reference ships no tests or golden vectors for these
+ * kernels.  The only reference-derived numbers available are
+ * the three checksums SURVEY.md Appendix A recorded from the reference's device
+ * code; oracle/appendix_a_check.cpp reproduces that experiment and
+ * tests/test_oracle_pins.py asserts this oracle matches all three.  The
+ * AttentionShift oracle (oracle/attention_oracle.py) IS pinned: its fixtures come
+ * from importing the reference's pure-PyTorch module (tests/golden/gen_attention_golden.py).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#define RK_T float
+#define RK_FN(name) name##_f32
+#include "rubiks_oracle_impl.h"
+#undef RK_T
+#undef RK_FN
+
+#define RK_T double
+#define RK_FN(name) name##_f64
+#include "rubiks_oracle_impl.h"
+#undef RK_T
+#undef RK_FN
+
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_num_threads(void) { return omp_get_max_threads(); }
+void oracle_set_num_threads(int n) { omp_set_num_threads(n); }
+#else
+int oracle_num_threads(void) { return 1; }
+void oracle_set_num_threads(int n) { (void)n; }
+#endif

@@ -1,0 +1,82 @@
+"""ctypes loader for librubiks_hip.so (the C ABI declared in include/rubiks_hip.h).
+
+There is deliberately NO fallback: if the HIP library has not been built, or a tensor is
+not on a GPU, the operators raise.  Build with `python -c "import __graft_entry__ as g;
+g.build()"` or `rubiksnet_amd/csrc/build.sh`.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librubiks_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/rubiks_hip.h one to one
+_DIMS3 = [_i] * 5 + [_i] * 6          # N,T,C,H,W, sT,sH,sW, pT,pH,pW
+_DIMS2 = [_i] * 4 + [_i] * 4          # N,C,H,W, sH,sW,pH,pW
+SIGNATURES = {
+    "rk_version": (_i, []),
+    "rk_error_string": (ctypes.c_char_p, [_i]),
+    "rk_out_len": (_i, [_i, _i, _i]),
+    "rk_device_count": (_i, []),
+    "rk3d_forward_f32": (_i, [_p, _p, _p] + _DIMS3 + [_i, _p]),
+    "rk3d_forward_f64": (_i, [_p, _p, _p] + _DIMS3 + [_i, _p]),
+    "rk3d_backward_workspace_bytes": (_sz, _DIMS3 + [_i]),
+    "rk3d_backward_f32": (_i, [_p] * 5 + _DIMS3 + [_i, ctypes.c_float, _i, _p, _sz, _p]),
+    "rk3d_backward_f64": (_i, [_p] * 5 + _DIMS3 + [_i, ctypes.c_double, _i, _p, _sz, _p]),
+    "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
+    "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+}
+for _sfx in ("f32", "f64", "f16", "bf16"):
+    SIGNATURES["rk2d_forward_" + _sfx] = (_i, [_p, _p, _p] + _DIMS2 + [_i, _p])
+    SIGNATURES["rk2d_backward_" + _sfx] = (_i, [_p] * 5 + _DIMS2 + [_i, _i, _i, _p, _sz, _p])
+    SIGNATURES["rk_tshift3_forward_" + _sfx] = (_i, [_p, _p, _p, _i, _i, _i, _i, _p])
+    SIGNATURES["rk_tshift3_backward_" + _sfx] = (_i, [_p] * 5 + [_i, _i, _i, _i, _p, _sz, _p])
+
+
+class RubiksHipError(RuntimeError):
+    """A librubiks_hip entry point returned a negative RK_ERR_* code."""
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "librubiks_hip.so not found at %s -- the HIP extension is not built and there is "
+                        "no CPU fallback. Run `python -c \"import __graft_entry__ as g; g.build()\"`." % LIB_PATH
+                    )
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)   # AttributeError here = ABI mismatch, loudly
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().rk_error_string(int(rc)).decode()
+        raise RubiksHipError("%s failed: %s (code %d)" % (what, msg, rc))
+
+
+def dtype_suffix(dtype):
+    import torch
+
+    return {
+        torch.float32: "f32",
+        torch.float64: "f64",
+        torch.float16: "f16",
+        torch.bfloat16: "bf16",
+    }.get(dtype)

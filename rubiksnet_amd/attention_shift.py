@@ -1,0 +1,92 @@
+"""AttentionShift: per-channel softmax attention over 3 temporal taps.
+
+Counterpart of rubiksnet/attention_shift.py:6-39.  Same module surface (`n_segment`,
+`kernel_size`, frozen temperature parameter `T`, lazily created `weight` [C, 3]) and the same
+maths; the difference is where the work runs.  The reference transposes the activation,
+inflates the [C,3] weights to [C*H*W,1,3] and calls a grouped conv1d (>= 3 full passes).
+Here the tiny [C,3] normalise+softmax stays in PyTorch (so autograd owns it) and the
+activation goes once through the HIP 3-tap kernel (rk_tshift3_*, include/rubiks_hip.h).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native
+
+__all__ = ["AttentionShift", "temporal_shift3"]
+
+
+def _run(name, dev, *args):
+    with torch.cuda.device(dev):
+        rc = getattr(_native.lib(), name)(*args, torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, name)
+
+
+class _TemporalShift3Func(torch.autograd.Function):
+    """y[n,t] = s[c,0] x[n,t-1] + s[c,1] x[n,t] + s[c,2] x[n,t+1], zero padded in t."""
+
+    @staticmethod
+    def forward(ctx, x, taps, n_segment):
+        assert x.is_cuda, "AttentionShift runs on the HIP device only (no CPU fallback)"
+        sfx = _native.dtype_suffix(x.dtype)
+        if sfx is None:
+            raise ValueError("AttentionShift supports float16/bfloat16/float32/float64, got %s" % x.dtype)
+        nt, c, h, w = x.shape
+        assert nt % n_segment == 0, "batch*time (%d) is not a multiple of n_segment (%d)" % (nt, n_segment)
+        x = x.contiguous()
+        taps32 = taps.detach().to(torch.float32).contiguous()
+        y = torch.empty_like(x)
+        _run("rk_tshift3_forward_" + sfx, x.device, x.data_ptr(), taps32.data_ptr(), y.data_ptr(),
+             nt, n_segment, c, h * w)
+        ctx.save_for_backward(x, taps32)
+        ctx.n_segment = n_segment
+        ctx.sfx = sfx
+        ctx.taps_dtype = taps.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, taps32 = ctx.saved_tensors
+        nt, c, h, w = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        gtaps = torch.empty_like(taps32)
+        L = _native.lib()
+        ws_bytes = int(L.rk_tshift3_backward_workspace_bytes(nt, ctx.n_segment, c, h * w))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        _run("rk_tshift3_backward_" + ctx.sfx, x.device, gy.data_ptr(), x.data_ptr(), taps32.data_ptr(),
+             gx.data_ptr(), gtaps.data_ptr(), nt, ctx.n_segment, c, h * w, ws.data_ptr(), ws_bytes)
+        return gx, gtaps.to(ctx.taps_dtype), None
+
+
+def temporal_shift3(x, taps, n_segment):
+    """Functional form: x [N*T, C, H, W], taps [C, 3] (already normalised)."""
+    return _TemporalShift3Func.apply(x, taps, n_segment)
+
+
+class AttentionShift(nn.Module):
+    def __init__(self, n_segment, num_channels=None):
+        super().__init__()
+        self.n_segment = n_segment
+        self.kernel_size = 3
+        self.T = nn.Parameter(torch.tensor(2.0), requires_grad=False)
+        # the reference creates `weight` on the first forward (attention_shift.py:24-27), which
+        # is why its -aq model constructor needs a dummy CUDA forward (models.py:100-104);
+        # passing num_channels creates it eagerly instead.
+        self.weight = None
+        if num_channels is not None:
+            self.weight = nn.Parameter(torch.rand(num_channels, self.kernel_size))
+
+    def soft_taps(self):
+        """softmax((w / (std(w) + 1e-6)) / T) over the 3 taps (attention_shift.py:29-30)."""
+        weight = self.weight / (torch.std(self.weight, dim=1, keepdim=True) + 1e-6)
+        return F.softmax(weight / self.T, dim=1)
+
+    def forward(self, x):
+        return self.attention_shift(x)
+
+    def attention_shift(self, x):
+        c = x.size(1)
+        if self.weight is None:
+            self.weight = nn.Parameter(torch.rand(c, self.kernel_size).to(x.device))
+        return temporal_shift3(x, self.soft_taps(), self.n_segment)

@@ -1,0 +1,19 @@
+#!/usr/bin/env bash
+# Builds librubiks_hip.so for gfx950 (cross-compiles without a GPU).  In-tree output so the
+# .so travels with the repo snapshot to the GPU box.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# -ffp-contract=off: multiplies and adds round separately, exactly as written, so the fp32 /
+# fp64 forward and d(x) are bit-identical to the oracle (the op is HBM-bound; FMA buys nothing).
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$root/include" -I"$here"
+       -Wall -Wno-unused-function -Wno-implicit-fallthrough)
+objs=()
+for src in rk_misc rk3d rk2d rk_tshift; do
+  "$HIPCC" "${FLAGS[@]}" ${RK_EXTRA_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
+  objs+=("$here/$src.o")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/librubiks_hip.so" "${objs[@]}"
+echo "built $here/librubiks_hip.so"

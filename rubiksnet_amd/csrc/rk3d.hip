@@ -1,0 +1,127 @@
+// rk3d.hip -- C-ABI entry points of the RubiksShift3D operator (include/rubiks_hip.h).
+// Host glue restating cuda_src/rubiks.cpp:161-379 (shape math, dispatch) without ATen:
+// caller-owned buffers and workspace, explicit stream, error codes instead of exit().
+#include "rk3d_generic.hpp"
+#include "rk3d_stream.hpp"
+
+using namespace rk;
+
+namespace {
+
+int make_dims(Dims3& d, int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW) {
+    if (N <= 0 || T <= 0 || C <= 0 || H <= 0 || W <= 0) return RK_ERR_BAD_DIMS;
+    if (sT <= 0 || sH <= 0 || sW <= 0 || pT < 0 || pH < 0 || pW < 0) return RK_ERR_BAD_STRIDE;
+    d.N = N; d.T = T; d.C = C; d.H = H; d.W = W;
+    d.sT = sT; d.sH = sH; d.sW = sW; d.pT = pT; d.pH = pH; d.pW = pW;
+    d.To = out_len(T, sT, pT); d.Ho = out_len(H, sH, pH); d.Wo = out_len(W, sW, pW);
+    if (d.To <= 0 || d.Ho <= 0 || d.Wo <= 0) return RK_ERR_BAD_DIMS;
+    // the reference indexes with int (rubiks3d_kernels.cu:34-36); keep the same limit
+    const long long nin = (long long)N * T * C * H * W, nout = (long long)N * d.To * C * d.Ho * d.Wo;
+    if (nin > 0x7fffffffLL || nout > 0x7fffffffLL) return RK_ERR_BAD_DIMS;
+    return RK_OK;
+}
+
+void set_group(Dims3& d, int plane_elems) {
+    d.E = pow2_at_least(plane_elems, kWave, kBlock);
+    d.logE = (d.E == 64) ? 6 : (d.E == 128 ? 7 : 8);
+}
+
+unsigned grid_for(const Dims3& d, long long planes) {
+    const int per_block = kBlock / d.E;
+    return (unsigned)((planes + per_block - 1) / per_block);
+}
+
+bool is_s1p0(const Dims3& d) {
+    return d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0;
+}
+
+template <typename T>
+int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, int W, int sT, int sH, int sW,
+                 int pT, int pH, int pW, int quantize, rk_stream_t stream_) {
+    if (!x || !shift || !y) return RK_ERR_NULL_POINTER;
+    Dims3 d;
+    if (int rc = make_dims(d, N, Tn, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (stream3d::forward_supported<T>(d, quantize)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
+    set_group(d, d.Ho * d.Wo);
+    const unsigned grid = grid_for(d, (long long)d.N * d.To * d.C);
+    if (quantize)
+        hipLaunchKernelGGL((k3d_forward_generic<T, true>), dim3(grid), dim3(kBlock), 0, stream, x, shift, y, d);
+    else
+        hipLaunchKernelGGL((k3d_forward_generic<T, false>), dim3(grid), dim3(kBlock), 0, stream, x, shift, y, d);
+    return launch_status();
+}
+
+template <typename T>
+int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int N, int Tn, int C, int H, int W,
+                  int sT, int sH, int sW, int pT, int pH, int pW, int normalize_grad, T t_factor, int quantize,
+                  void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    if (!shift || !gy || (!gx && !gshift)) return RK_ERR_NULL_POINTER;
+    if (gshift && !x) return RK_ERR_NULL_POINTER;
+    Dims3 d;
+    if (int rc = make_dims(d, N, Tn, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (gshift) {
+        const size_t need = rk3d_backward_workspace_bytes(N, Tn, C, H, W, sT, sH, sW, pT, pH, pW, (int)sizeof(T));
+        if (!ws || ws_bytes < need) return RK_ERR_WORKSPACE;
+    }
+    if (stream3d::backward_supported<T>(d, quantize))
+        return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
+
+    if (gshift) {   // rubiks.cpp:324-358
+        T* part = (T*)ws;
+        set_group(d, d.Ho * d.Wo);
+        hipLaunchKernelGGL((k3d_backward_shift_generic<T>), dim3(grid_for(d, (long long)d.N * d.To * d.C)),
+                           dim3(kBlock), 0, stream, x, shift, gy, part, d);
+        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(kBlock), 0, stream, (const T*)part, gshift, d.C,
+                           d.N * d.To, normalize_grad, t_factor);
+    }
+    if (gx) {       // rubiks.cpp:363-376
+        set_group(d, d.H * d.W);
+        const unsigned grid = grid_for(d, (long long)d.N * d.T * d.C);
+        if (quantize)
+            hipLaunchKernelGGL((k3d_backward_input_generic<T, true>), dim3(grid), dim3(kBlock), 0, stream, shift, gy,
+                               gx, d);
+        else
+            hipLaunchKernelGGL((k3d_backward_input_generic<T, false>), dim3(grid), dim3(kBlock), 0, stream, shift,
+                               gy, gx, d);
+    }
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH,
+                                     int pW, int elem_size) {
+    (void)H; (void)W; (void)sH; (void)sW; (void)pH; (void)pW;
+    if (N <= 0 || T <= 0 || C <= 0 || sT <= 0 || pT < 0) return 0;
+    // partials part[C][3][P]: P = N*To for the generic kernels, <= that for the streaming ones
+    const size_t P = (size_t)N * (size_t)out_len(T, sT, pT);
+    return (size_t)C * 3 * P * (size_t)elem_size;
+}
+
+int rk3d_forward_f32(const float* x, const float* shift, float* y, int N, int T, int C, int H, int W, int sT,
+                     int sH, int sW, int pT, int pH, int pW, int quantize, rk_stream_t stream) {
+    return forward_impl<float>(x, shift, y, N, T, C, H, W, sT, sH, sW, pT, pH, pW, quantize, stream);
+}
+int rk3d_forward_f64(const double* x, const double* shift, double* y, int N, int T, int C, int H, int W, int sT,
+                     int sH, int sW, int pT, int pH, int pW, int quantize, rk_stream_t stream) {
+    return forward_impl<double>(x, shift, y, N, T, C, H, W, sT, sH, sW, pT, pH, pW, quantize, stream);
+}
+int rk3d_backward_f32(const float* x, const float* shift, const float* gy, float* gx, float* gshift, int N, int T,
+                      int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW, int normalize_grad,
+                      float t_factor, int quantize, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return backward_impl<float>(x, shift, gy, gx, gshift, N, T, C, H, W, sT, sH, sW, pT, pH, pW, normalize_grad,
+                                t_factor, quantize, ws, ws_bytes, stream);
+}
+int rk3d_backward_f64(const double* x, const double* shift, const double* gy, double* gx, double* gshift, int N,
+                      int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW,
+                      int normalize_grad, double t_factor, int quantize, void* ws, size_t ws_bytes,
+                      rk_stream_t stream) {
+    return backward_impl<double>(x, shift, gy, gx, gshift, N, T, C, H, W, sT, sH, sW, pT, pH, pW, normalize_grad,
+                                 t_factor, quantize, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// rk_common.hpp -- shared device/host helpers for librubiks_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "rubiks_hip.h"
+
+namespace rk {
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kBlock = 256;    // 4 waves = one per SIMD
+
+// ---- storage <-> compute type mapping (f16/bf16 compute in fp32) -----------------
+template <typename T> struct Compute { using type = T; };
+template <> struct Compute<__half> { using type = float; };
+template <> struct Compute<__hip_bfloat16> { using type = float; };
+
+template <typename T> __device__ __forceinline__ typename Compute<T>::type ld(const T* p) { return *p; }
+template <> __device__ __forceinline__ float ld<__half>(const __half* p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float ld<__hip_bfloat16>(const __hip_bfloat16* p) {
+    return __bfloat162float(*p);
+}
+template <typename T> __device__ __forceinline__ void st(T* p, typename Compute<T>::type v) { *p = v; }
+template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half(v); }
+template <> __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, float v) {
+    *p = __float2bfloat16(v);
+}
+
+// ---- wave / block reductions (deterministic: fixed tree, no float atomics) -------
+template <typename A> __device__ __forceinline__ A wave_sum(A v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+// Sum `v` over groups of `group` consecutive threads (group in {64,128,256}, a divisor of
+// blockDim.x = 256).  Result valid in the first thread of every group.  `smem` must hold
+// kBlock / kWave values of A per reduced quantity; caller passes a distinct slice per call
+// or syncs in between.
+template <typename A> __device__ __forceinline__ A group_sum(A v, int group, A* smem) {
+    v = wave_sum(v);
+    if (group == kWave) return v;              // uniform across the block
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    const int waves_per_group = group / kWave;
+    A r = 0;
+    if (lane == 0 && (wave % waves_per_group) == 0)
+        for (int k = 0; k < waves_per_group; ++k) r += smem[wave + k];
+    __syncthreads();
+    return r;
+}
+
+// ---- host helpers ----------------------------------------------------------------
+inline int out_len(int in, int stride, int pad) { return (in + 2 * pad - 1) / stride + 1; }
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? RK_OK : RK_ERR_LAUNCH; }
+
+inline int pow2_at_least(int v, int lo, int hi) {
+    int p = lo;
+    while (p < v && p < hi) p <<= 1;
+    return p;
+}
+
+}  // namespace rk

@@ -1,0 +1,33 @@
+// rk_misc.hip -- version / error strings / shape helper of the C ABI (include/rubiks_hip.h).
+#include "rk_common.hpp"
+
+extern "C" {
+
+int rk_version(void) { return 1000 * 0 + 1; }
+
+const char* rk_error_string(int code) {
+    switch (code) {
+        case RK_OK: return "ok";
+        case RK_ERR_NULL_POINTER: return "a required device pointer is NULL";
+        case RK_ERR_BAD_DIMS: return "bad dimensions (non-positive, or element count exceeds int32)";
+        case RK_ERR_BAD_STRIDE: return "stride must be > 0 and padding >= 0";
+        case RK_ERR_WORKSPACE: return "workspace is NULL or smaller than *_workspace_bytes()";
+        case RK_ERR_LAUNCH: return "HIP kernel launch failed (hipGetLastError != hipSuccess)";
+        case RK_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return "unknown rubiks_hip error code";
+    }
+}
+
+// cuda_src/rubiks.cpp:14-30 / :161-178
+int rk_out_len(int in, int stride, int pad) {
+    if (stride <= 0) return RK_ERR_BAD_STRIDE;
+    return rk::out_len(in, stride, pad);
+}
+
+int rk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// rk_tshift.hip -- per-channel 3-tap temporal filter, the device half of AttentionShift
+// (rubiksnet/attention_shift.py:32-39) for gfx950.
+//
+// The reference realises y[n,t] = s0*x[n,t-1] + s1*x[n,t] + s2*x[n,t+1] as
+// view -> transpose -> conv1d(groups = C*H*W, inflated [C*H*W,1,3] weight) -> transpose ->
+// contiguous: >= 3 full passes over the activation plus a pathological grouped conv.
+// Here each thread owns VEC contiguous elements of one (n, c) column and walks t with a
+// 3-plane register window, so x is read once and y written once (8 B/elem fp32), 16 B per
+// lane per access when H*W allows.  Backward does the same walk over (gy, x) producing gx
+// and the [C,3] tap gradients through wave-shuffle -> LDS -> per-(n,c) partial -> fixed-order
+// fp64 finalize (no atomics).
+#include "rk_common.hpp"
+
+using namespace rk;
+
+namespace {
+
+struct DimsT {
+    int NB, S, C, HW;   // n_batch, n_segment, channels, H*W
+    int E, logE;        // threads per (n, c) column
+};
+
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_pack(const T* p, typename Compute<T>::type (&o)[VEC]) {
+    const Pack<T, VEC> q = *reinterpret_cast<const Pack<T, VEC>*>(p);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = ld(&q.v[k]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack(T* p, const typename Compute<T>::type (&o)[VEC]) {
+    Pack<T, VEC> q;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) st(&q.v[k], o[k]);
+    *reinterpret_cast<Pack<T, VEC>*>(p) = q;
+}
+
+__device__ __forceinline__ bool my_column(const DimsT& d, int& n, int& c, int& e) {
+    const int sub = threadIdx.x >> d.logE;
+    e = threadIdx.x & (d.E - 1);
+    const long long col = (long long)blockIdx.x * (kBlock >> d.logE) + sub;
+    const bool valid = col < (long long)d.NB * d.C;
+    const long long q = valid ? col : 0;
+    c = (int)(q % d.C);
+    n = (int)(q / d.C);
+    return valid;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict__ x, const float* __restrict__ taps,
+                                                            T* __restrict__ y, DimsT d) {
+    using CT = typename Compute<T>::type;
+    int n, c, e;
+    if (!my_column(d, n, c, e)) return;
+    const CT s0 = (CT)taps[c * 3 + 0], s1 = (CT)taps[c * 3 + 1], s2 = (CT)taps[c * 3 + 2];
+    const size_t tstride = (size_t)d.C * d.HW;
+    const size_t base = ((size_t)n * d.S * d.C + c) * d.HW;
+    for (int i = e * VEC; i < d.HW; i += d.E * VEC) {
+        const T* xp = x + base + i;
+        T* yp = y + base + i;
+        CT prev[VEC], cur[VEC], nxt[VEC], out[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) prev[k] = 0;
+        load_pack<T, VEC>(xp, cur);
+        for (int t = 0; t < d.S; ++t) {
+            if (t + 1 < d.S) load_pack<T, VEC>(xp + (size_t)(t + 1) * tstride, nxt);
+            else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) nxt[k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                out[k] = s0 * prev[k] + s1 * cur[k] + s2 * nxt[k];
+                prev[k] = cur[k];
+                cur[k] = nxt[k];
+            }
+            store_pack<T, VEC>(yp + (size_t)t * tstride, out);
+        }
+    }
+}
+
+// partials part[c][3][P], P = n_batch
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
+                                                             const float* __restrict__ taps, T* __restrict__ gx,
+                                                             typename Compute<T>::type* __restrict__ part, DimsT d) {
+    using CT = typename Compute<T>::type;
+    __shared__ CT red[3][kBlock / kWave];
+    int n, c, e;
+    const bool valid = my_column(d, n, c, e);
+    CT a0 = 0, a1 = 0, a2 = 0;
+    if (valid) {
+        const CT s0 = (CT)taps[c * 3 + 0], s1 = (CT)taps[c * 3 + 1], s2 = (CT)taps[c * 3 + 2];
+        const size_t tstride = (size_t)d.C * d.HW;
+        const size_t base = ((size_t)n * d.S * d.C + c) * d.HW;
+        for (int i = e * VEC; i < d.HW; i += d.E * VEC) {
+            const T* xp = x + base + i;
+            const T* gp = gy + base + i;
+            T* op = gx + base + i;
+            CT xprev[VEC], xcur[VEC], xnxt[VEC], gprev[VEC], gcur[VEC], gnxt[VEC], out[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { xprev[k] = 0; gprev[k] = 0; }
+            load_pack<T, VEC>(xp, xcur);
+            load_pack<T, VEC>(gp, gcur);
+            for (int t = 0; t < d.S; ++t) {
+                if (t + 1 < d.S) {
+                    load_pack<T, VEC>(xp + (size_t)(t + 1) * tstride, xnxt);
+                    load_pack<T, VEC>(gp + (size_t)(t + 1) * tstride, gnxt);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { xnxt[k] = 0; gnxt[k] = 0; }
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    // y[t'] uses x[t'-1+j] with tap j  =>  gx[t] = s0*gy[t+1] + s1*gy[t] + s2*gy[t-1]
+                    out[k] = s0 * gnxt[k] + s1 * gcur[k] + s2 * gprev[k];
+                    a0 += gcur[k] * xprev[k];
+                    a1 += gcur[k] * xcur[k];
+                    a2 += gcur[k] * xnxt[k];
+                    xprev[k] = xcur[k]; xcur[k] = xnxt[k];
+                    gprev[k] = gcur[k]; gcur[k] = gnxt[k];
+                }
+                store_pack<T, VEC>(op + (size_t)t * tstride, out);
+            }
+        }
+    }
+    a0 = group_sum(a0, d.E, red[0]);
+    a1 = group_sum(a1, d.E, red[1]);
+    a2 = group_sum(a2, d.E, red[2]);
+    if (valid && e == 0) {
+        CT* o = part + (size_t)c * 3 * d.NB + n;
+        o[0] = a0;
+        o[d.NB] = a1;
+        o[2 * d.NB] = a2;
+    }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(kBlock) void k_tshift3_finalize(const CT* __restrict__ part, float* __restrict__ gtaps,
+                                                             int P) {
+    __shared__ double red[3][kBlock / kWave];
+    const int c = blockIdx.x;
+    const CT* p = part + (size_t)c * 3 * P;
+    double s[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+        for (int i = threadIdx.x; i < P; i += kBlock) s[k] += (double)p[(size_t)k * P + i];
+    for (int k = 0; k < 3; ++k) s[k] = group_sum(s[k], kBlock, red[k]);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3; ++k) gtaps[c * 3 + k] = (float)s[k];
+}
+
+int make_dimsT(DimsT& d, int NT, int S, int C, int HW, int vec) {
+    if (NT <= 0 || S <= 0 || C <= 0 || HW <= 0 || NT % S != 0) return RK_ERR_BAD_DIMS;
+    if ((long long)NT * C * HW > 0x7fffffffLL) return RK_ERR_BAD_DIMS;
+    d.NB = NT / S; d.S = S; d.C = C; d.HW = HW;
+    d.E = pow2_at_least((HW + vec - 1) / vec, kWave, kBlock);
+    d.logE = (d.E == 64) ? 6 : (d.E == 128 ? 7 : 8);
+    return RK_OK;
+}
+
+unsigned gridT(const DimsT& d) {
+    const int per_block = kBlock / d.E;
+    return (unsigned)(((long long)d.NB * d.C + per_block - 1) / per_block);
+}
+
+template <typename T> constexpr int max_vec() { return 16 / (int)sizeof(T); }   // 16 B per lane
+
+// widest pack that divides H*W and that every pointer is aligned for
+template <typename T>
+int pick_vec(int HW, const void* a, const void* b, const void* c) {
+    int v = max_vec<T>();
+    const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+    while (v > 1 && (HW % v != 0 || bits % (v * sizeof(T)) != 0)) v >>= 1;
+    return v;
+}
+
+template <typename T, int VEC>
+int fwd_launch(const T* x, const float* taps, T* y, int NT, int S, int C, int HW, hipStream_t stream) {
+    DimsT d;
+    if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
+    hipLaunchKernelGGL((k_tshift3_forward<T, VEC>), dim3(gridT(d)), dim3(kBlock), 0, stream, x, taps, y, d);
+    return launch_status();
+}
+
+template <typename T, int VEC>
+int bwd_launch(const T* gy, const T* x, const float* taps, T* gx, float* gtaps, int NT, int S, int C, int HW,
+               void* ws, hipStream_t stream) {
+    using CT = typename Compute<T>::type;
+    DimsT d;
+    if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
+    hipLaunchKernelGGL((k_tshift3_backward<T, VEC>), dim3(gridT(d)), dim3(kBlock), 0, stream, gy, x, taps, gx,
+                       (CT*)ws, d);
+    hipLaunchKernelGGL((k_tshift3_finalize<CT>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gtaps, d.NB);
+    return launch_status();
+}
+
+template <typename T>
+int forwardT(const void* x_, const float* taps, void* y_, int NT, int S, int C, int HW, rk_stream_t stream_) {
+    const T* x = (const T*)x_; T* y = (T*)y_;
+    if (!x || !taps || !y) return RK_ERR_NULL_POINTER;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (HW <= 0) return RK_ERR_BAD_DIMS;
+    switch (pick_vec<T>(HW, x, y, nullptr)) {
+        case 8: if constexpr (max_vec<T>() >= 8) return fwd_launch<T, 8>(x, taps, y, NT, S, C, HW, stream);
+        case 4: if constexpr (max_vec<T>() >= 4) return fwd_launch<T, 4>(x, taps, y, NT, S, C, HW, stream);
+        case 2: return fwd_launch<T, 2>(x, taps, y, NT, S, C, HW, stream);
+        default: return fwd_launch<T, 1>(x, taps, y, NT, S, C, HW, stream);
+    }
+}
+
+template <typename T>
+int backwardT(const void* gy_, const void* x_, const float* taps, void* gx_, float* gtaps, int NT, int S, int C,
+              int HW, void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    const T* gy = (const T*)gy_; const T* x = (const T*)x_; T* gx = (T*)gx_;
+    if (!gy || !x || !taps || !gx || !gtaps) return RK_ERR_NULL_POINTER;
+    if (HW <= 0 || S <= 0) return RK_ERR_BAD_DIMS;
+    if (!ws || ws_bytes < rk_tshift3_backward_workspace_bytes(NT, S, C, HW)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (pick_vec<T>(HW, gy, x, gx)) {
+        case 8: if constexpr (max_vec<T>() >= 8) return bwd_launch<T, 8>(gy, x, taps, gx, gtaps, NT, S, C, HW, ws, stream);
+        case 4: if constexpr (max_vec<T>() >= 4) return bwd_launch<T, 4>(gy, x, taps, gx, gtaps, NT, S, C, HW, ws, stream);
+        case 2: return bwd_launch<T, 2>(gy, x, taps, gx, gtaps, NT, S, C, HW, ws, stream);
+        default: return bwd_launch<T, 1>(gy, x, taps, gx, gtaps, NT, S, C, HW, ws, stream);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk_tshift3_backward_workspace_bytes(int NT, int S, int C, int HW) {
+    (void)HW;
+    if (NT <= 0 || S <= 0 || C <= 0) return 0;
+    return (size_t)C * 3 * (size_t)(NT / S) * 8;   // sized for fp64 partials; fp32 uses half of it
+}
+
+#define RK_DEF_TAP(SFX, TYPE, CTYPE)                                                                           \
+    int rk_tshift3_forward_##SFX(const CTYPE* x, const float* taps, CTYPE* y, int NT, int S, int C, int HW,    \
+                                 rk_stream_t stream) {                                                         \
+        return forwardT<TYPE>(x, taps, y, NT, S, C, HW, stream);                                               \
+    }                                                                                                          \
+    int rk_tshift3_backward_##SFX(const CTYPE* gy, const CTYPE* x, const float* taps, CTYPE* gx, float* gtaps, \
+                                  int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream) { \
+        return backwardT<TYPE>(gy, x, taps, gx, gtaps, NT, S, C, HW, ws, ws_bytes, stream);                    \
+    }
+RK_DEF_TAP(f32, float, float)
+RK_DEF_TAP(f64, double, double)
+RK_DEF_TAP(f16, __half, void)
+RK_DEF_TAP(bf16, __hip_bfloat16, void)
+#undef RK_DEF_TAP
+
+}  // extern "C"
