@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- RubiksShift3D fwd+bwd effective GB/s vs the MI355X HBM roofline (BASELINE.json
+`metric`, configs[1]), plus RubiksNet-Tiny train-step clips/s, next to the CPU oracle.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward + one backward of the operator over one batch of synthetic input,
+x [32, 8, 64, 56, 56] fp32 (layout [N,T,C,H,W]), stride 1, pad 0, normalize_grad on.
+Inputs are resident in HBM before the timed region.  For N > 1 (launched by torchrun, one rank
+per GPU) every rank runs the same per-GPU batch -- the path shards along clips with no
+data-path collective (weak scaling); `value` is the whole-job aggregate.  Rank 0 prints ONE
+JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from rubiksnet_amd import dp, rubiksnet_cuda  # noqa: E402
+
+SHAPE = (32, 8, 64, 56, 56)          # N, T, C, H, W
+HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
+COPY_CEILING_GBS = 6290.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def op_bench(env, steps, warmup, nsets=3):
+    dev = env.device
+    N, T, C, H, W = SHAPE
+    numel = N * T * C * H * W
+    g = torch.Generator(device="cpu").manual_seed(0)
+    shift = (torch.rand(3, C, generator=g) * 2 - 1).to(dev)
+    sets = []
+    for _ in range(nsets):   # rotate buffer sets: one 205 MB tensor fits the 256 MiB Infinity Cache
+        x = torch.empty(SHAPE, device=dev).uniform_(-1, 1)
+        gy = torch.empty(SHAPE, device=dev).uniform_(-1, 1)
+        sets.append((x, gy, torch.empty_like(x), torch.empty_like(x)))
+    gshift = torch.empty(3, C, device=dev)
+    s1, p0 = [1, 1, 1], [0, 0, 0]
+    it = [0]
+    events = []
+
+    def step(record=False):
+        x, gy, y, gx = sets[it[0] % nsets]
+        it[0] += 1
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+        rubiksnet_cuda.rubiks_shift_3d_forward_float(x, shift, s1, p0, False, y)
+        if record:
+            e[1].record()
+        rubiksnet_cuda.rubiks_shift_3d_backward_float(x, shift, gy, s1, p0, gx, gshift, True, 1.0, False)
+        if record:
+            e[2].record()
+            events.append(e)
+
+    for _ in range(warmup):
+        step()
+    elapsed = dp.timed_region(env, lambda: step(True), steps)
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
+    return {
+        "elapsed_s": elapsed, "numel": numel, "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+        "bytes_fwd": 8 * numel, "bytes_bwd": 12 * numel,
+    }
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (a port: the reference has no CPU path) on the host cores, OpenMP over planes,
+    on a bounded sample of the same workload: n clips of [8,64,56,56], fwd+bwd."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    orc.build()
+    threads = os.cpu_count() or 1
+    orc.set_threads(threads)
+    _, T, C, H, W = SHAPE
+    rng = np.random.default_rng(0)
+    shift = rng.uniform(-1, 1, (3, C)).astype(np.float32)
+
+    def run(n):
+        x = rng.uniform(-1, 1, (n, T, C, H, W)).astype(np.float32)
+        gy = rng.uniform(-1, 1, (n, T, C, H, W)).astype(np.float32)
+        t0 = time.perf_counter()
+        orc.rk3d_forward(x, shift)
+        orc.rk3d_backward(gy, x, shift)
+        return time.perf_counter() - t0
+
+    run(1)                                        # warm-up (thread pool, page faults)
+    n = min(32, max(1, threads // 8))             # enough (n, t) planes to occupy every thread
+    reps, dt = 0, 0.0
+    while dt < budget_s and reps < 200:           # bounded sample: ~budget_s seconds of CPU work
+        dt += run(n)
+        reps += 1
+    n *= reps
+    bytes_total = 20 * n * T * C * H * W
+    return {
+        "value": bytes_total / dt / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
+        "sample": "%d clips of [8,64,56,56] fp32 fwd+bwd (same shift/stride/pad as the GPU run), oracle/librubiks_oracle.so, %d OpenMP threads, %.2f s"
+                  % (n, threads, dt),
+        "clips_per_s": n / dt,
+    }
+
+
+def model_bench(env, tier, per_gpu_batch, steps, warmup):
+    from rubiksnet_amd import RubiksNet
+
+    dev = env.device
+    torch.manual_seed(0)
+    net = RubiksNet(tier, num_classes=174, num_frames=8, verbose=False).to(dev)
+    model = dp.wrap_ddp(net, env)
+    opt = dp.make_optimizer(model, lr=1e-3, kind="adam")
+    clips = torch.randn(per_gpu_batch, 8, 3, 224, 224, device=dev)
+    labels = torch.randint(0, 174, (per_gpu_batch,), device=dev)
+    model.train()
+    for _ in range(warmup):
+        dp.train_step(model, opt, clips, labels)
+    dt = dp.timed_region(env, lambda: dp.train_step(model, opt, clips, labels), steps)
+    return {
+        "name": "rubiksnet-%s" % tier, "what": "train step (fwd+bwd+Adam), fp32, synthetic clips",
+        "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * env.world_size, "steps": steps,
+        "ms_per_step": 1e3 * dt / steps, "clips_per_s": per_gpu_batch * env.world_size * steps / dt,
+        "parallelism": "dp%d" % env.world_size,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="tiny", help="tier for the model leg, or 'none'")
+    ap.add_argument("--model-batch", type=int, default=32, help="clips per GPU for the model leg")
+    ap.add_argument("--model-steps", type=int, default=8)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    env = dp.init_distributed()
+    assert env.device.type == "cuda", "bench.py needs a GPU (no CPU fallback for the product path)"
+    assert env.world_size == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world_size)
+
+    r = op_bench(env, args.steps, args.warmup)
+    t_step = r["elapsed_s"] / args.steps
+    bytes_step = r["bytes_fwd"] + r["bytes_bwd"]
+    value = env.world_size * bytes_step / t_step / 1e9
+    bwd_gbs = r["bytes_bwd"] / (r["bwd_ms"] * 1e-3) / 1e9
+    fwd_gbs = r["bytes_fwd"] / (r["fwd_ms"] * 1e-3) / 1e9
+    both_gbs = bytes_step / ((r["fwd_ms"] + r["bwd_ms"]) * 1e-3) / 1e9
+
+    model = None
+    if args.model != "none":
+        try:
+            model = model_bench(env, args.model, args.model_batch, args.model_steps, 3)
+        except Exception as exc:  # the op number must still be reported
+            model = {"error": repr(exc)}
+
+    cpu = None
+    if env.is_main and env.world_size == 1 and not args.no_cpu:
+        cpu = cpu_baseline()
+
+    if env.is_main:
+        out = {
+            "metric": "RubiksShift3D fwd+bwd GB/s vs HBM roofline",
+            "value": value, "unit": "GB/s", "n_gpus": env.world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * t_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "RubiksShift3D fwd+bwd, x [N=32,T=8,C=64,H=56,W=56] fp32 per GPU "
+                            "(layout [N,T,C,H,W]), shift U(-1,1) [3,64], stride 1, pad 0, "
+                            "normalize_grad, 3 rotating buffer sets",
+                "per_gpu_batch": SHAPE[0], "global_batch": SHAPE[0] * env.world_size,
+                "parallelism": "dp%d (clips sharded, no data-path collective)" % env.world_size,
+                "algorithmic_bytes_per_step": bytes_step,
+            },
+            "clips_per_s": env.world_size * SHAPE[0] / t_step,
+            "frac_of_hbm_peak": both_gbs / HBM_PEAK_GBS,
+            "roofline": {
+                "kernel": "rk3d backward (d(x) + d(shift) + finalize)", "bound": "hbm",
+                "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": r["bwd_ms"], "algorithmic_bytes": r["bytes_bwd"],
+                "forward": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS, "avg_launch_ms": r["fwd_ms"],
+                            "algorithmic_bytes": r["bytes_fwd"]},
+                "fwd_plus_bwd": {"achieved": both_gbs, "frac": both_gbs / HBM_PEAK_GBS,
+                                 "frac_of_copy_ceiling": both_gbs / COPY_CEILING_GBS},
+            },
+            "cpu_baseline": cpu,
+            "model": model,
+        }
+        print(json.dumps(out), flush=True)
+    if env.distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

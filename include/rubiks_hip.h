@@ -134,24 +134,24 @@ size_t rk2d_backward_workspace_bytes(int N, int C, int H, int W,
 /* ------------------------------------------------------------ temporal 3-tap
  * The device half of AttentionShift (rubiksnet/attention_shift.py:32-39): the
  * per-channel 3-tap temporal filter the reference runs as transpose -> grouped
- * conv1d(groups=C*H*W) -> transpose -> contiguous.  `taps` is the [C,3] fp32 tensor
- * of already soft-maxed weights (attention_shift.py:29-30, computed on the host side
+ * conv1d(groups=C*H*W) -> transpose -> contiguous.  `taps` is the [C,3] tensor (fp32;
+ * fp64 for the _f64 entry points) of already soft-maxed weights (attention_shift.py:29-30, computed on the host side
  * in PyTorch so autograd owns std/softmax); x, y are [NT, C, H, W] with
  * NT = n_batch * n_segment; zero padding in t.
  *   y[n,t] = taps[c,0]*x[n,t-1] + taps[c,1]*x[n,t] + taps[c,2]*x[n,t+1]
- * backward: gx = adjoint; gtaps[C,3] (fp32) = sum over n,t,h,w of gy * x[t-1+k]. */
-#define RK_DECL_TAP(SFX, TYPE)                                                             \
-    int rk_tshift3_forward_##SFX(const TYPE* x, const float* taps, TYPE* y,                \
+ * backward: gx = adjoint; gtaps[C,3] (same type as taps) = sum over n,t,h,w of gy * x[t-1+k]. */
+#define RK_DECL_TAP(SFX, TYPE, TAPT)                                                       \
+    int rk_tshift3_forward_##SFX(const TYPE* x, const TAPT* taps, TYPE* y,                 \
                                  int NT, int n_segment, int C, int HW, rk_stream_t stream);\
-    int rk_tshift3_backward_##SFX(const TYPE* gy, const TYPE* x, const float* taps,        \
-                                  TYPE* gx, float* gtaps,                                  \
+    int rk_tshift3_backward_##SFX(const TYPE* gy, const TYPE* x, const TAPT* taps,         \
+                                  TYPE* gx, TAPT* gtaps,                                   \
                                   int NT, int n_segment, int C, int HW,                    \
                                   void* workspace, size_t workspace_bytes,                 \
                                   rk_stream_t stream);
-RK_DECL_TAP(f32, float)
-RK_DECL_TAP(f64, double)
-RK_DECL_TAP(f16, void)
-RK_DECL_TAP(bf16, void)
+RK_DECL_TAP(f32, float, float)
+RK_DECL_TAP(f64, double, double)
+RK_DECL_TAP(f16, void, float)
+RK_DECL_TAP(bf16, void, float)
 #undef RK_DECL_TAP
 
 size_t rk_tshift3_backward_workspace_bytes(int NT, int n_segment, int C, int HW);

@@ -34,7 +34,8 @@ class _TemporalShift3Func(torch.autograd.Function):
         nt, c, h, w = x.shape
         assert nt % n_segment == 0, "batch*time (%d) is not a multiple of n_segment (%d)" % (nt, n_segment)
         x = x.contiguous()
-        taps32 = taps.detach().to(torch.float32).contiguous()
+        # the ABI takes taps in the compute type: fp64 for f64 tensors, fp32 otherwise
+        taps32 = taps.detach().to(torch.float64 if x.dtype == torch.float64 else torch.float32).contiguous()
         y = torch.empty_like(x)
         _run("rk_tshift3_forward_" + sfx, x.device, x.data_ptr(), taps32.data_ptr(), y.data_ptr(),
              nt, n_segment, c, h * w)

@@ -42,7 +42,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     Dims3 d;
     if (int rc = make_dims(d, N, Tn, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    if (stream3d::forward_supported<T>(d, quantize)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
+    if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);
     const unsigned grid = grid_for(d, (long long)d.N * d.To * d.C);
     if (quantize)
@@ -65,7 +65,7 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         const size_t need = rk3d_backward_workspace_bytes(N, Tn, C, H, W, sT, sH, sW, pT, pH, pW, (int)sizeof(T));
         if (!ws || ws_bytes < need) return RK_ERR_WORKSPACE;
     }
-    if (stream3d::backward_supported<T>(d, quantize))
+    if (stream3d::backward_supported<T>(d, quantize, x, gy, gx))
         return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
 
     if (gshift) {   // rubiks.cpp:324-358

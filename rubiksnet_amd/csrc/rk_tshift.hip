@@ -48,12 +48,13 @@ __device__ __forceinline__ bool my_column(const DimsT& d, int& n, int& c, int& e
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict__ x, const float* __restrict__ taps,
+__global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict__ x,
+                                                            const typename Compute<T>::type* __restrict__ taps,
                                                             T* __restrict__ y, DimsT d) {
     using CT = typename Compute<T>::type;
     int n, c, e;
     if (!my_column(d, n, c, e)) return;
-    const CT s0 = (CT)taps[c * 3 + 0], s1 = (CT)taps[c * 3 + 1], s2 = (CT)taps[c * 3 + 2];
+    const CT s0 = taps[c * 3 + 0], s1 = taps[c * 3 + 1], s2 = taps[c * 3 + 2];
     const size_t tstride = (size_t)d.C * d.HW;
     const size_t base = ((size_t)n * d.S * d.C + c) * d.HW;
     for (int i = e * VEC; i < d.HW; i += d.E * VEC) {
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
 // partials part[c][3][P], P = n_batch
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
-                                                             const float* __restrict__ taps, T* __restrict__ gx,
+                                                             const typename Compute<T>::type* __restrict__ taps,
+                                                             T* __restrict__ gx,
                                                              typename Compute<T>::type* __restrict__ part, DimsT d) {
     using CT = typename Compute<T>::type;
     __shared__ CT red[3][kBlock / kWave];
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
     const bool valid = my_column(d, n, c, e);
     CT a0 = 0, a1 = 0, a2 = 0;
     if (valid) {
-        const CT s0 = (CT)taps[c * 3 + 0], s1 = (CT)taps[c * 3 + 1], s2 = (CT)taps[c * 3 + 2];
+        const CT s0 = taps[c * 3 + 0], s1 = taps[c * 3 + 1], s2 = taps[c * 3 + 2];
         const size_t tstride = (size_t)d.C * d.HW;
         const size_t base = ((size_t)n * d.S * d.C + c) * d.HW;
         for (int i = e * VEC; i < d.HW; i += d.E * VEC) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
 }
 
 template <typename CT>
-__global__ __launch_bounds__(kBlock) void k_tshift3_finalize(const CT* __restrict__ part, float* __restrict__ gtaps,
+__global__ __launch_bounds__(kBlock) void k_tshift3_finalize(const CT* __restrict__ part, CT* __restrict__ gtaps,
                                                              int P) {
     __shared__ double red[3][kBlock / kWave];
     const int c = blockIdx.x;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_finalize(const CT* __restric
         for (int i = threadIdx.x; i < P; i += kBlock) s[k] += (double)p[(size_t)k * P + i];
     for (int k = 0; k < 3; ++k) s[k] = group_sum(s[k], kBlock, red[k]);
     if (threadIdx.x == 0)
-        for (int k = 0; k < 3; ++k) gtaps[c * 3 + k] = (float)s[k];
+        for (int k = 0; k < 3; ++k) gtaps[c * 3 + k] = (CT)s[k];
 }
 
 int make_dimsT(DimsT& d, int NT, int S, int C, int HW, int vec) {
@@ -176,7 +178,7 @@ int pick_vec(int HW, const void* a, const void* b, const void* c) {
 }
 
 template <typename T, int VEC>
-int fwd_launch(const T* x, const float* taps, T* y, int NT, int S, int C, int HW, hipStream_t stream) {
+int fwd_launch(const T* x, const typename Compute<T>::type* taps, T* y, int NT, int S, int C, int HW, hipStream_t stream) {
     DimsT d;
     if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
     hipLaunchKernelGGL((k_tshift3_forward<T, VEC>), dim3(gridT(d)), dim3(kBlock), 0, stream, x, taps, y, d);
@@ -184,7 +186,8 @@ int fwd_launch(const T* x, const float* taps, T* y, int NT, int S, int C, int HW
 }
 
 template <typename T, int VEC>
-int bwd_launch(const T* gy, const T* x, const float* taps, T* gx, float* gtaps, int NT, int S, int C, int HW,
+int bwd_launch(const T* gy, const T* x, const typename Compute<T>::type* taps, T* gx,
+               typename Compute<T>::type* gtaps, int NT, int S, int C, int HW,
                void* ws, hipStream_t stream) {
     using CT = typename Compute<T>::type;
     DimsT d;
@@ -196,7 +199,7 @@ int bwd_launch(const T* gy, const T* x, const float* taps, T* gx, float* gtaps, 
 }
 
 template <typename T>
-int forwardT(const void* x_, const float* taps, void* y_, int NT, int S, int C, int HW, rk_stream_t stream_) {
+int forwardT(const void* x_, const typename Compute<T>::type* taps, void* y_, int NT, int S, int C, int HW, rk_stream_t stream_) {
     const T* x = (const T*)x_; T* y = (T*)y_;
     if (!x || !taps || !y) return RK_ERR_NULL_POINTER;
     hipStream_t stream = (hipStream_t)stream_;
@@ -210,7 +213,8 @@ int forwardT(const void* x_, const float* taps, void* y_, int NT, int S, int C, 
 }
 
 template <typename T>
-int backwardT(const void* gy_, const void* x_, const float* taps, void* gx_, float* gtaps, int NT, int S, int C,
+int backwardT(const void* gy_, const void* x_, const typename Compute<T>::type* taps, void* gx_,
+              typename Compute<T>::type* gtaps, int NT, int S, int C,
               int HW, void* ws, size_t ws_bytes, rk_stream_t stream_) {
     const T* gy = (const T*)gy_; const T* x = (const T*)x_; T* gx = (T*)gx_;
     if (!gy || !x || !taps || !gx || !gtaps) return RK_ERR_NULL_POINTER;
@@ -235,19 +239,19 @@ size_t rk_tshift3_backward_workspace_bytes(int NT, int S, int C, int HW) {
     return (size_t)C * 3 * (size_t)(NT / S) * 8;   // sized for fp64 partials; fp32 uses half of it
 }
 
-#define RK_DEF_TAP(SFX, TYPE, CTYPE)                                                                           \
-    int rk_tshift3_forward_##SFX(const CTYPE* x, const float* taps, CTYPE* y, int NT, int S, int C, int HW,    \
+#define RK_DEF_TAP(SFX, TYPE, CTYPE, TAPT)                                                                     \
+    int rk_tshift3_forward_##SFX(const CTYPE* x, const TAPT* taps, CTYPE* y, int NT, int S, int C, int HW,     \
                                  rk_stream_t stream) {                                                         \
         return forwardT<TYPE>(x, taps, y, NT, S, C, HW, stream);                                               \
     }                                                                                                          \
-    int rk_tshift3_backward_##SFX(const CTYPE* gy, const CTYPE* x, const float* taps, CTYPE* gx, float* gtaps, \
+    int rk_tshift3_backward_##SFX(const CTYPE* gy, const CTYPE* x, const TAPT* taps, CTYPE* gx, TAPT* gtaps,   \
                                   int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream) { \
         return backwardT<TYPE>(gy, x, taps, gx, gtaps, NT, S, C, HW, ws, ws_bytes, stream);                    \
     }
-RK_DEF_TAP(f32, float, float)
-RK_DEF_TAP(f64, double, double)
-RK_DEF_TAP(f16, __half, void)
-RK_DEF_TAP(bf16, __hip_bfloat16, void)
+RK_DEF_TAP(f32, float, float, float)
+RK_DEF_TAP(f64, double, double, double)
+RK_DEF_TAP(f16, __half, void, float)
+RK_DEF_TAP(bf16, __hip_bfloat16, void, float)
 #undef RK_DEF_TAP
 
 }  // extern "C"

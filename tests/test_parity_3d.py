@@ -1,0 +1,215 @@
+"""GPU parity: RubiksShift3D through the C ABI (rubiksnet_amd.rubiksnet_cuda -> librubiks_hip.so)
+versus the CPU oracle on identical seeded inputs.
+
+Bars: forward and d(x) BIT-EXACT in fp32 and fp64 (both sides evaluate the reference's
+expression tree with FP contraction off; quantize is a pure gather); d(shift) within
+1e-5 (relative to the gradient's scale) of the oracle evaluated in fp64.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import rand, seed_of, special_shifts, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # N, T, C, H, W, stride, padding
+    (2, 8, 16, 14, 14, (1, 1, 1), (0, 0, 0)),      # BASELINE configs[0] plumbing shape
+    (2, 8, 6, 56, 56, (1, 1, 1), (0, 0, 0)),       # benchmark plane size
+    (3, 8, 9, 7, 7, (1, 1, 1), (0, 0, 0)),         # small-plane regime (4 planes per workgroup)
+    (1, 4, 5, 28, 28, (1, 2, 2), (0, 0, 0)),       # the networks' down-sampling layers
+    (2, 3, 4, 9, 7, (1, 2, 2), (0, 1, 1)),
+    (1, 6, 3, 10, 11, (2, 1, 3), (1, 2, 0)),       # stride/pad in T too
+    (1, 1, 2, 5, 5, (1, 1, 1), (0, 0, 0)),         # T = 1
+    (2, 8, 3, 112, 112, (1, 2, 2), (0, 0, 0)),     # first stage of the nets
+]
+KINDS = ["generic", "wide", "integer", "half", "oob"]
+
+
+def _run_fwd(x, shift, s, p, q):
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_forward
+    return to_np(rubiks_shift_3d_forward(to_dev(x), to_dev(shift), s, p, quantize=q))
+
+
+def _run_bwd(gy, x, shift, s, p, q, normalize=True, tf=1.0):
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
+    gx, gs = rubiks_shift_3d_backward(to_dev(gy), to_dev(x), to_dev(shift), s, p, normalize,
+                                      normalize_t_factor=tf, quantize=q)
+    return to_np(gx), to_np(gs)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("quantize", [False, True])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("cfg", SHAPES)
+def test_forward_and_input_grad_bit_exact(oracle, cfg, kind, quantize, dtype):
+    N, T, C, H, W, s, p = cfg
+    rng = np.random.default_rng(seed_of(cfg, kind))
+    x = rand(rng, (N, T, C, H, W), dtype)
+    shift = special_shifts(rng, 3, C, dtype, kind)
+    y_ref = oracle.rk3d_forward(x, shift, s, p, quantize)
+    y = _run_fwd(x, shift, s, p, quantize)
+    assert y.shape == y_ref.shape
+    np.testing.assert_array_equal(y, y_ref)
+    gy = rand(rng, y_ref.shape, dtype)
+    gx_ref, _ = oracle.rk3d_backward(gy, x, shift, s, p, quantize=quantize)
+    gx, _ = _run_bwd(gy, x, shift, s, p, quantize)
+    np.testing.assert_array_equal(gx, gx_ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["generic", "wide", "integer", "oob"])
+@pytest.mark.parametrize("cfg", SHAPES)
+def test_shift_grad_matches_fp64_oracle(oracle, cfg, kind, dtype):
+    N, T, C, H, W, s, p = cfg
+    rng = np.random.default_rng(seed_of(cfg, kind, "g"))
+    x = rand(rng, (N, T, C, H, W), dtype)
+    shift = special_shifts(rng, 3, C, dtype, kind)
+    gy = rand(rng, oracle.rk3d_forward(x, shift, s, p).shape, dtype)
+    x64, s64, g64 = x.astype(np.float64), shift.astype(np.float64), gy.astype(np.float64)
+    _, _, raw_ref = oracle.rk3d_backward(g64, x64, s64, s, p, normalize_grad=False, return_raw=True)
+    _, raw = _run_bwd(gy, x, shift, s, p, False, normalize=False)
+    scale = max(1.0, float(np.abs(raw_ref).max()))
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(raw, raw_ref, rtol=0, atol=tol * scale)
+    # normalised (K5), default t_factor and the two other branches
+    for tf in (1.0, 0.25, -1.0):
+        _, g_ref = oracle.rk3d_backward(g64, x64, s64, s, p, normalize_grad=True, normalize_t_factor=tf)
+        _, g = _run_bwd(gy, x, shift, s, p, False, normalize=True, tf=tf)
+        np.testing.assert_allclose(g, g_ref, rtol=0, atol=(2e-5 if dtype == np.float32 else 1e-11))
+
+
+def test_autograd_function_and_module(oracle):
+    """rubiks_shift_3d (Function) and RubiksShift3D (Module) wire the same numbers through autograd."""
+    from rubiksnet_amd.shiftlib import RubiksShift3D
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import RubiksShift3DFunc, rubiks_shift_3d
+
+    rng = np.random.default_rng(11)
+    x = rand(rng, (2, 8, 16, 14, 14), np.float32)
+    gy = rand(rng, x.shape, np.float32)
+    mod = RubiksShift3D(16).to("cuda:0")
+    shift = to_np(mod.shift)
+    xt = to_dev(x).requires_grad_(True)
+    y = mod(xt)
+    y.backward(to_dev(gy))
+    np.testing.assert_array_equal(to_np(y), oracle.rk3d_forward(x, shift))
+    gx_ref, gs_ref = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64))
+    np.testing.assert_allclose(to_np(xt.grad), gx_ref, atol=1e-6)
+    np.testing.assert_allclose(to_np(mod.shift.grad), gs_ref, atol=2e-5)
+    # Function returns (x_grad, shift_grad, None x 5); "auto" t-factor = T / H
+    y2 = rubiks_shift_3d(xt, mod.shift, normalize_t_factor="auto")
+    assert y2.grad_fn is not None and RubiksShift3DFunc.__name__ == "RubiksShift3DFunc"
+    mod.shift.grad = None
+    y2.backward(to_dev(gy))
+    _, gs_auto = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64),
+                                      normalize_t_factor=8 / 14)
+    np.testing.assert_allclose(to_np(mod.shift.grad), gs_auto, atol=2e-5)
+    # frozen shift: only d(x) is produced
+    xt2 = to_dev(x).requires_grad_(True)
+    rubiks_shift_3d(xt2, mod.shift.detach()).backward(to_dev(gy))
+    np.testing.assert_allclose(to_np(xt2.grad), gx_ref, atol=1e-6)
+
+
+def test_gradcheck_fp64():
+    """BASELINE configs[1]: gradcheck of the op in fp64 (shifts kept away from integers, raw grads)."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d
+
+    torch.manual_seed(0)
+    x = (torch.rand(1, 3, 2, 4, 5, dtype=torch.float64, device="cuda:0") * 2 - 1).requires_grad_(True)
+    shift = torch.tensor([[0.3, -0.6], [0.45, 1.2], [-0.7, 0.15]], dtype=torch.float64, device="cuda:0",
+                         requires_grad=True)
+    for stride, pad in [(1, 0), ((1, 2, 2), (0, 1, 1))]:
+        fn = lambda a, b: rubiks_shift_3d(a, b, stride, pad, False, 1.0, False)  # noqa: E731
+        assert torch.autograd.gradcheck(fn, (x, shift), eps=1e-6, atol=1e-7, nondet_tol=0.0)
+
+
+def test_errors_are_raised_not_fatal():
+    from rubiksnet_amd import rubiksnet_cuda
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_forward
+
+    x = torch.zeros(1, 2, 3, 4, 4, device="cuda:0")
+    sh = torch.zeros(3, 3, device="cuda:0")
+    with pytest.raises(ValueError):
+        rubiks_shift_3d_forward(x.half(), sh.half(), 1, 0)
+    with pytest.raises(AssertionError):
+        rubiks_shift_3d_forward(x.cpu(), sh.cpu(), 1, 0)
+    with pytest.raises(RuntimeError):      # non-contiguous input reaches the binding
+        rubiksnet_cuda.rubiks_shift_3d_forward_float(x.transpose(3, 4), sh, [1, 1, 1], [0, 0, 0], False, x.clone())
+    with pytest.raises(RuntimeError):      # bad stride -> RK_ERR_BAD_STRIDE, not a crash
+        rubiksnet_cuda.rubiks_shift_3d_forward_float(x, sh, [0, 1, 1], [0, 0, 0], False, x.clone())
+
+
+# ----------------------------------------------------------------- BASELINE full size
+FULL = (32, 8, 64, 56, 56)
+
+
+@pytest.fixture(scope="module")
+def full():
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    x = torch.rand(FULL, device="cuda:0", generator=g) * 2 - 1
+    gy = torch.rand(FULL, device="cuda:0", generator=g) * 2 - 1
+    shift = torch.rand(3, 64, device="cuda:0", generator=g) * 2 - 1
+    return x, gy, shift
+
+
+def test_full_size_slices_bit_exact_vs_oracle(oracle, full):
+    """(32,8,64,56,56): clips are independent, so clip 0 / 17 / 31 of the full-size result must equal
+    the oracle run on that clip alone."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward, rubiks_shift_3d_forward
+
+    x, gy, shift = full
+    y = rubiks_shift_3d_forward(x, shift, 1, 0)
+    gx, _ = rubiks_shift_3d_backward(gy, x, shift, 1, 0, True)
+    sh = to_np(shift)
+    for n in (0, 17, 31):
+        xn, gn = to_np(x[n:n + 1]), to_np(gy[n:n + 1])
+        np.testing.assert_array_equal(to_np(y[n:n + 1]), oracle.rk3d_forward(xn, sh))
+        gx_ref, _ = oracle.rk3d_backward(gn, xn, sh)
+        np.testing.assert_array_equal(to_np(gx[n:n + 1]), gx_ref)
+
+
+def test_full_size_adjoint_and_linearity(full):
+    """Size-independent properties at full size: <fwd(x), gy> == <x, d(x)>, and raw d(shift) is additive
+    over a partition of the batch."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward, rubiks_shift_3d_forward
+
+    x, gy, shift = full
+    y = rubiks_shift_3d_forward(x, shift, 1, 0)
+    gx, raw = rubiks_shift_3d_backward(gy, x, shift, 1, 0, False)
+    lhs = torch.dot(y.double().flatten(), gy.double().flatten()).item()
+    rhs = torch.dot(x.double().flatten(), gx.double().flatten()).item()
+    assert lhs == pytest.approx(rhs, rel=1e-6)
+    parts = torch.zeros_like(raw, dtype=torch.float64)
+    for lo in range(0, 32, 8):
+        _, r = rubiks_shift_3d_backward(gy[lo:lo + 8].contiguous(), x[lo:lo + 8].contiguous(), shift, 1, 0, False)
+        parts += r.double()
+    np.testing.assert_allclose(to_np(raw), to_np(parts), rtol=0, atol=1e-5 * float(parts.abs().max()))
+
+
+def test_full_size_shift_grad_vs_oracle_subbatch(oracle, full):
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
+
+    x, gy, shift = full
+    xs, gs = x[:4].contiguous(), gy[:4].contiguous()
+    _, g = rubiks_shift_3d_backward(gs, xs, shift, 1, 0, True)
+    _, g_ref = oracle.rk3d_backward(to_np(gs).astype(np.float64), to_np(xs).astype(np.float64),
+                                    to_np(shift).astype(np.float64))
+    np.testing.assert_allclose(to_np(g), g_ref, rtol=0, atol=1e-5)
+
+
+def test_full_size_quantize_is_translation(full):
+    """quantize=True at full size equals an independent torch translate (pad + slice) per channel."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_forward
+
+    x, _, shift = full
+    y = rubiks_shift_3d_forward(x, shift, 1, 0, quantize=True)
+    sh = to_np(shift)
+    fl = np.floor(sh.astype(np.float32)).astype(np.int64)
+    q = np.where((sh - fl) < 0.5, fl, fl + 1)
+    P = 3
+    xp = torch.nn.functional.pad(x, (P, P, P, P, 0, 0, P, P))      # pad W, H, (C none), T
+    for c in (0, 5, 33, 63):
+        qt, qh, qw = (int(v) for v in q[:, c])
+        want = xp[:, P + qt:P + qt + 8, c, P + qh:P + qh + 56, P + qw:P + qw + 56]
+        assert torch.equal(y[:, :, c], want)
