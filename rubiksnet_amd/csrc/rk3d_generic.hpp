@@ -141,23 +141,21 @@ __device__ __forceinline__ int unmap(int p, int s, int lim) {
     return (q >= 0 && q < lim) ? q : -1;
 }
 
+// One input plane (n, t, c) of d(x), computed by the E threads e = 0..E-1 that call it.
 template <typename T, bool QUANT>
-__global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __restrict__ shift,
-                                                                     const T* __restrict__ gy,
-                                                                     T* __restrict__ gx, Dims3 d) {
-    int e;
-    const PlaneId pl = my_plane(d, d.T, e);   // planes of the INPUT
-    if (!pl.valid) return;
-    const T nT = -shift[pl.c], nH = -shift[d.C + pl.c], nW = -shift[2 * d.C + pl.c];
+__device__ __forceinline__ void backward_input_plane(const T* __restrict__ shift, const T* __restrict__ gy,
+                                                     T* __restrict__ gx, const Dims3& d, int n, int t, int c,
+                                                     int e, int E) {
+    const T nT = -shift[c], nH = -shift[d.C + c], nW = -shift[2 * d.C + c];
     const Frac<T> fT = split_shift(nT), fH = split_shift(nH), fW = split_shift(nW);
     const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
     const size_t tstride = (size_t)d.C * HWo;
-    const T* gc = gy + ((size_t)pl.n * d.To * d.C + pl.c) * HWo;   // (n, to=0, c)
-    T* gp = gx + (((size_t)pl.n * d.T + pl.t) * d.C + pl.c) * HW;
-    const int oT = pl.t + d.pT;
+    const T* gc = gy + ((size_t)n * d.To * d.C + c) * HWo;   // (n, to=0, c)
+    T* gp = gx + (((size_t)n * d.T + t) * d.C + c) * HW;
+    const int oT = t + d.pT;
 
     int h = e / d.W, w = e - h * d.W;
-    const int dh = d.E / d.W, dw = d.E - dh * d.W;
+    const int dh = E / d.W, dw = E - dh * d.W;
 
     // 0 = single tap at the nearest position (quantize), 1 = all shifts exactly zero
     // (rubiks3d_kernels.cu:561-576), 2 = trilinear
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __
         const int aW = QUANT ? ((fW.r < 0.5f) ? fW.fl : fW.fl + 1) : 0;
         const int tt = unmap(oT + aT, d.sT, d.To);
         const T* p = gc + (tt >= 0 ? (size_t)tt * tstride : 0);
-        for (int i = e; i < HW; i += d.E) {
+        for (int i = e; i < HW; i += E) {
             const int hh = unmap(h + d.pH + aH, d.sH, d.Ho), ww = unmap(w + d.pW + aW, d.sW, d.Wo);
             T v = 0;
             if (tt >= 0 && hh >= 0 && ww >= 0) v = p[hh * d.Wo + ww];
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __
     const int t0 = unmap(oT + fT.fl, d.sT, d.To), t1 = unmap(oT + fT.fl + 1, d.sT, d.To);
     const T* p0 = gc + (t0 >= 0 ? (size_t)t0 * tstride : 0);
     const T* p1 = gc + (t1 >= 0 ? (size_t)t1 * tstride : 0);
-    for (int i = e; i < HW; i += d.E) {
+    for (int i = e; i < HW; i += E) {
         const int h0 = unmap(h + d.pH + fH.fl, d.sH, d.Ho), h1 = unmap(h + d.pH + fH.fl + 1, d.sH, d.Ho);
         const int w0 = unmap(w + d.pW + fW.fl, d.sW, d.Wo), w1 = unmap(w + d.pW + fW.fl + 1, d.sW, d.Wo);
         T q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
@@ -204,6 +202,16 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __
     }
 }
 
+template <typename T, bool QUANT>
+__global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __restrict__ shift,
+                                                                     const T* __restrict__ gy,
+                                                                     T* __restrict__ gx, Dims3 d) {
+    int e;
+    const PlaneId pl = my_plane(d, d.T, e);   // planes of the INPUT
+    if (!pl.valid) return;
+    backward_input_plane<T, QUANT>(shift, gy, gx, d, pl.n, pl.t, pl.c, e, d.E);
+}
+
 // ------------------------------------------------------------------------------ K2
 // d(shift) partials.  For every output element the reference forms, per dimension, the
 // difference between the bilinear interpolation of the "large" face and of the "small"
@@ -212,6 +220,60 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __
 // used by every tap on that face (:359-431) -- reproduced through `lo`.
 //
 // Partials layout: part[c][3][P], P = N*To, p = n*To + to.
+// This thread's share of the d(shift) terms of one output plane (n, to, c) (E cooperating threads).
+template <typename T>
+__device__ __forceinline__ void shift_grad_plane(const T* __restrict__ x, const T* __restrict__ shift,
+                                                 const T* __restrict__ gy, const Dims3& d, int n, int to, int c,
+                                                 int e, int E, T& aT, T& aH, T& aW) {
+    const Frac<T> fT = split_shift(shift[c]);
+    const Frac<T> fH = split_shift(shift[d.C + c]);
+    const Frac<T> fW = split_shift(shift[2 * d.C + c]);
+    const int zT = (fT.r == 0) ? 1 : 0, zH = (fH.r == 0) ? 1 : 0, zW = (fW.r == 0) ? 1 : 0;
+    const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
+    const size_t tstride = (size_t)d.C * HW;
+    const T* xc = x + ((size_t)n * d.T * d.C + c) * HW;
+    const T* gp = gy + (((size_t)n * d.To + to) * d.C + c) * HWo;
+    const int bT = to * d.sT - d.pT;
+    const int t0 = bT + fT.fl - zT, t1 = bT + fT.fl + 1;
+    const bool v0 = t0 >= 0 && t0 < d.T, v1 = t1 >= 0 && t1 < d.T;
+    const T* p0 = xc + (v0 ? (size_t)t0 * tstride : 0);
+    const T* p1 = xc + (v1 ? (size_t)t1 * tstride : 0);
+
+    int ho = e / d.Wo, wo = e - ho * d.Wo;
+    const int dh = E / d.Wo, dw = E - dh * d.Wo;
+    for (int i = e; i < HWo; i += E) {
+        const int hb = ho * d.sH - d.pH + fH.fl, wb = wo * d.sW - d.pW + fW.fl;
+        const int h0 = hb - zH, h1 = hb + 1, w0 = wb - zW, w1 = wb + 1;
+        const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h1 >= 0 && h1 < d.H;
+        const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w1 >= 0 && w1 < d.W;
+        T q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
+        if (v0) {
+            if (mh0 && mw0) q000 = p0[h0 * d.W + w0];
+            if (mh0 && mw1) q001 = p0[h0 * d.W + w1];
+            if (mh1 && mw0) q010 = p0[h1 * d.W + w0];
+            if (mh1 && mw1) q011 = p0[h1 * d.W + w1];
+        }
+        if (v1) {
+            if (mh0 && mw0) q100 = p1[h0 * d.W + w0];
+            if (mh0 && mw1) q101 = p1[h0 * d.W + w1];
+            if (mh1 && mw0) q110 = p1[h1 * d.W + w0];
+            if (mh1 && mw1) q111 = p1[h1 * d.W + w1];
+        }
+        const T Ts = interp2(q000, q001, q010, q011, fH.r, fW.r);
+        const T Tl = interp2(q100, q101, q110, q111, fH.r, fW.r);
+        const T Hs = interp2(q000, q001, q100, q101, fT.r, fW.r);
+        const T Hl = interp2(q010, q011, q110, q111, fT.r, fW.r);
+        const T Ws = interp2(q000, q010, q100, q110, fT.r, fH.r);
+        const T Wl = interp2(q001, q011, q101, q111, fT.r, fH.r);
+        const T up = gp[i];
+        aT += (-Ts + Tl) * up;
+        aH += (-Hs + Hl) * up;
+        aW += (-Ws + Wl) * up;
+        wo += dw; ho += dh;
+        if (wo >= d.Wo) { wo -= d.Wo; ++ho; }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k3d_backward_shift_generic(const T* __restrict__ x,
                                                                      const T* __restrict__ shift,
@@ -221,55 +283,7 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_shift_generic(const T* __
     int e;
     const PlaneId pl = my_plane(d, d.To, e);
     T aT = 0, aH = 0, aW = 0;
-    if (pl.valid) {
-        const Frac<T> fT = split_shift(shift[pl.c]);
-        const Frac<T> fH = split_shift(shift[d.C + pl.c]);
-        const Frac<T> fW = split_shift(shift[2 * d.C + pl.c]);
-        const int zT = (fT.r == 0) ? 1 : 0, zH = (fH.r == 0) ? 1 : 0, zW = (fW.r == 0) ? 1 : 0;
-        const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
-        const size_t tstride = (size_t)d.C * HW;
-        const T* xc = x + ((size_t)pl.n * d.T * d.C + pl.c) * HW;
-        const T* gp = gy + (((size_t)pl.n * d.To + pl.t) * d.C + pl.c) * HWo;
-        const int bT = pl.t * d.sT - d.pT;
-        const int t0 = bT + fT.fl - zT, t1 = bT + fT.fl + 1;
-        const bool v0 = t0 >= 0 && t0 < d.T, v1 = t1 >= 0 && t1 < d.T;
-        const T* p0 = xc + (v0 ? (size_t)t0 * tstride : 0);
-        const T* p1 = xc + (v1 ? (size_t)t1 * tstride : 0);
-
-        int ho = e / d.Wo, wo = e - ho * d.Wo;
-        const int dh = d.E / d.Wo, dw = d.E - dh * d.Wo;
-        for (int i = e; i < HWo; i += d.E) {
-            const int hb = ho * d.sH - d.pH + fH.fl, wb = wo * d.sW - d.pW + fW.fl;
-            const int h0 = hb - zH, h1 = hb + 1, w0 = wb - zW, w1 = wb + 1;
-            const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h1 >= 0 && h1 < d.H;
-            const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w1 >= 0 && w1 < d.W;
-            T q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
-            if (v0) {
-                if (mh0 && mw0) q000 = p0[h0 * d.W + w0];
-                if (mh0 && mw1) q001 = p0[h0 * d.W + w1];
-                if (mh1 && mw0) q010 = p0[h1 * d.W + w0];
-                if (mh1 && mw1) q011 = p0[h1 * d.W + w1];
-            }
-            if (v1) {
-                if (mh0 && mw0) q100 = p1[h0 * d.W + w0];
-                if (mh0 && mw1) q101 = p1[h0 * d.W + w1];
-                if (mh1 && mw0) q110 = p1[h1 * d.W + w0];
-                if (mh1 && mw1) q111 = p1[h1 * d.W + w1];
-            }
-            const T Ts = interp2(q000, q001, q010, q011, fH.r, fW.r);
-            const T Tl = interp2(q100, q101, q110, q111, fH.r, fW.r);
-            const T Hs = interp2(q000, q001, q100, q101, fT.r, fW.r);
-            const T Hl = interp2(q010, q011, q110, q111, fT.r, fW.r);
-            const T Ws = interp2(q000, q010, q100, q110, fT.r, fH.r);
-            const T Wl = interp2(q001, q011, q101, q111, fT.r, fH.r);
-            const T up = gp[i];
-            aT += (-Ts + Tl) * up;
-            aH += (-Hs + Hl) * up;
-            aW += (-Ws + Wl) * up;
-            wo += dw; ho += dh;
-            if (wo >= d.Wo) { wo -= d.Wo; ++ho; }
-        }
-    }
+    if (pl.valid) shift_grad_plane<T>(x, shift, gy, d, pl.n, pl.t, pl.c, e, d.E, aT, aH, aW);
     aT = group_sum(aT, d.E, red[0]);
     aH = group_sum(aH, d.E, red[1]);
     aW = group_sum(aW, d.E, red[2]);

@@ -325,6 +325,129 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_shift_grad(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused backward: d(x) and the d(shift) partials in ONE pass over (gy, x) -- 12 B/elem instead of
+// the 16 B/elem of k3d_stream_shift_grad + k3d_stream_interp<true>.
+//
+// Adjoint form: with the negated shift (fl', r') the reference's d(x) is
+//     gx[t] = (1-r'T) Q(t+fl'T) + r'T Q(t+fl'T+1),   Q(tg) = bilinear(gy[tg]; fl'H, fl'W, r'H, r'W)
+// (rubiks3d_kernels.cu:914-924, evaluated in that exact tree => bit-identical), and because
+// y is linear in x the shift gradients can be collected on the INPUT side from the same taps:
+//     gT = sum_x x[t] * (Q(t+fl'T) - Q(t+fl'T+1))
+//     gH = sum_x x[t] * ((1-r'T) QH(t+fl'T) + r'T QH(t+fl'T+1)),  QH = lerpW'(row A) - lerpW'(row B)
+//     gW = likewise with QW = lerpH'(col k) - lerpH'(col k+1)
+// so only gy needs the LDS tile; x is read at the thread's own (aligned) cells, 16 B per lane,
+// through a 2-plane register window (x[to], x[to+1]) + one plane in flight.
+// Regrouped per gy plane tg (to = tg - fl'T - 1):
+//     sT += Q(tg) * (x[to+1] - x[to]);   sH += QH(tg) * ((1-r'T) x[to+1] + r'T x[to]);   sW alike.
+template <int ROUNDS>
+__global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float* __restrict__ x,
+                                                                    const float* __restrict__ shift,
+                                                                    const float* __restrict__ gy,
+                                                                    float* __restrict__ gx,
+                                                                    float* __restrict__ part, SDims d, Dims3 gd) {
+    extern __shared__ __attribute__((aligned(16))) float4 tile[];
+    __shared__ float red[3][kBlock / kWave];
+    const int c = blockIdx.x % d.C, n = blockIdx.x / d.C;
+    const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
+    float accT = 0.f, accH = 0.f, accW = 0.f;
+
+    if (split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0) {
+        // exactly-integer component (lowered-index quirk / zero-shift copy branch): rare, per element
+        for (int t = 0; t < d.T; ++t) backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+        for (int to = 0; to < d.T; ++to)
+            shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
+    } else {
+        const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r'
+        const int HW = d.H * d.W;
+        const size_t tstride = (size_t)d.C * HW;
+        const float* xp = x + ((size_t)n * d.T * d.C + c) * HW;
+        const float* gp = gy + ((size_t)n * d.T * d.C + c) * HW;
+        float* op = gx + ((size_t)n * d.T * d.C + c) * HW;
+
+        const int off = ((fW.fl % 4) + 4) % 4;
+        Cells<ROUNDS> cs;
+        make_cells<ROUNDS>(cs, d, fH.fl, (fW.fl - off) / 4);
+        zero_halo(tile, d);
+        const float rT = fT.r, rH = fH.r, rW = fW.r;
+        const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
+
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 gpre[ROUNDS], xpre[ROUNDS], xa[ROUNDS], xb[ROUNDS], Qprev[ROUNDS];
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) gpre[i] = xpre[i] = xa[i] = xb[i] = Qprev[i] = z4;
+        float sT = 0.f, sH = 0.f, sW = 0.f;
+
+        const int t_first = fT.fl, t_last = d.T + fT.fl;          // gy plane index tg; T+1 steps
+        fetch_plane<ROUNDS>(gpre, cs, gp, t_first, d.T, tstride);
+        fetch_plane<ROUNDS>(xb, cs, xp, 0, d.T, tstride);          // x[to+1] of the first step (to = -1)
+        for (int tg = t_first; tg <= t_last; ++tg) {
+            const bool valid = tg >= 0 && tg < d.T;
+            const int to = tg - fT.fl - 1;
+            const bool emit = to >= 0;                              // to <= T-1 always
+            if (valid) stash_plane<ROUNDS>(tile, gpre, cs);
+            __syncthreads();
+            fetch_plane<ROUNDS>(gpre, cs, gp, tg + 1, d.T, tstride);
+            if (to + 2 < d.T) fetch_plane<ROUNDS>(xpre, cs, xp, to + 2, d.T, tstride);
+            else {
+#pragma unroll
+                for (int i = 0; i < ROUNDS; ++i) xpre[i] = z4;
+            }
+            float4* out = reinterpret_cast<float4*>(op + (size_t)(emit ? to : 0) * tstride);
+#pragma unroll
+            for (int i = 0; i < ROUNDS; ++i) {
+                if (!wave_round_on(i, d.cells)) continue;
+                float4 Qc = z4;
+                if (valid) {
+                    float a[5], b[5], col[5], q[4];
+                    pick5(tile[cs.rowA[i] + cs.g0[i]], tile[cs.rowA[i] + cs.g1[i]], off, a);
+                    pick5(tile[cs.rowB[i] + cs.g0[i]], tile[cs.rowB[i] + cs.g1[i]], off, b);
+                    const float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
+                    const float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) col[k] = fmaf(uH, a[k], rH * b[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float la = a[k] * uW + a[k + 1] * rW, lb = b[k] * uW + b[k + 1] * rW;
+                        q[k] = uH * la + rH * lb;                   // the reference's tree, contraction off
+                        if (cs.live[i]) {
+                            const float dx = xbv[k] - xav[k];
+                            const float mx = fmaf(uT, xbv[k], rT * xav[k]);
+                            sT = fmaf(q[k], dx, sT);
+                            sH = fmaf(la - lb, mx, sH);
+                            sW = fmaf(col[k] - col[k + 1], mx, sW);
+                        }
+                    }
+                    Qc = make_float4(q[0], q[1], q[2], q[3]);
+                }
+                if (emit && cs.live[i]) {
+                    float4 o;
+                    o.x = uT * Qprev[i].x + rT * Qc.x;
+                    o.y = uT * Qprev[i].y + rT * Qc.y;
+                    o.z = uT * Qprev[i].z + rT * Qc.z;
+                    o.w = uT * Qprev[i].w + rT * Qc.w;
+                    out[cs.cell[i]] = o;
+                }
+                Qprev[i] = Qc;
+            }
+#pragma unroll
+            for (int i = 0; i < ROUNDS; ++i) { xa[i] = xb[i]; xb[i] = xpre[i]; }
+            __syncthreads();
+        }
+        accT = sT; accH = sH; accW = sW;
+    }
+
+    accT = group_sum(accT, kBlock, red[0]);
+    accH = group_sum(accH, kBlock, red[1]);
+    accW = group_sum(accW, kBlock, red[2]);
+    if (threadIdx.x == 0) {
+        float* o = part + (size_t)c * 3 * d.N + n;
+        o[0] = accT;
+        o[d.N] = accH;
+        o[2 * d.N] = accW;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 inline bool env_force_generic() {
     static const bool v = [] { const char* e = getenv("RK_FORCE_GENERIC"); return e && e[0] == '1'; }();
     return v;
@@ -388,6 +511,19 @@ template <>
 inline int launch_backward<float>(const float* x, const float* shift, const float* gy, float* gx, float* gshift,
                                   const Dims3& d, int normalize, float t_factor, float* ws, hipStream_t stream) {
     const SDims s = make_sdims(d);
+    if (gshift && gx) {
+        const size_t lds = (size_t)(s.H + 1) * s.Wp * sizeof(float);
+        const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);
+        switch ((s.cells + kBlock - 1) / kBlock) {
+            case 1: hipLaunchKernelGGL((k3d_stream_backward_fused<1>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+            case 2: hipLaunchKernelGGL((k3d_stream_backward_fused<2>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+            case 3: hipLaunchKernelGGL((k3d_stream_backward_fused<3>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+            default: hipLaunchKernelGGL((k3d_stream_backward_fused<4>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+        }
+        hipLaunchKernelGGL((k3d_finalize<float>), dim3(s.C), dim3(kBlock), 0, stream, (const float*)ws, gshift, s.C,
+                           s.N, normalize, t_factor);
+        return launch_status();
+    }
     if (gshift) {
         const size_t lds = (size_t)(s.H + 1) * s.Wp * sizeof(float);
         const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);

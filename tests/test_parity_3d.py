@@ -213,3 +213,25 @@ def test_full_size_quantize_is_translation(full):
         qt, qh, qw = (int(v) for v in q[:, c])
         want = xp[:, P + qt:P + qt + 8, c, P + qh:P + qh + 56, P + qw:P + qw + 56]
         assert torch.equal(y[:, :, c], want)
+
+
+@pytest.mark.parametrize("kind", ["generic", "integer"])
+def test_backward_halves_match_fused(oracle, kind):
+    """d(x)-only, d(shift)-only and the fused backward agree (different kernels on the streaming path)."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
+
+    rng = np.random.default_rng(21)
+    x = rand(rng, (3, 8, 10, 28, 28), np.float32)
+    gy = rand(rng, x.shape, np.float32)
+    shift = special_shifts(rng, 3, 10, np.float32, kind)
+    args = (to_dev(gy), to_dev(x), to_dev(shift), 1, 0, False)
+    gx_f, gs_f = rubiks_shift_3d_backward(*args)
+    gx_only, none_s = rubiks_shift_3d_backward(*args, need_shift_grad=False)
+    none_x, gs_only = rubiks_shift_3d_backward(*args, need_x_grad=False)
+    assert none_s is None and none_x is None
+    np.testing.assert_array_equal(to_np(gx_f), to_np(gx_only))
+    _, _, raw_ref = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64),
+                                         normalize_grad=False, return_raw=True)
+    scale = max(1.0, float(np.abs(raw_ref).max()))
+    np.testing.assert_allclose(to_np(gs_f), raw_ref, rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(to_np(gs_only), raw_ref, rtol=0, atol=1e-5 * scale)
