@@ -38,6 +38,16 @@ struct SDims {
     int W4, Wp, cells;                 // W/4, W+4, H*W/4
 };
 
+// A full, aligned ds_read_b128.  The empty asm makes all four components "used", so the compiler
+// cannot narrow the access to the components one switch-case of pick5 needs: narrowed b32/b64 reads
+// at a 16 B lane stride are 4-way / 2-way bank conflicts (66% of LDS cycles in the first profile),
+// b128 at a 16 B stride is conflict-free.
+__device__ __forceinline__ float4 lds_b128(const float4* p) {
+    float4 v = *p;
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+}
+
 // the 5 consecutive values starting `off` floats into the aligned pair (q0, q1); off is wave-uniform
 __device__ __forceinline__ void pick5(const float4& q0, const float4& q1, int off, float (&v)[5]) {
     switch (off) {
@@ -165,8 +175,8 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_interp(const float* __restr
             float4 Bc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid) {
                 float a[5], b[5];
-                pick5(tile[cs.rowA[i] + cs.g0[i]], tile[cs.rowA[i] + cs.g1[i]], off, a);
-                pick5(tile[cs.rowB[i] + cs.g0[i]], tile[cs.rowB[i] + cs.g1[i]], off, b);
+                pick5(lds_b128(tile + cs.rowA[i] + cs.g0[i]), lds_b128(tile + cs.rowA[i] + cs.g1[i]), off, a);
+                pick5(lds_b128(tile + cs.rowB[i] + cs.g0[i]), lds_b128(tile + cs.rowB[i] + cs.g1[i]), off, b);
                 Bc.x = uH * (a[0] * uW + a[1] * rW) + rH * (b[0] * uW + b[1] * rW);
                 Bc.y = uH * (a[1] * uW + a[2] * rW) + rH * (b[1] * uW + b[2] * rW);
                 Bc.z = uH * (a[2] * uW + a[3] * rW) + rH * (b[2] * uW + b[3] * rW);
@@ -278,8 +288,8 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_shift_grad(const float* __r
                 float Bc[4] = {0.f, 0.f, 0.f, 0.f}, Hc[4] = {0.f, 0.f, 0.f, 0.f}, Wc[4] = {0.f, 0.f, 0.f, 0.f};
                 if (xvalid) {
                     float a[5], b[5], col[5];
-                    pick5(tile[cs.rowA[i] + cs.g0[i]], tile[cs.rowA[i] + cs.g1[i]], off, a);
-                    pick5(tile[cs.rowB[i] + cs.g0[i]], tile[cs.rowB[i] + cs.g1[i]], off, b);
+                    pick5(lds_b128(tile + cs.rowA[i] + cs.g0[i]), lds_b128(tile + cs.rowA[i] + cs.g1[i]), off, a);
+                    pick5(lds_b128(tile + cs.rowB[i] + cs.g0[i]), lds_b128(tile + cs.rowB[i] + cs.g1[i]), off, b);
 #pragma unroll
                     for (int k = 0; k < 5; ++k) col[k] = fmaf(uH, a[k], rH * b[k]);
 #pragma unroll
@@ -399,8 +409,8 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float*
                 float4 Qc = z4;
                 if (valid) {
                     float a[5], b[5], col[5], q[4];
-                    pick5(tile[cs.rowA[i] + cs.g0[i]], tile[cs.rowA[i] + cs.g1[i]], off, a);
-                    pick5(tile[cs.rowB[i] + cs.g0[i]], tile[cs.rowB[i] + cs.g1[i]], off, b);
+                    pick5(lds_b128(tile + cs.rowA[i] + cs.g0[i]), lds_b128(tile + cs.rowA[i] + cs.g1[i]), off, a);
+                    pick5(lds_b128(tile + cs.rowB[i] + cs.g0[i]), lds_b128(tile + cs.rowB[i] + cs.g1[i]), off, b);
                     const float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
                     const float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
 #pragma unroll
