@@ -3,6 +3,9 @@
 // caller-owned buffers and workspace, explicit stream, error codes instead of exit().
 #include "rk3d_generic.hpp"
 #include "rk3d_stream.hpp"
+#include "rk3d_dma.hpp"
+
+#include <type_traits>
 
 using namespace rk;
 
@@ -42,7 +45,12 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     Dims3 d;
     if (int rc = make_dims(d, N, Tn, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
+    if (stream3d::forward_supported<T>(d, quantize, x, y)) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (dma3d::launch_interp<false>(x, shift, y, stream3d::make_sdims(d), stream)) return launch_status();
+        }
+        return stream3d::launch_forward<T>(x, shift, y, d, stream);
+    }
     set_group(d, d.Ho * d.Wo);
     const unsigned grid = grid_for(d, (long long)d.N * d.To * d.C);
     if (quantize)
@@ -65,8 +73,18 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         const size_t need = rk3d_backward_workspace_bytes(N, Tn, C, H, W, sT, sH, sW, pT, pH, pW, (int)sizeof(T));
         if (!ws || ws_bytes < need) return RK_ERR_WORKSPACE;
     }
-    if (stream3d::backward_supported<T>(d, quantize, x, gy, gx))
+    if (stream3d::backward_supported<T>(d, quantize, x, gy, gx)) {
+        if constexpr (std::is_same<T, float>::value) {
+            const stream3d::SDims sd = stream3d::make_sdims(d);
+            if (gshift && dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, sd, d, stream)) {
+                hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(kBlock), 0, stream, (const float*)ws, gshift,
+                                   d.C, d.N, normalize_grad, t_factor);
+                return launch_status();
+            }
+            if (!gshift && gx && dma3d::launch_interp<true>(gy, shift, gx, sd, stream)) return launch_status();
+        }
         return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
+    }
 
     if (gshift) {   // rubiks.cpp:324-358
         T* part = (T*)ws;

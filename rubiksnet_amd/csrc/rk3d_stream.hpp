@@ -116,6 +116,23 @@ __device__ __forceinline__ void fetch_plane(float4 (&pre)[ROUNDS], const Cells<R
     }
 }
 
+// same, for a plane index the caller guarantees to be in range: straight-line loads hipcc can count
+template <int ROUNDS>
+__device__ __forceinline__ void fetch_plane_always(float4 (&pre)[ROUNDS], const Cells<ROUNDS>& cs, const float* col,
+                                                   int t, size_t tstride) {
+    const float4* p = reinterpret_cast<const float4*>(col + (size_t)t * tstride);
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) pre[i] = p[cs.cell[i]];
+}
+
+// Pin: everything that produces `v` (including the wait for the loads behind it) is scheduled before
+// this point, and no later load is hoisted above it.
+template <int ROUNDS> __device__ __forceinline__ void pin(float4 (&v)[ROUNDS]) {
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+        asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w)::"memory");
+}
+
 template <int ROUNDS>
 __device__ __forceinline__ void stash_plane(float4* tile, const float4 (&pre)[ROUNDS], const Cells<ROUNDS>& cs) {
 #pragma unroll
@@ -197,164 +214,33 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_interp(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// d(shift) partials, one per (n, c): part[c][3][P = N], p = n.
-//   gT = sum gy * (B(t1) - B(t0)),  gH = sum gy * ((1-rT) RH(t0) + rT RH(t1)),  gW likewise,
-// with t0 = to+flT, t1 = t0+1 and, per input plane, B = bilinear field, RH = lerpW(row+1) -
-// lerpW(row), RW = lerpH(col+1) - lerpH(col) -- the face differences of
-// rubiks3d_kernels.cu:432-441 regrouped so each x plane is interpolated once.
-template <int ROUNDS>
-__global__ __launch_bounds__(kBlock) void k3d_stream_shift_grad(const float* __restrict__ x,
-                                                                const float* __restrict__ shift,
-                                                                const float* __restrict__ gy,
-                                                                float* __restrict__ part, SDims d) {
-    extern __shared__ __attribute__((aligned(16))) float4 tile[];
-    __shared__ float red[3][kBlock / kWave];
-    const int c = blockIdx.x % d.C, n = blockIdx.x / d.C;
-    const Frac<float> fT = split_shift(shift[c]), fH = split_shift(shift[d.C + c]),
-                      fW = split_shift(shift[2 * d.C + c]);
-    const int HW = d.H * d.W;
-    const size_t tstride = (size_t)d.C * HW;
-    const float* xp = x + ((size_t)n * d.T * d.C + c) * HW;
-    const float* gp = gy + ((size_t)n * d.T * d.C + c) * HW;
-    float accT = 0.f, accH = 0.f, accW = 0.f;
-
-    if (fT.r == 0 || fH.r == 0 || fW.r == 0) {
-        // exactly-integer component: lowered small index (rubiks3d_kernels.cu:290-298, :359-431).
-        // Rare (tsm / group inits); per-element gathers straight from global memory.
-        const int zT = fT.r == 0, zH = fH.r == 0, zW = fW.r == 0;
-        for (int to = 0; to < d.T; ++to) {
-            const int t0 = to + fT.fl - zT, t1 = to + fT.fl + 1;
-            const bool v0 = t0 >= 0 && t0 < d.T, v1 = t1 >= 0 && t1 < d.T;
-            const float* p0 = xp + (v0 ? (size_t)t0 * tstride : 0);
-            const float* p1 = xp + (v1 ? (size_t)t1 * tstride : 0);
-            const float* g = gp + (size_t)to * tstride;
-            for (int i = threadIdx.x; i < HW; i += kBlock) {
-                const int ho = i / d.W, wo = i - ho * d.W;
-                const int h0 = ho + fH.fl - zH, h1 = ho + fH.fl + 1, w0 = wo + fW.fl - zW, w1 = wo + fW.fl + 1;
-                const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h1 >= 0 && h1 < d.H;
-                const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w1 >= 0 && w1 < d.W;
-                float q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
-                if (v0) {
-                    if (mh0 && mw0) q000 = p0[h0 * d.W + w0];
-                    if (mh0 && mw1) q001 = p0[h0 * d.W + w1];
-                    if (mh1 && mw0) q010 = p0[h1 * d.W + w0];
-                    if (mh1 && mw1) q011 = p0[h1 * d.W + w1];
-                }
-                if (v1) {
-                    if (mh0 && mw0) q100 = p1[h0 * d.W + w0];
-                    if (mh0 && mw1) q101 = p1[h0 * d.W + w1];
-                    if (mh1 && mw0) q110 = p1[h1 * d.W + w0];
-                    if (mh1 && mw1) q111 = p1[h1 * d.W + w1];
-                }
-                const float up = g[i];
-                accT += (interp2(q100, q101, q110, q111, fH.r, fW.r) - interp2(q000, q001, q010, q011, fH.r, fW.r)) * up;
-                accH += (interp2(q010, q011, q110, q111, fT.r, fW.r) - interp2(q000, q001, q100, q101, fT.r, fW.r)) * up;
-                accW += (interp2(q001, q011, q101, q111, fT.r, fH.r) - interp2(q000, q010, q100, q110, fT.r, fH.r)) * up;
-            }
-        }
-    } else {
-        const int off = ((fW.fl % 4) + 4) % 4;
-        Cells<ROUNDS> cs;
-        make_cells<ROUNDS>(cs, d, fH.fl, (fW.fl - off) / 4);
-        zero_halo(tile, d);
-        const float rT = fT.r, rH = fH.r, rW = fW.r;
-        const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
-
-        float4 pre[ROUNDS], gpre[ROUNDS];
-        // sums of gy * field, kept apart for the "small" (t0) and "large" (t1) pairing
-        float sB0 = 0.f, sB1 = 0.f, sH0 = 0.f, sH1 = 0.f, sW0 = 0.f, sW1 = 0.f;
-        float4 Bp[ROUNDS], Hp[ROUNDS], Wp_[ROUNDS];   // fields of the previous x plane
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i)
-            pre[i] = gpre[i] = Bp[i] = Hp[i] = Wp_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-        // step `to` pairs gy[to] with x planes t0 = to+flT (fields kept from the previous step)
-        // and t1 = to+flT+1 (in the tile now); one extra leading step builds the fields of t0(to=0).
-        const int to_first = -1, to_last = d.T - 1;
-        fetch_plane<ROUNDS>(pre, cs, xp, to_first + fT.fl + 1, d.T, tstride);
-        for (int to = to_first; to <= to_last; ++to) {
-            const int tx = to + fT.fl + 1;
-            const bool xvalid = tx >= 0 && tx < d.T, gvalid = to >= 0;
-            if (xvalid) stash_plane<ROUNDS>(tile, pre, cs);
-            float4 gcur[ROUNDS];
-#pragma unroll
-            for (int i = 0; i < ROUNDS; ++i) gcur[i] = gpre[i];
-            __syncthreads();
-            fetch_plane<ROUNDS>(pre, cs, xp, tx + 1, d.T, tstride);
-            fetch_plane<ROUNDS>(gpre, cs, gp, to + 1, d.T, tstride);
-#pragma unroll
-            for (int i = 0; i < ROUNDS; ++i) {
-                if (!wave_round_on(i, d.cells)) continue;
-                float Bc[4] = {0.f, 0.f, 0.f, 0.f}, Hc[4] = {0.f, 0.f, 0.f, 0.f}, Wc[4] = {0.f, 0.f, 0.f, 0.f};
-                if (xvalid) {
-                    float a[5], b[5], col[5];
-                    pick5(lds_b128(tile + cs.rowA[i] + cs.g0[i]), lds_b128(tile + cs.rowA[i] + cs.g1[i]), off, a);
-                    pick5(lds_b128(tile + cs.rowB[i] + cs.g0[i]), lds_b128(tile + cs.rowB[i] + cs.g1[i]), off, b);
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) col[k] = fmaf(uH, a[k], rH * b[k]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float la = fmaf(uW, a[k], rW * a[k + 1]), lb = fmaf(uW, b[k], rW * b[k + 1]);
-                        Bc[k] = fmaf(uH, la, rH * lb);
-                        Hc[k] = lb - la;
-                        Wc[k] = col[k + 1] - col[k];
-                    }
-                }
-                if (gvalid && cs.live[i]) {
-                    const float g[4] = {gcur[i].x, gcur[i].y, gcur[i].z, gcur[i].w};
-                    const float bp[4] = {Bp[i].x, Bp[i].y, Bp[i].z, Bp[i].w};
-                    const float hp[4] = {Hp[i].x, Hp[i].y, Hp[i].z, Hp[i].w};
-                    const float wp[4] = {Wp_[i].x, Wp_[i].y, Wp_[i].z, Wp_[i].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        sB0 = fmaf(g[k], bp[k], sB0); sB1 = fmaf(g[k], Bc[k], sB1);
-                        sH0 = fmaf(g[k], hp[k], sH0); sH1 = fmaf(g[k], Hc[k], sH1);
-                        sW0 = fmaf(g[k], wp[k], sW0); sW1 = fmaf(g[k], Wc[k], sW1);
-                    }
-                }
-                Bp[i] = make_float4(Bc[0], Bc[1], Bc[2], Bc[3]);
-                Hp[i] = make_float4(Hc[0], Hc[1], Hc[2], Hc[3]);
-                Wp_[i] = make_float4(Wc[0], Wc[1], Wc[2], Wc[3]);
-            }
-            __syncthreads();
-        }
-        accT = sB1 - sB0;
-        accH = fmaf(uT, sH0, rT * sH1);
-        accW = fmaf(uT, sW0, rT * sW1);
-    }
-
-    accT = group_sum(accT, kBlock, red[0]);
-    accH = group_sum(accH, kBlock, red[1]);
-    accW = group_sum(accW, kBlock, red[2]);
-    if (threadIdx.x == 0) {
-        float* o = part + (size_t)c * 3 * d.N + n;
-        o[0] = accT;
-        o[d.N] = accH;
-        o[2 * d.N] = accW;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused backward: d(x) and the d(shift) partials in ONE pass over (gy, x) -- 12 B/elem instead of
-// the 16 B/elem of k3d_stream_shift_grad + k3d_stream_interp<true>.
+// Backward: d(x) and the d(shift) partials in ONE pass over (gy, x) -- 12 B/elem -- or, with
+// WRITE_GX = false, the d(shift) partials alone (8 B/elem).  One partial per (n, c):
+// part[c][3][P = N], p = n, reduced wave-shuffle -> LDS (no atomics), summed by k3d_finalize.
 //
 // Adjoint form: with the negated shift (fl', r') the reference's d(x) is
 //     gx[t] = (1-r'T) Q(t+fl'T) + r'T Q(t+fl'T+1),   Q(tg) = bilinear(gy[tg]; fl'H, fl'W, r'H, r'W)
 // (rubiks3d_kernels.cu:914-924, evaluated in that exact tree => bit-identical), and because
-// y is linear in x the shift gradients can be collected on the INPUT side from the same taps:
+// y is linear in x the shift gradients (the face differences of rubiks3d_kernels.cu:432-441) can
+// be collected on the INPUT side from the same taps:
 //     gT = sum_x x[t] * (Q(t+fl'T) - Q(t+fl'T+1))
 //     gH = sum_x x[t] * ((1-r'T) QH(t+fl'T) + r'T QH(t+fl'T+1)),  QH = lerpW'(row A) - lerpW'(row B)
 //     gW = likewise with QW = lerpH'(col k) - lerpH'(col k+1)
 // so only gy needs the LDS tile; x is read at the thread's own (aligned) cells, 16 B per lane,
-// through a 2-plane register window (x[to], x[to+1]) + one plane in flight.
+// through a register window (x[to], x[to+1]) with one more plane in flight.
 // Regrouped per gy plane tg (to = tg - fl'T - 1):
 //     sT += Q(tg) * (x[to+1] - x[to]);   sH += QH(tg) * ((1-r'T) x[to+1] + r'T x[to]);   sW alike.
-template <int ROUNDS>
-__global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float* __restrict__ x,
-                                                                    const float* __restrict__ shift,
-                                                                    const float* __restrict__ gy,
-                                                                    float* __restrict__ gx,
-                                                                    float* __restrict__ part, SDims d, Dims3 gd) {
+//
+// Pipeline note: prefetch registers are written ONLY by loads (plane index clamped into range,
+// out-of-range planes are masked where they are used).  Merging a prefetch with a constant
+// ("else = 0") makes hipcc copy the loaded registers at the merge point behind an
+// s_waitcnt vmcnt(0) right after the loads are issued, which serialises every step.
+template <int ROUNDS, bool WRITE_GX>
+__global__ __launch_bounds__(kBlock) void k3d_stream_backward(const float* __restrict__ x,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ gy,
+                                                              float* __restrict__ gx,
+                                                              float* __restrict__ part, SDims d, Dims3 gd) {
     extern __shared__ __attribute__((aligned(16))) float4 tile[];
     __shared__ float red[3][kBlock / kWave];
     const int c = blockIdx.x % d.C, n = blockIdx.x / d.C;
@@ -363,7 +249,9 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float*
 
     if (split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0) {
         // exactly-integer component (lowered-index quirk / zero-shift copy branch): rare, per element
-        for (int t = 0; t < d.T; ++t) backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+        if (WRITE_GX)
+            for (int t = 0; t < d.T; ++t)
+                backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
         for (int to = 0; to < d.T; ++to)
             shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
     } else {
@@ -372,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float*
         const size_t tstride = (size_t)d.C * HW;
         const float* xp = x + ((size_t)n * d.T * d.C + c) * HW;
         const float* gp = gy + ((size_t)n * d.T * d.C + c) * HW;
-        float* op = gx + ((size_t)n * d.T * d.C + c) * HW;
+        float* op = WRITE_GX ? gx + ((size_t)n * d.T * d.C + c) * HW : nullptr;
 
         const int off = ((fW.fl % 4) + 4) % 4;
         Cells<ROUNDS> cs;
@@ -387,21 +275,22 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float*
         for (int i = 0; i < ROUNDS; ++i) gpre[i] = xpre[i] = xa[i] = xb[i] = Qprev[i] = z4;
         float sT = 0.f, sH = 0.f, sW = 0.f;
 
+        auto clampT = [&](int t) { return t < 0 ? 0 : (t >= d.T ? d.T - 1 : t); };
         const int t_first = fT.fl, t_last = d.T + fT.fl;          // gy plane index tg; T+1 steps
         fetch_plane<ROUNDS>(gpre, cs, gp, t_first, d.T, tstride);
-        fetch_plane<ROUNDS>(xb, cs, xp, 0, d.T, tstride);          // x[to+1] of the first step (to = -1)
+        fetch_plane<ROUNDS>(xpre, cs, xp, 0, d.T, tstride);        // becomes x[to+1] of the first step (to = -1)
         for (int tg = t_first; tg <= t_last; ++tg) {
             const bool valid = tg >= 0 && tg < d.T;
-            const int to = tg - fT.fl - 1;
-            const bool emit = to >= 0;                              // to <= T-1 always
+            const int to = tg - fT.fl - 1;                          // -1 .. T-1
             if (valid) stash_plane<ROUNDS>(tile, gpre, cs);
             __syncthreads();
-            fetch_plane<ROUNDS>(gpre, cs, gp, tg + 1, d.T, tstride);
-            if (to + 2 < d.T) fetch_plane<ROUNDS>(xpre, cs, xp, to + 2, d.T, tstride);
-            else {
 #pragma unroll
-                for (int i = 0; i < ROUNDS; ++i) xpre[i] = z4;
-            }
+            for (int i = 0; i < ROUNDS; ++i) { xa[i] = xb[i]; xb[i] = xpre[i]; }   // window: x[to], x[to+1]
+            pin<ROUNDS>(xb);                                        // the wait for xpre sits HERE, before new loads
+            fetch_plane_always<ROUNDS>(xpre, cs, xp, clampT(to + 2), tstride);     // always a real load
+            fetch_plane<ROUNDS>(gpre, cs, gp, tg + 1, d.T, tstride);
+            const float ka = (to >= 0) ? 1.f : 0.f, kb = (to + 1 < d.T) ? 1.f : 0.f; // x[-1] = x[T] = 0
+            const bool emit = WRITE_GX && to >= 0;                  // to <= T-1 always
             float4* out = reinterpret_cast<float4*>(op + (size_t)(emit ? to : 0) * tstride);
 #pragma unroll
             for (int i = 0; i < ROUNDS; ++i) {
@@ -411,8 +300,8 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float*
                     float a[5], b[5], col[5], q[4];
                     pick5(lds_b128(tile + cs.rowA[i] + cs.g0[i]), lds_b128(tile + cs.rowA[i] + cs.g1[i]), off, a);
                     pick5(lds_b128(tile + cs.rowB[i] + cs.g0[i]), lds_b128(tile + cs.rowB[i] + cs.g1[i]), off, b);
-                    const float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
-                    const float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
+                    const float xav[4] = {ka * xa[i].x, ka * xa[i].y, ka * xa[i].z, ka * xa[i].w};
+                    const float xbv[4] = {kb * xb[i].x, kb * xb[i].y, kb * xb[i].z, kb * xb[i].w};
 #pragma unroll
                     for (int k = 0; k < 5; ++k) col[k] = fmaf(uH, a[k], rH * b[k]);
 #pragma unroll
@@ -437,10 +326,8 @@ __global__ __launch_bounds__(kBlock) void k3d_stream_backward_fused(const float*
                     o.w = uT * Qprev[i].w + rT * Qc.w;
                     out[cs.cell[i]] = o;
                 }
-                Qprev[i] = Qc;
+                if (WRITE_GX) Qprev[i] = Qc;
             }
-#pragma unroll
-            for (int i = 0; i < ROUNDS; ++i) { xa[i] = xb[i]; xb[i] = xpre[i]; }
             __syncthreads();
         }
         accT = sT; accH = sH; accW = sW;
@@ -513,6 +400,19 @@ inline int launch_forward<float>(const float* x, const float* shift, float* y, c
     return launch_status();
 }
 
+template <bool WRITE_GX>
+inline void launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* ws, const SDims& s,
+                       const Dims3& d, hipStream_t stream) {
+    const size_t lds = (size_t)(s.H + 1) * s.Wp * sizeof(float);
+    const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);
+    switch ((s.cells + kBlock - 1) / kBlock) {
+        case 1: hipLaunchKernelGGL((k3d_stream_backward<1, WRITE_GX>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+        case 2: hipLaunchKernelGGL((k3d_stream_backward<2, WRITE_GX>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+        case 3: hipLaunchKernelGGL((k3d_stream_backward<3, WRITE_GX>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+        default: hipLaunchKernelGGL((k3d_stream_backward<4, WRITE_GX>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
+    }
+}
+
 template <typename T>
 int launch_backward(const T*, const T*, const T*, T*, T*, const Dims3&, int, T, T*, hipStream_t) {
     return RK_ERR_LAUNCH;
@@ -521,33 +421,14 @@ template <>
 inline int launch_backward<float>(const float* x, const float* shift, const float* gy, float* gx, float* gshift,
                                   const Dims3& d, int normalize, float t_factor, float* ws, hipStream_t stream) {
     const SDims s = make_sdims(d);
-    if (gshift && gx) {
-        const size_t lds = (size_t)(s.H + 1) * s.Wp * sizeof(float);
-        const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);
-        switch ((s.cells + kBlock - 1) / kBlock) {
-            case 1: hipLaunchKernelGGL((k3d_stream_backward_fused<1>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-            case 2: hipLaunchKernelGGL((k3d_stream_backward_fused<2>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-            case 3: hipLaunchKernelGGL((k3d_stream_backward_fused<3>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-            default: hipLaunchKernelGGL((k3d_stream_backward_fused<4>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-        }
-        hipLaunchKernelGGL((k3d_finalize<float>), dim3(s.C), dim3(kBlock), 0, stream, (const float*)ws, gshift, s.C,
-                           s.N, normalize, t_factor);
-        return launch_status();
-    }
     if (gshift) {
-        const size_t lds = (size_t)(s.H + 1) * s.Wp * sizeof(float);
-        const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);
-        const int rounds = (s.cells + kBlock - 1) / kBlock;
-        switch (rounds) {
-            case 1: hipLaunchKernelGGL((k3d_stream_shift_grad<1>), grid, block, lds, stream, x, shift, gy, ws, s); break;
-            case 2: hipLaunchKernelGGL((k3d_stream_shift_grad<2>), grid, block, lds, stream, x, shift, gy, ws, s); break;
-            case 3: hipLaunchKernelGGL((k3d_stream_shift_grad<3>), grid, block, lds, stream, x, shift, gy, ws, s); break;
-            default: hipLaunchKernelGGL((k3d_stream_shift_grad<4>), grid, block, lds, stream, x, shift, gy, ws, s); break;
-        }
+        if (gx) launch_bwd<true>(x, shift, gy, gx, ws, s, d, stream);
+        else launch_bwd<false>(x, shift, gy, nullptr, ws, s, d, stream);
         hipLaunchKernelGGL((k3d_finalize<float>), dim3(s.C), dim3(kBlock), 0, stream, (const float*)ws, gshift, s.C,
                            s.N, normalize, t_factor);
+    } else if (gx) {
+        launch_interp<true>(gy, shift, gx, s, stream);
     }
-    if (gx) launch_interp<true>(gy, shift, gx, s, stream);
     return launch_status();
 }
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--sets", type=int, default=3)
     ap.add_argument("--stride", default="1,1,1")
+    ap.add_argument("--bwd", default="fused", choices=["fused", "gx", "gs"])
     args = ap.parse_args()
     shape = tuple(int(v) for v in args.shape.split(","))
     stride = [int(v) for v in args.stride.split(",")]
@@ -36,7 +37,8 @@ def main():
         e[0].record()
         rubiksnet_cuda.rubiks_shift_3d_forward_float(x, shift, stride, p0, False, y)
         e[1].record()
-        rubiksnet_cuda.rubiks_shift_3d_backward_float(x, shift, gy, stride, p0, gx, gs, True, 1.0, False)
+        rubiksnet_cuda.rubiks_shift_3d_backward_float(x, shift, gy, stride, p0, None if args.bwd == "gs" else gx,
+                                                      None if args.bwd == "gx" else gs, True, 1.0, False)
         e[2].record()
         ev.append(e)
     torch.cuda.synchronize()
