@@ -75,6 +75,22 @@ def op_bench(env, steps, warmup, nsets=3):
     }
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest PMC summary committed under profiles/
+    (tools/pmc.sh + tools/make_profile_summary.py: separate rocprofv3 --pmc passes, FETCH_SIZE doubled)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for name, rec in data.items():
+        if kernel_substr in name:
+            return rec["hbm_bytes"], "%s :: %s" % (os.path.relpath(files[-1], ROOT), name)
+    return None, None
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle (a port: the reference has no CPU path) on the host cores, OpenMP over planes,
     on a bounded sample of the same workload: n clips of [8,64,56,56], fwd+bwd."""
@@ -169,6 +185,8 @@ def main():
     if env.is_main and env.world_size == 1 and not args.no_cpu:
         cpu = cpu_baseline()
 
+    traffic, traffic_src = pmc_traffic("backward")
+
     if env.is_main:
         out = {
             "metric": "RubiksShift3D fwd+bwd GB/s vs HBM roofline",
@@ -188,7 +206,7 @@ def main():
             "roofline": {
                 "kernel": "rk3d backward (d(x) + d(shift) + finalize)", "bound": "hbm",
                 "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": r["bwd_ms"], "algorithmic_bytes": r["bytes_bwd"],
                 "forward": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS, "avg_launch_ms": r["fwd_ms"],
                             "algorithmic_bytes": r["bytes_fwd"]},
