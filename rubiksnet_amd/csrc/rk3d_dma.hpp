@@ -28,23 +28,59 @@ using stream3d::lds_b128;
 using stream3d::pick5;
 using stream3d::wave_round_on;
 
+// Output planes are written once and never read back by these kernels: store them non-temporal
+// (global_store_dwordx4 ... nt) unless RK_NT_STORES=0 was set when the library was built.
+#ifndef RK_NT_FWD
+#define RK_NT_FWD 1
+#endif
+#ifndef RK_NT_BWD
+#define RK_NT_BWD 1
+#endif
+// Input planes are read exactly once, by one CU: stream them too (MI355X_MICROARCH "nt-weights")
+#ifndef RK_NT_LOADS_FWD
+#define RK_NT_LOADS_FWD 1
+#endif
+#ifndef RK_NT_LOADS_BWD
+#define RK_NT_LOADS_BWD 1
+#endif
+template <bool NT> __device__ __forceinline__ void stream_store(float4* p, const float4& v) {
+    if (NT) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+    } else {
+        *p = v;
+    }
+}
+
 __device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
 // one wave-instruction: lane l copies 16 B from its own `gsrc` to LDS byte address lds_dst + 16*l.
 // M0 holds the LDS base; it is compiler-reserved, so it is saved, set and restored in ONE statement.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+template <bool NT> __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst_uniform)
-        : "memory");
+    if (NT)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst_uniform)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst_uniform)
+            : "memory");
 }
 
 #define RK_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -98,14 +134,14 @@ template <int ROUNDS> __device__ __forceinline__ int wave_rounds(int cells) {
 }
 
 // DMA plane `plane` (global float pointer) into the slot whose LDS byte address is `slot_addr`
-template <int ROUNDS>
+template <int ROUNDS, bool NEGATE>
 __device__ __forceinline__ void dma_plane(const float* plane, unsigned slot_addr, const DCells<ROUNDS>& cs, int cells) {
     const unsigned wave = __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6);
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) {
         if (!wave_round_on(i, cells)) continue;
         const unsigned dst = slot_addr + (wave + 4u * i) * 1024u;       // chunk (wave + 4 i) of 64 cells
-        if (cs.live[i]) dma16(reinterpret_cast<const float4*>(plane) + cs.cell[i], dst);
+        if (cs.live[i]) dma16<(NEGATE ? RK_NT_LOADS_BWD : RK_NT_LOADS_FWD) != 0>(reinterpret_cast<const float4*>(plane) + cs.cell[i], dst);
     }
 }
 
@@ -158,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
 #pragma unroll
     for (int j = 0; j < D; ++j) {                                    // prologue: planes 0..D-1 -> slots 0..D-1
         if (in_range(t_first + j)) {
-            dma_plane<ROUNDS>(sp + (size_t)(t_first + j) * tstride, ring_addr + j * slot_bytes, cs, d.cells);
+            dma_plane<ROUNDS, NEGATE>(sp + (size_t)(t_first + j) * tstride, ring_addr + j * slot_bytes, cs, d.cells);
             issued += nr;
         }
         mark[j] = issued;
@@ -174,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
             const int tn = t + D;
             int sn = slot + D; if (sn >= R) sn -= R;                  // = slot of plane k-1, free now
             if (in_range(tn)) {
-                dma_plane<ROUNDS>(sp + (size_t)tn * tstride, ring_addr + sn * slot_bytes, cs, d.cells);
+                dma_plane<ROUNDS, NEGATE>(sp + (size_t)tn * tstride, ring_addr + sn * slot_bytes, cs, d.cells);
                 issued += nr;
             }
 #pragma unroll
@@ -204,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
                 o.y = uT * Bprev[i].y + rT * Bc.y;
                 o.z = uT * Bprev[i].z + rT * Bc.z;
                 o.w = uT * Bprev[i].w + rT * Bc.w;
-                out[cs.cell[i]] = o;
+                stream_store<(NEGATE ? RK_NT_BWD : RK_NT_FWD) != 0>(out + cs.cell[i], o);
             }
             Bprev[i] = Bc;
         }
@@ -220,11 +256,81 @@ template <int OFF> __device__ __forceinline__ float tap(const float4& q0, const 
          : j == 6 ? q1.z : q1.w;
 }
 
-// zero this thread's own cells of a slot (out-of-range planes are all-zero planes)
+// Geometry with the invariant the launchers guarantee (ROUNDS = ceil(cells / 256)): rounds
+// 0 .. ROUNDS-2 are FULL (every lane of every wave owns a cell), only the last round is ragged.
+// So only the tail round carries a wave-uniform "on" test and a lane mask.
+template <int ROUNDS> struct TCells {
+    int off16[ROUNDS];                                   // byte offset of the own cell inside a plane / slot
+    int a0[ROUNDS], a1[ROUNDS], b0[ROUNDS], b1[ROUNDS];  // tap float4 indices (zero cell if outside)
+    int xown;                                            // tail round: own float4 index, or the zero cell if dead
+    bool tail_live;                                      // tail round: this lane owns a cell
+    bool tail_on;                                        // tail round: this WAVE owns at least one cell (uniform)
+};
+
 template <int ROUNDS>
-__device__ __forceinline__ void zero_plane(float4* slot, const DCells<ROUNDS>& cs) {
+__device__ __forceinline__ void make_tcells(TCells<ROUNDS>& cs, const SDims& d, int flH, int group_shift) {
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) slot[cs.cell[i]] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int raw = (int)threadIdx.x + kBlock * i;
+        const bool live = raw < d.cells;
+        const int cell = live ? raw : d.cells - 1;
+        cs.off16[i] = cell * 16;
+        const int h = cell / d.W4, w4 = cell - h * d.W4;
+        const int ra = h + flH, rb = ra + 1, ga = w4 + group_shift, gb = ga + 1;
+        const bool ra_ok = ra >= 0 && ra < d.H, rb_ok = rb >= 0 && rb < d.H;
+        const bool ga_ok = ga >= 0 && ga < d.W4, gb_ok = gb >= 0 && gb < d.W4;
+        const int zero = d.cells;
+        cs.a0[i] = (ra_ok && ga_ok) ? ra * d.W4 + ga : zero;
+        cs.a1[i] = (ra_ok && gb_ok) ? ra * d.W4 + gb : zero;
+        cs.b0[i] = (rb_ok && ga_ok) ? rb * d.W4 + ga : zero;
+        cs.b1[i] = (rb_ok && gb_ok) ? rb * d.W4 + gb : zero;
+        if (i == ROUNDS - 1) { cs.tail_live = live; cs.xown = live ? cell : zero; }
+    }
+    cs.tail_on = wave_round_on(ROUNDS - 1, d.cells);
+}
+
+#if RK_NT_LOADS_BWD
+#define RK_BWD_LD_NT " nt"
+#else
+#define RK_BWD_LD_NT ""
+#endif
+// One wave-instruction of LDS-DMA in the saddr form: lane l copies 16 B from (sbase + voff_l) to LDS byte
+// address lds_dst + 16*l.  An s_waitcnt lgkmcnt(0) in front orders it behind this wave's earlier LDS reads
+// of the slot being refilled.
+__device__ __forceinline__ void dma16s(const void* sbase_uniform, int voff, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "global_load_lds_dwordx4 %1, %2" RK_BWD_LD_NT "\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
+        : "memory");
+}
+
+// DMA one plane (uniform global pointer `plane`) into the slot at LDS byte address `slot_addr`.
+// Returns the number of VMEM instructions this wave issued.
+template <int ROUNDS>
+__device__ __forceinline__ int dma_plane_t(const float* plane, unsigned slot_addr, const TCells<ROUNDS>& cs) {
+    const unsigned wave = __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6);
+    const unsigned dst = slot_addr + wave * 1024u;                   // chunk (wave + 4 i) of 64 cells
+#pragma unroll
+    for (int i = 0; i + 1 < ROUNDS; ++i) dma16s(plane, cs.off16[i], dst + 4096u * i);
+    if (cs.tail_on) {
+        if (cs.tail_live) dma16s(plane, cs.off16[ROUNDS - 1], dst + 4096u * (ROUNDS - 1));
+        return ROUNDS;
+    }
+    return ROUNDS - 1;
+}
+
+template <int ROUNDS>
+__device__ __forceinline__ void zero_plane_t(float4* slot, const TCells<ROUNDS>& cs) {
+    char* base = reinterpret_cast<char*>(slot);
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+        *reinterpret_cast<float4*>(base + cs.off16[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,7 +346,8 @@ __device__ __forceinline__ void zero_plane(float4* slot, const DCells<ROUNDS>& c
 // Hence: the tap offset (flW mod 4) is a template parameter (the kernel switches once into one
 // of four copies of the loop); an out-of-range plane is a slot of zeros, filled with plain LDS
 // stores where its DMA would have been issued, so the step body has no validity branches or
-// masks; lanes past the end of the plane read x from a zero cell, so they add nothing.
+// masks; the full rounds carry no liveness tests at all; lanes past the end of the plane (tail
+// round) read x from a zero cell, so they add nothing.
 template <int ROUNDS, bool WRITE_GX, int D, int OFF>
 __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
                                                   float* __restrict__ op, float4* ring, const SDims& d,
@@ -249,21 +356,17 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
                                                   float& accW) {
     constexpr int RG = D + 1, RX = D;
     const int slot_f4 = d.cells + 1;
-    DCells<ROUNDS> cs;
-    make_dcells<ROUNDS>(cs, d, fH.fl, (fW.fl - OFF) / 4);
+    TCells<ROUNDS> cs;
+    make_tcells<ROUNDS>(cs, d, fH.fl, (fW.fl - OFF) / 4);
     float4* const gring = ring;
     float4* const xring = ring + RG * slot_f4;
     if (threadIdx.x < RG + RX) ring[threadIdx.x * slot_f4 + d.cells] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int xcell[ROUNDS];                 // own cell in an x slot; dead lanes read the slot's zero cell
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) xcell[i] = cs.live[i] ? cs.cell[i] : d.cells;
 
     const float rT = fT.r, rH = fH.r, rW = fW.r;
     const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
     const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(gring));
     const unsigned xaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(xring));
     const unsigned slot_bytes = (unsigned)slot_f4 * 16u;
-    const int nr = wave_rounds<ROUNDS>(d.cells);
 
     float4 xa[ROUNDS], xb[ROUNDS], Qprev[ROUNDS];
 #pragma unroll
@@ -276,26 +379,63 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     int issued = 0;
     // bring plane (gy: tg, x: tx) into its slot: DMA when it exists, zeros when it does not
     auto feed = [&](int tg, int gs, int tx, int xs) {
-        if (in_range(tg)) { dma_plane<ROUNDS>(gp + (size_t)tg * tstride, gaddr + gs * slot_bytes, cs, d.cells); issued += nr; }
-        else zero_plane<ROUNDS>(gring + gs * slot_f4, cs);
-        if (in_range(tx)) { dma_plane<ROUNDS>(xp + (size_t)tx * tstride, xaddr + xs * slot_bytes, cs, d.cells); issued += nr; }
-        else zero_plane<ROUNDS>(xring + xs * slot_f4, cs);
+        if (in_range(tg)) issued += dma_plane_t<ROUNDS>(gp + (size_t)tg * tstride, gaddr + gs * slot_bytes, cs);
+        else zero_plane_t<ROUNDS>(gring + gs * slot_f4, cs);
+        if (in_range(tx)) issued += dma_plane_t<ROUNDS>(xp + (size_t)tx * tstride, xaddr + xs * slot_bytes, cs);
+        else zero_plane_t<ROUNDS>(xring + xs * slot_f4, cs);
     };
     int mark[D];                       // `issued` after the DMAs that feed step k+j (j = 0..D-1)
 #pragma unroll
     for (int j = 0; j < D; ++j) { feed(t_first + j, j, j, j); mark[j] = issued; }
 
+    // one round of one step: fields of the gy plane at this thread's cell meet x[to], x[to+1]
+    auto round = [&](int i, const float4* cur, float4* out, bool store) {
+        const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
+        const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
+        const float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
+        const float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
+        float col[5], q[4];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) col[m] = fmaf(uH, tap<OFF>(qa0, qa1, m), rH * tap<OFF>(qb0, qb1, m));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float la = tap<OFF>(qa0, qa1, m) * uW + tap<OFF>(qa0, qa1, m + 1) * rW;
+            const float lb = tap<OFF>(qb0, qb1, m) * uW + tap<OFF>(qb0, qb1, m + 1) * rW;
+            q[m] = uH * la + rH * lb;                             // the reference's tree, contraction off
+            const float dx = xbv[m] - xav[m];
+            const float mx = fmaf(uT, xbv[m], rT * xav[m]);
+            sT = fmaf(q[m], dx, sT);
+            sH = fmaf(la - lb, mx, sH);
+            sW = fmaf(col[m] - col[m + 1], mx, sW);
+        }
+        if (WRITE_GX) {
+            if (store) {
+                float4 o;
+                o.x = uT * Qprev[i].x + rT * q[0];
+                o.y = uT * Qprev[i].y + rT * q[1];
+                o.z = uT * Qprev[i].z + rT * q[2];
+                o.w = uT * Qprev[i].w + rT * q[3];
+                stream_store<RK_NT_BWD != 0>(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off16[i]), o);
+            }
+            Qprev[i] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+    };
+
     int gslot = 0, xslot = 0;
     for (int k = 0; k < steps; ++k) {
         wait_vmcnt(issued - mark[0]);                             // my pieces of gy(tg) and x[k] have landed
         __syncthreads();                                          // everyone's gy pieces have; step k-1 retired
-        const float4* xs = xring + xslot * slot_f4;
+        const char* xs = reinterpret_cast<const char*>(xring + xslot * slot_f4);
 #pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) { xa[i] = xb[i]; xb[i] = xs[xcell[i]]; }   // window: x[k-1], x[k]
-        stream3d::pin<ROUNDS>(xb);                                // LDS reads done before the slot is refilled
+        for (int i = 0; i + 1 < ROUNDS; ++i) {                    // window: x[k-1], x[k]
+            xa[i] = xb[i];
+            xb[i] = *reinterpret_cast<const float4*>(xs + cs.off16[i]);
+        }
+        xa[ROUNDS - 1] = xb[ROUNDS - 1];
+        xb[ROUNDS - 1] = reinterpret_cast<const float4*>(xs)[cs.xown];
         {
             int gs = gslot + D; if (gs >= RG) gs -= RG;           // gy slot of plane k-1: free now
-            feed(t_first + k + D, gs, k + D, xslot);
+            feed(t_first + k + D, gs, k + D, xslot);              // (its DMA waits for the LDS reads above)
 #pragma unroll
             for (int j = 0; j + 1 < D; ++j) mark[j] = mark[j + 1];
             mark[D - 1] = issued;
@@ -304,39 +444,9 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
         const bool emit = WRITE_GX && k >= 1;                     // output plane to = k - 1
         float4* out = reinterpret_cast<float4*>(op + (size_t)(emit ? k - 1 : 0) * tstride);
 #pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            if (!wave_round_on(i, d.cells)) continue;
-            const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
-            const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
-            const float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
-            const float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
-            float col[5], q[4];
-#pragma unroll
-            for (int m = 0; m < 5; ++m) col[m] = fmaf(uH, tap<OFF>(qa0, qa1, m), rH * tap<OFF>(qb0, qb1, m));
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float la = tap<OFF>(qa0, qa1, m) * uW + tap<OFF>(qa0, qa1, m + 1) * rW;
-                const float lb = tap<OFF>(qb0, qb1, m) * uW + tap<OFF>(qb0, qb1, m + 1) * rW;
-                q[m] = uH * la + rH * lb;                         // the reference's tree, contraction off
-                const float dx = xbv[m] - xav[m];
-                const float mx = fmaf(uT, xbv[m], rT * xav[m]);
-                sT = fmaf(q[m], dx, sT);
-                sH = fmaf(la - lb, mx, sH);
-                sW = fmaf(col[m] - col[m + 1], mx, sW);
-            }
-            if (WRITE_GX) {
-                if (emit && cs.live[i]) {
-                    float4 o;
-                    o.x = uT * Qprev[i].x + rT * q[0];
-                    o.y = uT * Qprev[i].y + rT * q[1];
-                    o.z = uT * Qprev[i].z + rT * q[2];
-                    o.w = uT * Qprev[i].w + rT * q[3];
-                    out[cs.cell[i]] = o;
-                }
-                Qprev[i] = make_float4(q[0], q[1], q[2], q[3]);
-            }
-        }
-        if (emit) issued += nr;
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, out, emit);
+        if (cs.tail_on) round(ROUNDS - 1, cur, out, emit && cs.tail_live);
+        if (emit) issued += cs.tail_on ? ROUNDS : ROUNDS - 1;
         if (++gslot == RG) gslot = 0;
         if (++xslot == RX) xslot = 0;
     }
