@@ -45,12 +45,10 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     Dims3 d;
     if (int rc = make_dims(d, N, Tn, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    if (stream3d::forward_supported<T>(d, quantize, x, y)) {
-        if constexpr (std::is_same<T, float>::value) {
-            if (dma3d::launch_interp<false>(x, shift, y, stream3d::make_sdims(d), stream)) return launch_status();
-        }
-        return stream3d::launch_forward<T>(x, shift, y, d, stream);
+    if constexpr (std::is_same<T, float>::value) {
+        if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
     }
+    if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);
     const unsigned grid = grid_for(d, (long long)d.N * d.To * d.C);
     if (quantize)
@@ -73,18 +71,19 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         const size_t need = rk3d_backward_workspace_bytes(N, Tn, C, H, W, sT, sH, sW, pT, pH, pW, (int)sizeof(T));
         if (!ws || ws_bytes < need) return RK_ERR_WORKSPACE;
     }
-    if (stream3d::backward_supported<T>(d, quantize, x, gy, gx)) {
-        if constexpr (std::is_same<T, float>::value) {
-            const stream3d::SDims sd = stream3d::make_sdims(d);
-            if (gshift && dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, sd, d, stream)) {
+    if constexpr (std::is_same<T, float>::value) {
+        if (!quantize && gshift) {
+            if (const int P = dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) {
                 hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(kBlock), 0, stream, (const float*)ws, gshift,
-                                   d.C, d.N, normalize_grad, t_factor);
+                                   d.C, P, normalize_grad, t_factor);
                 return launch_status();
             }
-            if (!gshift && gx && dma3d::launch_interp<true>(gy, shift, gx, sd, stream)) return launch_status();
+        } else if (!quantize && gx) {
+            if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
         }
-        return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
     }
+    if (stream3d::backward_supported<T>(d, quantize, x, gy, gx))
+        return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
 
     if (gshift) {   // rubiks.cpp:324-358
         T* part = (T*)ws;
@@ -113,10 +112,12 @@ extern "C" {
 
 size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH,
                                      int pW, int elem_size) {
-    (void)H; (void)W; (void)sH; (void)sW; (void)pH; (void)pW;
+    (void)W; (void)sH; (void)sW; (void)pH; (void)pW;
     if (N <= 0 || T <= 0 || C <= 0 || sT <= 0 || pT < 0) return 0;
-    // partials part[C][3][P]: P = N*To for the generic kernels, <= that for the streaming ones
-    const size_t P = (size_t)N * (size_t)out_len(T, sT, pT);
+    // partials part[C][3][P]: P = N*To for the generic kernels, N*nbands (row bands) for the streaming ones
+    size_t per_n = (size_t)out_len(T, sT, pT);
+    if (H > 0 && (size_t)H > per_n) per_n = (size_t)H;    // nbands <= H
+    const size_t P = (size_t)N * per_n;
     return (size_t)C * 3 * P * (size_t)elem_size;
 }
 

@@ -1,86 +1,78 @@
-// rk3d_dma.hpp -- RubiksShift3D streaming kernels fed by LDS-DMA (gfx950 global_load_lds_dwordx4).
+// rk3d_dma.hpp -- RubiksShift3D streaming kernels fed by LDS-DMA (gfx950 global_load_lds_dwordx4),
+// fp32, stride 1 / pad 0, W % 4 == 0.  These are the kernels the benchmark shape and the
+// stride-1 layers of the networks run on (56x56, 28x28 whole planes; 112x112 in 4 row bands).
 //
-// Same maths and cell mapping as rk3d_stream.hpp; what changes is how planes reach the LDS.
-// The register-staged kernels keep ONE plane per column in flight and pay for it in VGPRs, which
-// caps a CU at ~50 KB of outstanding reads -- they measure latency-bound (waves wait ~60% of
-// their cycles, HBM traffic == algorithmic bytes).  Here each wave DMAs its own 1 KiB chunks of
-// a plane straight into a ring of R = D+1 linear LDS slots, D planes ahead, and only waits -- with
-// a COUNTED s_waitcnt vmcnt(N), never a drain -- for the plane it is about to read.  hipcc neither
-// sees the asm DMA nor waits for it, so the loads stay in flight across barriers
-// (cdna_hip_programming.md 5.7 / "Pipelining across barriers").
+// Maths (see rk3d_stream.hpp for the derivation): the shift is constant per channel, so an output
+// plane is a fixed 2-D translate-and-blend of two input planes and the H/W-interpolated field
+// B(t) of an input plane is shared by the two outputs that touch it,
+//     y[to] = (1-rT) B(to+flT) + rT B(to+flT+1),  B = (1-rH) lerpW(row) + rH lerpW(row+1),
+// evaluated in the reference's own expression tree (rubiks3d_kernels.cu:193-203; contraction off)
+// => bit-identical to the oracle.  The backward uses the adjoint form: only gy needs taps, x is
+// read at the thread's own cells, d(x) and the d(shift) partials come out of ONE pass (12 B/elem).
 //
-// vmcnt bookkeeping (per wave, all wave-uniform): `issued` counts every VMEM instruction the wave
-// has issued (DMA pieces and 16 B output stores, both = rounds-with-a-live-lane per plane);
-// mark[j] is `issued` right after the DMA of the j-th plane ahead.  VMEM ops retire in order, so
-// "plane k has landed" <=> outstanding <= issued - mark(k).  Under-counting `issued` only makes
-// the wait stricter; it is never over-counted (a skipped round or plane is not counted).
+// Work decomposition: one 256-thread workgroup owns one (n, c, row band) and walks t (T+1 steps).
+// A band is BH output rows x W4 float4 "cells"; thread `tid` owns cells tid + 256 i.  The launcher
+// picks equal bands with (BH+1) * W4 <= 1024, so rounds 0..ROUNDS-2 are full (no liveness tests)
+// and only the last round is ragged.
 //
-// Slot layout: the plane's float4 cells in flat order (so the DMA destination is lane-linear), then
-// ONE zero float4; every out-of-range (row, group) tap is redirected to that zero cell.
+// Data movement: each wave DMAs its own 1 KiB chunks of a plane's band straight into a ring of
+// linear LDS slots, D planes ahead, with `global_load_lds_dwordx4 ... nt` (inline asm, M0 saved
+// and restored in the same statement), and waits -- with a COUNTED s_waitcnt vmcnt(N), never a
+// drain -- only for the plane it is about to read.  hipcc neither sees nor waits for these loads,
+// so they stay in flight across the single barrier per step.  Bookkeeping per wave (all uniform):
+// `issued` counts every VMEM instruction the wave has issued (DMA pieces + 16 B output stores),
+// mark[j] is `issued` right after the DMAs feeding step k+j.  VMEM retires in order, so "plane k
+// landed" <=> outstanding <= issued - mark[0].  `issued` is never over-counted (under-counting
+// only makes the wait stricter).
+//
+// Tap slot layout: rows_out+1 input rows of the band (rows outside the plane are zero-filled once)
+// x W4 float4 in flat order -- so the DMA destination is lane-linear -- then ONE zero float4 that
+// every out-of-range column group is redirected to.  All LDS accesses are aligned b128.
+// An out-of-range PLANE is a slot of zeros (plain LDS stores where its DMA would have been
+// issued), so the step body carries no validity branches; the tap offset flW mod 4 is a template
+// parameter (the kernel switches once into one of four copies of the loop).  The first version
+// of the backward loop was instruction-issue bound: 308 of ~650 VALU instructions per step were
+// v_mov from run-time tap selection, validity merges and masks.
+//
+// Loads and stores are non-temporal: every plane is read once by one CU and every output written
+// once.  Measured on [32,8,64,56,56]: nt stores + nt loads 197 us fwd+bwd vs 216 us without.
 #pragma once
 #include "rk3d_stream.hpp"
 
 namespace rk {
 namespace dma3d {
 
-using stream3d::SDims;
 using stream3d::lds_b128;
-using stream3d::pick5;
-using stream3d::wave_round_on;
 
-// Output planes are written once and never read back by these kernels: store them non-temporal
-// (global_store_dwordx4 ... nt) unless RK_NT_STORES=0 was set when the library was built.
-#ifndef RK_NT_FWD
-#define RK_NT_FWD 1
-#endif
-#ifndef RK_NT_BWD
-#define RK_NT_BWD 1
-#endif
-// Input planes are read exactly once, by one CU: stream them too (MI355X_MICROARCH "nt-weights")
-#ifndef RK_NT_LOADS_FWD
-#define RK_NT_LOADS_FWD 1
-#endif
-#ifndef RK_NT_LOADS_BWD
-#define RK_NT_LOADS_BWD 1
-#endif
-template <bool NT> __device__ __forceinline__ void stream_store(float4* p, const float4& v) {
-    if (NT) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 t = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
-    } else {
-        *p = v;
-    }
-}
+struct BDims {
+    int N, T, C, H, W, W4;
+    int BH, nbands;          // output rows per band (H % BH == 0), bands per plane
+};
 
 __device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// one wave-instruction: lane l copies 16 B from its own `gsrc` to LDS byte address lds_dst + 16*l.
-// M0 holds the LDS base; it is compiler-reserved, so it is saved, set and restored in ONE statement.
-template <bool NT> __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+__device__ __forceinline__ void stream_store(float4* p, const float4& v) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
+
+// One wave-instruction of LDS-DMA, saddr form: lane l copies 16 B from (sbase + voff_l) to LDS byte
+// address lds_dst + 16*l.  The s_waitcnt lgkmcnt(0) orders it behind this wave's earlier LDS reads of
+// the slot being refilled (and covers the M0 write -> use hazard).
+__device__ __forceinline__ void dma16s(const void* sbase_uniform, int voff, unsigned lds_dst_uniform) {
     unsigned keep;
-    if (NT)
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off nt\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(gsrc), "s"(lds_dst_uniform)
-            : "memory");
-    else
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(gsrc), "s"(lds_dst_uniform)
-            : "memory");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
+        : "memory");
 }
 
 #define RK_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -98,63 +90,211 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 #undef RK_VMCNT_CASE
 
-// Per-thread geometry in float4 units relative to a slot's start.
-template <int ROUNDS> struct DCells {
-    int cell[ROUNDS];   // clamped flat float4 index of the thread's cell
-    bool live[ROUNDS];
-    int a0[ROUNDS], a1[ROUNDS], b0[ROUNDS], b1[ROUNDS];   // tap groups (row A/B x group 0/1), zero cell if outside
+// compile-time tap selection: the 5 consecutive values starting OFF floats into the aligned pair (q0, q1)
+template <int OFF> __device__ __forceinline__ float tap(const float4& q0, const float4& q1, int k) {
+    const int j = OFF + k;   // 0..7, constant after unrolling
+    return j == 0 ? q0.x : j == 1 ? q0.y : j == 2 ? q0.z : j == 3 ? q0.w : j == 4 ? q1.x : j == 5 ? q1.y
+         : j == 6 ? q1.z : q1.w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-workgroup band geometry (wave-uniform) and per-thread cell geometry.
+struct Band {
+    int cells_out;               // output float4 cells of this band (BH * W4)
+    int out0;                    // float4 index of the band's first output cell inside a plane
+    int cells_in;                // tap-slot cells: (BH + 1) * W4
+    int src0;                    // float4 index (may be negative) of the slot's cell 0 inside a source plane
+    int s_lo, s_hi;              // slot cells [s_lo, s_hi) hold real source rows; the rest stay zero
+};
+
+__device__ __forceinline__ Band make_band(const BDims& d, int band, int flH) {
+    Band b;
+    b.cells_out = d.BH * d.W4;
+    b.out0 = band * d.BH * d.W4;
+    b.cells_in = (d.BH + 1) * d.W4;
+    const int r0 = band * d.BH + flH;                     // source row held by slot row 0
+    b.src0 = r0 * d.W4;
+    int j_lo = r0 < 0 ? -r0 : 0;                          // first slot row inside the plane
+    j_lo = j_lo > d.BH + 1 ? d.BH + 1 : j_lo;
+    int j_hi = d.H - r0;                                  // first slot row past the plane
+    j_hi = j_hi < 0 ? 0 : (j_hi > d.BH + 1 ? d.BH + 1 : j_hi);
+    b.s_lo = j_lo * d.W4;
+    b.s_hi = j_hi > j_lo ? j_hi * d.W4 : b.s_lo;
+    return b;
+}
+
+template <int ROUNDS> struct BCells {
+    int off0;                                            // tid * 16: byte offset of cell `tid`; round i adds 4096 i
+    int a0[ROUNDS], a1[ROUNDS], b0[ROUNDS], b1[ROUNDS];  // tap float4 indices into a tap slot (zero cell if outside)
+    bool in_act[ROUNDS];                                 // this lane DMAs tap-slot cell tid + 256 i
+    bool tail_live;                                      // this lane owns an output cell in the last round
+    bool tail_on;                                        // ... and this WAVE has at least one such lane (uniform)
+    int xown;                                            // last round: own float4 index in an x slot, or its zero cell
+    int n_tap_wave;                                      // tap-plane DMA instructions per plane for this wave (uniform)
+    int n_out_wave;                                      // output stores / x DMA instructions per plane for this wave
 };
 
 template <int ROUNDS>
-__device__ __forceinline__ void make_dcells(DCells<ROUNDS>& cs, const SDims& d, int flH, int group_shift) {
+__device__ __forceinline__ void make_bcells(BCells<ROUNDS>& cs, const BDims& d, const Band& b, int group_shift) {
+    cs.off0 = (int)threadIdx.x * 16;
+    int n_tap = 0;
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) {
-        const int raw = (int)threadIdx.x + kBlock * i;
-        cs.live[i] = raw < d.cells;
-        const int cell = cs.live[i] ? raw : d.cells - 1;
-        cs.cell[i] = cell;
-        const int h = cell / d.W4, w4 = cell - h * d.W4;
-        const int ra = h + flH, rb = ra + 1, ga = w4 + group_shift, gb = ga + 1;
-        const bool ra_ok = ra >= 0 && ra < d.H, rb_ok = rb >= 0 && rb < d.H;
+        const int o = (int)threadIdx.x + kBlock * i;
+        const bool live = o < b.cells_out;
+        const int oc = live ? o : 0;
+        const int j = oc / d.W4, w4 = oc - j * d.W4;     // band-local output row, column group
+        const int ga = w4 + group_shift, gb = ga + 1;
         const bool ga_ok = ga >= 0 && ga < d.W4, gb_ok = gb >= 0 && gb < d.W4;
-        const int zero = d.cells;
-        cs.a0[i] = (ra_ok && ga_ok) ? ra * d.W4 + ga : zero;
-        cs.a1[i] = (ra_ok && gb_ok) ? ra * d.W4 + gb : zero;
-        cs.b0[i] = (rb_ok && ga_ok) ? rb * d.W4 + ga : zero;
-        cs.b1[i] = (rb_ok && gb_ok) ? rb * d.W4 + gb : zero;
+        const int zero = b.cells_in;                     // dead lanes read zeros everywhere
+        cs.a0[i] = (live && ga_ok) ? j * d.W4 + ga : zero;
+        cs.a1[i] = (live && gb_ok) ? j * d.W4 + gb : zero;
+        cs.b0[i] = (live && ga_ok) ? (j + 1) * d.W4 + ga : zero;
+        cs.b1[i] = (live && gb_ok) ? (j + 1) * d.W4 + gb : zero;
+        cs.in_act[i] = o >= b.s_lo && o < b.s_hi;
+        n_tap += (__ballot(cs.in_act[i]) != 0ull) ? 1 : 0;
+        if (i == ROUNDS - 1) { cs.tail_live = live; cs.xown = live ? o : b.cells_out; }
     }
+    cs.tail_on = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~(kWave - 1))) + kBlock * (ROUNDS - 1) < b.cells_out;
+    cs.n_tap_wave = __builtin_amdgcn_readfirstlane(n_tap);
+    cs.n_out_wave = cs.tail_on ? ROUNDS : ROUNDS - 1;
 }
 
-// number of rounds in which this wave has at least one live lane (= VMEM instructions per plane)
-template <int ROUNDS> __device__ __forceinline__ int wave_rounds(int cells) {
-    int n = 0;
+// DMA the band of a tap plane (uniform pointer to slot cell 0's source, may lie before the plane) into a slot
+template <int ROUNDS>
+__device__ __forceinline__ void dma_taps(const float* src0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
+    const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) n += wave_round_on(i, cells) ? 1 : 0;
-    return n;
+    for (int i = 0; i < ROUNDS; ++i)
+        if (cs.in_act[i]) dma16s(src0, cs.off0 + 4096 * i, dst + 4096u * i);
+}
+// zero the same cells instead (the plane lies outside [0, T))
+template <int ROUNDS>
+__device__ __forceinline__ void zero_taps(float4* slot, const BCells<ROUNDS>& cs) {
+    char* base = reinterpret_cast<char*>(slot) + cs.off0;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+        if (cs.in_act[i]) *reinterpret_cast<float4*>(base + 4096 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// DMA the thread's own output-aligned cells of a plane (uniform pointer to the band's first cell)
+template <int ROUNDS>
+__device__ __forceinline__ void dma_own(const float* band0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
+    const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
+#pragma unroll
+    for (int i = 0; i + 1 < ROUNDS; ++i) dma16s(band0, cs.off0 + 4096 * i, dst + 4096u * i);
+    if (cs.tail_on && cs.tail_live) dma16s(band0, cs.off0 + 4096 * (ROUNDS - 1), dst + 4096u * (ROUNDS - 1));
+}
+template <int ROUNDS>
+__device__ __forceinline__ void zero_own(float4* slot, const BCells<ROUNDS>& cs) {
+    char* base = reinterpret_cast<char*>(slot) + cs.off0;
+#pragma unroll
+    for (int i = 0; i + 1 < ROUNDS; ++i) *reinterpret_cast<float4*>(base + 4096 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cs.tail_live) *reinterpret_cast<float4*>(base + 4096 * (ROUNDS - 1)) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// DMA plane `plane` (global float pointer) into the slot whose LDS byte address is `slot_addr`
-template <int ROUNDS, bool NEGATE>
-__device__ __forceinline__ void dma_plane(const float* plane, unsigned slot_addr, const DCells<ROUNDS>& cs, int cells) {
-    const unsigned wave = __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6);
+// once per kernel: zero cell of every slot + the slot rows that lie outside the plane
+template <int ROUNDS>
+__device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slot_f4, const Band& b,
+                                               const BCells<ROUNDS>& cs) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslots; ++s) {
+        float4* slot = ring + s * slot_f4;
+        if (threadIdx.x == 0) slot[b.cells_in] = z;
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        if (!wave_round_on(i, cells)) continue;
-        const unsigned dst = slot_addr + (wave + 4u * i) * 1024u;       // chunk (wave + 4 i) of 64 cells
-        if (cs.live[i]) dma16<(NEGATE ? RK_NT_LOADS_BWD : RK_NT_LOADS_FWD) != 0>(reinterpret_cast<const float4*>(plane) + cs.cell[i], dst);
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int o = (int)threadIdx.x + kBlock * i;
+            if (o < b.cells_in && !cs.in_act[i]) slot[o] = z;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward (NEGATE = false: src = x, dst = y) and d(x) (NEGATE = true: src = gy, dst = gx).
+// Forward (NEGATE = false: src = x, dst = y) and d(x) alone (NEGATE = true: src = gy, dst = gx).
+template <bool NEGATE, int ROUNDS, int D, int OFF>
+__device__ __forceinline__ void dma_interp_loop(const float* __restrict__ sp, float* __restrict__ dp, float4* ring,
+                                                const BDims& d, const Band& b, const Frac<float>& fT,
+                                                const Frac<float>& fH, const Frac<float>& fW, size_t tstride) {
+    constexpr int R = D + 1;
+    const int slot_f4 = b.cells_in + 1;
+    BCells<ROUNDS> cs;
+    make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
+    init_tap_slots<ROUNDS>(ring, R, slot_f4, b, cs);
+
+    const float rT = fT.r, rH = fH.r, rW = fW.r;
+    const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
+    const unsigned slot_bytes = (unsigned)slot_f4 * 16u;
+    const float* src0 = sp + (ptrdiff_t)b.src0 * 4;               // source of slot cell 0 at t = 0
+    float* out0 = dp + (size_t)b.out0 * 4;
+
+    float4 Bprev[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) Bprev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int t_first = fT.fl, steps = d.T + 1;                   // plane of step k is t_first + k
+    auto in_range = [&](int t) { return t >= 0 && t < d.T; };
+    int issued = 0;
+    auto feed = [&](int t, int s) {
+        if (in_range(t)) {
+            dma_taps<ROUNDS>(src0 + (ptrdiff_t)t * (ptrdiff_t)tstride, ring_addr + s * slot_bytes, cs);
+            issued += cs.n_tap_wave;
+        } else {
+            zero_taps<ROUNDS>(ring + s * slot_f4, cs);
+        }
+    };
+    int mark[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { feed(t_first + j, j); mark[j] = issued; }
+
+    auto round = [&](int i, const float4* cur, float4* out, bool store) {
+        const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
+        const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
+        float q[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            q[m] = uH * (tap<OFF>(qa0, qa1, m) * uW + tap<OFF>(qa0, qa1, m + 1) * rW) +
+                   rH * (tap<OFF>(qb0, qb1, m) * uW + tap<OFF>(qb0, qb1, m + 1) * rW);
+        if (store) {
+            float4 o;
+            o.x = uT * Bprev[i].x + rT * q[0];
+            o.y = uT * Bprev[i].y + rT * q[1];
+            o.z = uT * Bprev[i].z + rT * q[2];
+            o.w = uT * Bprev[i].w + rT * q[3];
+            stream_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off0 + 4096 * i), o);
+        }
+        Bprev[i] = make_float4(q[0], q[1], q[2], q[3]);
+    };
+
+    int slot = 0;                                                  // slot of step k = k % R
+#pragma nounroll
+    for (int k = 0; k < steps; ++k) {
+        wait_vmcnt(issued - mark[0]);                              // my pieces of plane k have landed
+        __syncthreads();                                           // everyone's have; plane k-1 is retired
+        {
+            int sn = slot + D; if (sn >= R) sn -= R;               // = slot of plane k-1, free now
+            feed(t_first + k + D, sn);
+#pragma unroll
+            for (int j = 0; j + 1 < D; ++j) mark[j] = mark[j + 1];
+            mark[D - 1] = issued;
+        }
+        const float4* cur = ring + slot * slot_f4;
+        const bool emit = k >= 1;                                  // output plane to = k - 1
+        float4* out = reinterpret_cast<float4*>(out0 + (size_t)(emit ? k - 1 : 0) * tstride);
+#pragma unroll
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, out, emit);
+        if (cs.tail_on) round(ROUNDS - 1, cur, out, emit && cs.tail_live);
+        if (emit) issued += cs.n_out_wave;
+        if (++slot == R) slot = 0;
+    }
+}
+
 template <bool NEGATE, int ROUNDS, int D>
 __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict__ src,
                                                          const float* __restrict__ shift,
-                                                         float* __restrict__ dst, SDims d) {
-    constexpr int R = D + 1;
+                                                         float* __restrict__ dst, BDims d) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
-    const int slot_f4 = d.cells + 1;                                 // float4 per slot (plane + zero cell)
-    const int c = blockIdx.x % d.C, n = blockIdx.x / d.C;
+    const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
+    const int c = col % d.C, n = col / d.C;
     float sT = shift[c], sH = shift[d.C + c], sW = shift[2 * d.C + c];
     if (NEGATE) { sT = -sT; sH = -sH; sW = -sW; }
     const Frac<float> fT = split_shift(sT), fH = split_shift(sH), fW = split_shift(sW);
@@ -162,211 +302,54 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
     const size_t tstride = (size_t)d.C * HW;
     const float* sp = src + ((size_t)n * d.T * d.C + c) * HW;
     float* dp = dst + ((size_t)n * d.T * d.C + c) * HW;
+    const Band b = make_band(d, band, fH.fl);
 
-    if (NEGATE && sT == 0 && sH == 0 && sW == 0) {                   // rubiks3d_kernels.cu:819-827
+    if (NEGATE && sT == 0 && sH == 0 && sW == 0) {                  // rubiks3d_kernels.cu:819-827: plain copy
         for (int t = 0; t < d.T; ++t)
-            for (int cell = threadIdx.x; cell < d.cells; cell += kBlock)
-                reinterpret_cast<float4*>(dp + (size_t)t * tstride)[cell] =
-                    reinterpret_cast<const float4*>(sp + (size_t)t * tstride)[cell];
+            for (int cell = threadIdx.x; cell < b.cells_out; cell += kBlock)
+                reinterpret_cast<float4*>(dp + (size_t)t * tstride)[b.out0 + cell] =
+                    reinterpret_cast<const float4*>(sp + (size_t)t * tstride)[b.out0 + cell];
         return;
     }
-
-    const int off = ((fW.fl % 4) + 4) % 4;
-    DCells<ROUNDS> cs;
-    make_dcells<ROUNDS>(cs, d, fH.fl, (fW.fl - off) / 4);
-    if (threadIdx.x < R) ring[threadIdx.x * slot_f4 + d.cells] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const float rT = fT.r, rH = fH.r, rW = fW.r;
-    const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
-    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
-    const unsigned slot_bytes = (unsigned)slot_f4 * 16u;
-    const int nr = wave_rounds<ROUNDS>(d.cells);
-
-    float4 Bprev[ROUNDS];
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) Bprev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const int t_first = fT.fl, steps = d.T + 1;                      // plane of step k is t_first + k
-    auto in_range = [&](int t) { return t >= 0 && t < d.T; };
-
-    int issued = 0;
-    int mark[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {                                    // prologue: planes 0..D-1 -> slots 0..D-1
-        if (in_range(t_first + j)) {
-            dma_plane<ROUNDS, NEGATE>(sp + (size_t)(t_first + j) * tstride, ring_addr + j * slot_bytes, cs, d.cells);
-            issued += nr;
-        }
-        mark[j] = issued;
+    switch (((fW.fl % 4) + 4) % 4) {                                // wave-uniform
+        case 0: dma_interp_loop<NEGATE, ROUNDS, D, 0>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
+        case 1: dma_interp_loop<NEGATE, ROUNDS, D, 1>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
+        case 2: dma_interp_loop<NEGATE, ROUNDS, D, 2>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
+        default: dma_interp_loop<NEGATE, ROUNDS, D, 3>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
     }
-
-    int slot = 0;                                                     // slot of step k = k % R
-    for (int k = 0; k < steps; ++k) {
-        const int t = t_first + k;
-        const bool valid = in_range(t);
-        if (valid) wait_vmcnt(issued - mark[0]);                      // my pieces of plane k have landed
-        __syncthreads();                                              // everyone's have; plane k-1 is retired
-        {
-            const int tn = t + D;
-            int sn = slot + D; if (sn >= R) sn -= R;                  // = slot of plane k-1, free now
-            if (in_range(tn)) {
-                dma_plane<ROUNDS, NEGATE>(sp + (size_t)tn * tstride, ring_addr + sn * slot_bytes, cs, d.cells);
-                issued += nr;
-            }
-#pragma unroll
-            for (int j = 0; j + 1 < D; ++j) mark[j] = mark[j + 1];
-            mark[D - 1] = issued;
-        }
-        const float4* cur = ring + slot * slot_f4;
-        const int to = k - 1;                                         // = t - flT - 1
-        const bool emit = to >= 0;                                    // to <= T-1 always
-        float4* out = reinterpret_cast<float4*>(dp + (size_t)(emit ? to : 0) * tstride);
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            if (!wave_round_on(i, d.cells)) continue;
-            float4 Bc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) {
-                float a[5], b[5];
-                pick5(lds_b128(cur + cs.a0[i]), lds_b128(cur + cs.a1[i]), off, a);
-                pick5(lds_b128(cur + cs.b0[i]), lds_b128(cur + cs.b1[i]), off, b);
-                Bc.x = uH * (a[0] * uW + a[1] * rW) + rH * (b[0] * uW + b[1] * rW);
-                Bc.y = uH * (a[1] * uW + a[2] * rW) + rH * (b[1] * uW + b[2] * rW);
-                Bc.z = uH * (a[2] * uW + a[3] * rW) + rH * (b[2] * uW + b[3] * rW);
-                Bc.w = uH * (a[3] * uW + a[4] * rW) + rH * (b[3] * uW + b[4] * rW);
-            }
-            if (emit && cs.live[i]) {
-                float4 o;
-                o.x = uT * Bprev[i].x + rT * Bc.x;
-                o.y = uT * Bprev[i].y + rT * Bc.y;
-                o.z = uT * Bprev[i].z + rT * Bc.z;
-                o.w = uT * Bprev[i].w + rT * Bc.w;
-                stream_store<(NEGATE ? RK_NT_BWD : RK_NT_FWD) != 0>(out + cs.cell[i], o);
-            }
-            Bprev[i] = Bc;
-        }
-        if (emit) issued += nr;
-        if (++slot == R) slot = 0;
-    }
-}
-
-// compile-time pick5: the 5 consecutive values starting OFF floats into the aligned pair (q0, q1)
-template <int OFF> __device__ __forceinline__ float tap(const float4& q0, const float4& q1, int k) {
-    const int j = OFF + k;   // 0..7, constant after unrolling
-    return j == 0 ? q0.x : j == 1 ? q0.y : j == 2 ? q0.z : j == 3 ? q0.w : j == 4 ? q1.x : j == 5 ? q1.y
-         : j == 6 ? q1.z : q1.w;
-}
-
-// Geometry with the invariant the launchers guarantee (ROUNDS = ceil(cells / 256)): rounds
-// 0 .. ROUNDS-2 are FULL (every lane of every wave owns a cell), only the last round is ragged.
-// So only the tail round carries a wave-uniform "on" test and a lane mask.
-template <int ROUNDS> struct TCells {
-    int off16[ROUNDS];                                   // byte offset of the own cell inside a plane / slot
-    int a0[ROUNDS], a1[ROUNDS], b0[ROUNDS], b1[ROUNDS];  // tap float4 indices (zero cell if outside)
-    int xown;                                            // tail round: own float4 index, or the zero cell if dead
-    bool tail_live;                                      // tail round: this lane owns a cell
-    bool tail_on;                                        // tail round: this WAVE owns at least one cell (uniform)
-};
-
-template <int ROUNDS>
-__device__ __forceinline__ void make_tcells(TCells<ROUNDS>& cs, const SDims& d, int flH, int group_shift) {
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        const int raw = (int)threadIdx.x + kBlock * i;
-        const bool live = raw < d.cells;
-        const int cell = live ? raw : d.cells - 1;
-        cs.off16[i] = cell * 16;
-        const int h = cell / d.W4, w4 = cell - h * d.W4;
-        const int ra = h + flH, rb = ra + 1, ga = w4 + group_shift, gb = ga + 1;
-        const bool ra_ok = ra >= 0 && ra < d.H, rb_ok = rb >= 0 && rb < d.H;
-        const bool ga_ok = ga >= 0 && ga < d.W4, gb_ok = gb >= 0 && gb < d.W4;
-        const int zero = d.cells;
-        cs.a0[i] = (ra_ok && ga_ok) ? ra * d.W4 + ga : zero;
-        cs.a1[i] = (ra_ok && gb_ok) ? ra * d.W4 + gb : zero;
-        cs.b0[i] = (rb_ok && ga_ok) ? rb * d.W4 + ga : zero;
-        cs.b1[i] = (rb_ok && gb_ok) ? rb * d.W4 + gb : zero;
-        if (i == ROUNDS - 1) { cs.tail_live = live; cs.xown = live ? cell : zero; }
-    }
-    cs.tail_on = wave_round_on(ROUNDS - 1, d.cells);
-}
-
-#if RK_NT_LOADS_BWD
-#define RK_BWD_LD_NT " nt"
-#else
-#define RK_BWD_LD_NT ""
-#endif
-// One wave-instruction of LDS-DMA in the saddr form: lane l copies 16 B from (sbase + voff_l) to LDS byte
-// address lds_dst + 16*l.  An s_waitcnt lgkmcnt(0) in front orders it behind this wave's earlier LDS reads
-// of the slot being refilled.
-__device__ __forceinline__ void dma16s(const void* sbase_uniform, int voff, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "global_load_lds_dwordx4 %1, %2" RK_BWD_LD_NT "\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
-        : "memory");
-}
-
-// DMA one plane (uniform global pointer `plane`) into the slot at LDS byte address `slot_addr`.
-// Returns the number of VMEM instructions this wave issued.
-template <int ROUNDS>
-__device__ __forceinline__ int dma_plane_t(const float* plane, unsigned slot_addr, const TCells<ROUNDS>& cs) {
-    const unsigned wave = __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6);
-    const unsigned dst = slot_addr + wave * 1024u;                   // chunk (wave + 4 i) of 64 cells
-#pragma unroll
-    for (int i = 0; i + 1 < ROUNDS; ++i) dma16s(plane, cs.off16[i], dst + 4096u * i);
-    if (cs.tail_on) {
-        if (cs.tail_live) dma16s(plane, cs.off16[ROUNDS - 1], dst + 4096u * (ROUNDS - 1));
-        return ROUNDS;
-    }
-    return ROUNDS - 1;
-}
-
-template <int ROUNDS>
-__device__ __forceinline__ void zero_plane_t(float4* slot, const TCells<ROUNDS>& cs) {
-    char* base = reinterpret_cast<char*>(slot);
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i)
-        *reinterpret_cast<float4*>(base + cs.off16[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward, all loads by LDS-DMA: d(x) + d(shift) partials (WRITE_GX) or the partials alone.
-// Maths = stream3d::k3d_stream_backward (adjoint form; gx in the reference's tree, bit-identical).
+// Backward: d(x) + d(shift) partials (WRITE_GX) or the partials alone.  One partial per
+// (n, c, band): part[c][3][P], P = N * nbands, p = n * nbands + band.
 //   gy: ring of D+1 tap slots (plane tg needed whole for the taps while D more are in flight)
-//   x : ring of D landing slots; a wave only ever reads back the cells it DMA'd itself (its own
-//       aligned cells), into the 2-plane register window (x[to], x[to+1]) at the top of the step,
-//       which frees the slot for the plane D steps ahead.
-// The first version of this loop was instruction-issue bound (a lone workgroup needs ~3.5 us per
-// step whatever the prefetch depth; 308 of ~650 VALU instructions were v_mov from a runtime tap
-// selection, from merging "plane out of range -> 0" with computed values, and from masking).
-// Hence: the tap offset (flW mod 4) is a template parameter (the kernel switches once into one
-// of four copies of the loop); an out-of-range plane is a slot of zeros, filled with plain LDS
-// stores where its DMA would have been issued, so the step body has no validity branches or
-// masks; the full rounds carry no liveness tests at all; lanes past the end of the plane (tail
-// round) read x from a zero cell, so they add nothing.
-template <int ROUNDS, bool WRITE_GX, int D, int OFF>
+//   x : ring of D landing slots; a wave only reads back the cells it DMA'd itself (its own aligned
+//       cells), into the 2-plane register window (x[to], x[to+1]) at the top of the step, which
+//       frees the slot for the plane D steps ahead.
+template <int ROUNDS, bool WRITE_GX, int DG, int DX, int OFF>
 __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
-                                                  float* __restrict__ op, float4* ring, const SDims& d,
-                                                  const Frac<float>& fT, const Frac<float>& fH,
+                                                  float* __restrict__ op, float4* ring, const BDims& d,
+                                                  const Band& b, const Frac<float>& fT, const Frac<float>& fH,
                                                   const Frac<float>& fW, size_t tstride, float& accT, float& accH,
                                                   float& accW) {
-    constexpr int RG = D + 1, RX = D;
-    const int slot_f4 = d.cells + 1;
-    TCells<ROUNDS> cs;
-    make_tcells<ROUNDS>(cs, d, fH.fl, (fW.fl - OFF) / 4);
+    static_assert(DG >= DX && DX >= 1, "gy runs at least as far ahead as x");
+    constexpr int RG = DG + 1, RX = DX;
+    const int gslot_f4 = b.cells_in + 1, xslot_f4 = b.cells_out + 1;
+    BCells<ROUNDS> cs;
+    make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
     float4* const gring = ring;
-    float4* const xring = ring + RG * slot_f4;
-    if (threadIdx.x < RG + RX) ring[threadIdx.x * slot_f4 + d.cells] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* const xring = ring + RG * gslot_f4;
+    init_tap_slots<ROUNDS>(gring, RG, gslot_f4, b, cs);
+    if (threadIdx.x < RX) xring[threadIdx.x * xslot_f4 + b.cells_out] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float rT = fT.r, rH = fH.r, rW = fW.r;
     const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
     const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(gring));
     const unsigned xaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(xring));
-    const unsigned slot_bytes = (unsigned)slot_f4 * 16u;
+    const unsigned gslot_bytes = (unsigned)gslot_f4 * 16u, xslot_bytes = (unsigned)xslot_f4 * 16u;
+    const float* gsrc0 = gp + (ptrdiff_t)b.src0 * 4;
+    const float* xsrc0 = xp + (size_t)b.out0 * 4;
+    float* out0 = WRITE_GX ? op + (size_t)b.out0 * 4 : nullptr;
 
     float4 xa[ROUNDS], xb[ROUNDS], Qprev[ROUNDS];
 #pragma unroll
@@ -377,16 +360,37 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     const int t_first = fT.fl, steps = d.T + 1;
     auto in_range = [&](int t) { return t >= 0 && t < d.T; };
     int issued = 0;
-    // bring plane (gy: tg, x: tx) into its slot: DMA when it exists, zeros when it does not
-    auto feed = [&](int tg, int gs, int tx, int xs) {
-        if (in_range(tg)) issued += dma_plane_t<ROUNDS>(gp + (size_t)tg * tstride, gaddr + gs * slot_bytes, cs);
-        else zero_plane_t<ROUNDS>(gring + gs * slot_f4, cs);
-        if (in_range(tx)) issued += dma_plane_t<ROUNDS>(xp + (size_t)tx * tstride, xaddr + xs * slot_bytes, cs);
-        else zero_plane_t<ROUNDS>(xring + xs * slot_f4, cs);
+    auto feed = [&](int tg, int gs, int tx, int xs) {               // DMA when the plane exists, zeros when not
+        if (in_range(tg)) {
+            dma_taps<ROUNDS>(gsrc0 + (ptrdiff_t)tg * (ptrdiff_t)tstride, gaddr + gs * gslot_bytes, cs);
+            issued += cs.n_tap_wave;
+        } else {
+            zero_taps<ROUNDS>(gring + gs * gslot_f4, cs);
+        }
+        if (in_range(tx)) {
+            dma_own<ROUNDS>(xsrc0 + (size_t)tx * tstride, xaddr + xs * xslot_bytes, cs);
+            issued += cs.n_out_wave;
+        } else {
+            zero_own<ROUNDS>(xring + xs * xslot_f4, cs);
+        }
     };
-    int mark[D];                       // `issued` after the DMAs that feed step k+j (j = 0..D-1)
+    // marks follow the stream that is issued last for a step (x, DX ahead); gy for the same step went out
+    // earlier (DG >= DX) and VMEM retires in order
+    int mark[DX];
 #pragma unroll
-    for (int j = 0; j < D; ++j) { feed(t_first + j, j, j, j); mark[j] = issued; }
+    for (int j = 0; j < DG; ++j) {
+        if (in_range(t_first + j)) {
+            dma_taps<ROUNDS>(gsrc0 + (ptrdiff_t)(t_first + j) * (ptrdiff_t)tstride, gaddr + j * gslot_bytes, cs);
+            issued += cs.n_tap_wave;
+        } else {
+            zero_taps<ROUNDS>(gring + j * gslot_f4, cs);
+        }
+        if (j < DX) {
+            if (in_range(j)) { dma_own<ROUNDS>(xsrc0 + (size_t)j * tstride, xaddr + j * xslot_bytes, cs); issued += cs.n_out_wave; }
+            else zero_own<ROUNDS>(xring + j * xslot_f4, cs);
+            mark[j] = issued;
+        }
+    }
 
     // one round of one step: fields of the gy plane at this thread's cell meet x[to], x[to+1]
     auto round = [&](int i, const float4* cur, float4* out, bool store) {
@@ -415,64 +419,74 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
                 o.y = uT * Qprev[i].y + rT * q[1];
                 o.z = uT * Qprev[i].z + rT * q[2];
                 o.w = uT * Qprev[i].w + rT * q[3];
-                stream_store<RK_NT_BWD != 0>(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off16[i]), o);
+                stream_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off0 + 4096 * i), o);
             }
             Qprev[i] = make_float4(q[0], q[1], q[2], q[3]);
         }
     };
 
     int gslot = 0, xslot = 0;
-    for (int k = 0; k < steps; ++k) {
+    // one step; EMIT is a compile-time flag (step 0 produces no output plane): a run-time flag here costs
+    // ~55 VGPRs in hipcc's allocation of this loop
+    auto step = [&](int k, auto emit_tag) {
+        constexpr bool EMIT = decltype(emit_tag)::value;
         wait_vmcnt(issued - mark[0]);                             // my pieces of gy(tg) and x[k] have landed
         __syncthreads();                                          // everyone's gy pieces have; step k-1 retired
-        const char* xs = reinterpret_cast<const char*>(xring + xslot * slot_f4);
+        const char* xs = reinterpret_cast<const char*>(xring + xslot * xslot_f4);
 #pragma unroll
         for (int i = 0; i + 1 < ROUNDS; ++i) {                    // window: x[k-1], x[k]
             xa[i] = xb[i];
-            xb[i] = *reinterpret_cast<const float4*>(xs + cs.off16[i]);
+            xb[i] = *reinterpret_cast<const float4*>(xs + cs.off0 + 4096 * i);
         }
         xa[ROUNDS - 1] = xb[ROUNDS - 1];
         xb[ROUNDS - 1] = reinterpret_cast<const float4*>(xs)[cs.xown];
         {
-            int gs = gslot + D; if (gs >= RG) gs -= RG;           // gy slot of plane k-1: free now
-            feed(t_first + k + D, gs, k + D, xslot);              // (its DMA waits for the LDS reads above)
+            int gs = gslot + DG; if (gs >= RG) gs -= RG;          // gy slot of plane k-1: free now
+            feed(t_first + k + DG, gs, k + DX, xslot);            // (the DMA waits for the LDS reads above)
 #pragma unroll
-            for (int j = 0; j + 1 < D; ++j) mark[j] = mark[j + 1];
-            mark[D - 1] = issued;
+            for (int j = 0; j + 1 < DX; ++j) mark[j] = mark[j + 1];
+            mark[DX - 1] = issued;
         }
-        const float4* cur = gring + gslot * slot_f4;
-        const bool emit = WRITE_GX && k >= 1;                     // output plane to = k - 1
-        float4* out = reinterpret_cast<float4*>(op + (size_t)(emit ? k - 1 : 0) * tstride);
+        const float4* cur = gring + gslot * gslot_f4;
+        constexpr bool emit = WRITE_GX && EMIT;                   // output plane to = k - 1
+        float4* out = reinterpret_cast<float4*>(out0 + (size_t)(emit ? k - 1 : 0) * tstride);
 #pragma unroll
         for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, out, emit);
         if (cs.tail_on) round(ROUNDS - 1, cur, out, emit && cs.tail_live);
-        if (emit) issued += cs.tail_on ? ROUNDS : ROUNDS - 1;
+        if (emit) issued += cs.n_out_wave;
         if (++gslot == RG) gslot = 0;
         if (++xslot == RX) xslot = 0;
-    }
+    };
+    step(0, std::false_type{});
+#pragma nounroll
+    for (int k = 1; k < steps; ++k) step(k, std::true_type{});
     accT = sT; accH = sH; accW = sW;
 }
 
-// (forcing <= 128 VGPRs with __launch_bounds__(256, 4) spills 32 B/lane and measures 13% slower)
-template <int ROUNDS, bool WRITE_GX, int D>
+// (forcing <= 128 VGPRs with __launch_bounds__(256, 4) on an earlier version spilled and ran 13% slower)
+template <int ROUNDS, bool WRITE_GX, int DG, int DX>
 __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restrict__ x,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gy,
                                                            float* __restrict__ gx,
-                                                           float* __restrict__ part, SDims d, Dims3 gd) {
+                                                           float* __restrict__ part, BDims d, Dims3 gd) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[3][kBlock / kWave];
-    const int c = blockIdx.x % d.C, n = blockIdx.x / d.C;
+    const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
+    const int c = col % d.C, n = col / d.C;
     const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
     float accT = 0.f, accH = 0.f, accW = 0.f;
 
     if (split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0) {
-        // exactly-integer component (lowered-index quirk / zero-shift copy branch): rare, per element
-        if (WRITE_GX)
-            for (int t = 0; t < d.T; ++t)
-                backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
-        for (int to = 0; to < d.T; ++to)
-            shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
+        // exactly-integer component (lowered-index quirk / zero-shift copy branch): rare, per element.
+        // Band 0 does the whole column; the other bands contribute zero partials.
+        if (band == 0) {
+            if (WRITE_GX)
+                for (int t = 0; t < d.T; ++t)
+                    backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+            for (int to = 0; to < d.T; ++to)
+                shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
+        }
     } else {
         const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r'
         const int HW = d.H * d.W;
@@ -480,11 +494,12 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
         const float* xp = x + ((size_t)n * d.T * d.C + c) * HW;
         const float* gp = gy + ((size_t)n * d.T * d.C + c) * HW;
         float* op = WRITE_GX ? gx + ((size_t)n * d.T * d.C + c) * HW : nullptr;
+        const Band b = make_band(d, band, fH.fl);
         switch (((fW.fl % 4) + 4) % 4) {   // wave-uniform; one specialised copy of the loop per tap offset
-            case 0: dma_backward_loop<ROUNDS, WRITE_GX, D, 0>(xp, gp, op, ring, d, fT, fH, fW, tstride, accT, accH, accW); break;
-            case 1: dma_backward_loop<ROUNDS, WRITE_GX, D, 1>(xp, gp, op, ring, d, fT, fH, fW, tstride, accT, accH, accW); break;
-            case 2: dma_backward_loop<ROUNDS, WRITE_GX, D, 2>(xp, gp, op, ring, d, fT, fH, fW, tstride, accT, accH, accW); break;
-            default: dma_backward_loop<ROUNDS, WRITE_GX, D, 3>(xp, gp, op, ring, d, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 0: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 0>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 1: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 1>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 2: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 2>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            default: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 3>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
         }
     }
 
@@ -492,77 +507,106 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
     accH = group_sum(accH, kBlock, red[1]);
     accW = group_sum(accW, kBlock, red[2]);
     if (threadIdx.x == 0) {
-        float* o = part + (size_t)c * 3 * d.N + n;
+        const int P = d.N * d.nbands;
+        float* o = part + (size_t)c * 3 * P + (size_t)n * d.nbands + band;
         o[0] = accT;
-        o[d.N] = accH;
-        o[2 * d.N] = accW;
+        o[P] = accH;
+        o[2 * P] = accW;
     }
 }
 
-inline size_t ring_bytes(const SDims& s, int D) { return (size_t)(D + 1) * (s.cells + 1) * 16; }
+// ---------------------------------------------------------------------------------------------
+// Host side: band choice and launchers.
+inline bool env_force_generic() {
+    static const bool v = [] { const char* e = getenv("RK_FORCE_GENERIC"); return e && e[0] == '1'; }();
+    return v;
+}
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+inline int rounds_for(int cells) { return (cells + kBlock - 1) / kBlock; }
+
+// Equal bands with (BH + 1) * W4 <= 1024 cells and the same number of rounds on the tap side and on the
+// output side (so rounds 0..ROUNDS-2 are full).  false = shape not handled by the DMA kernels.
+inline bool make_bdims(BDims& b, const Dims3& d) {
+    const bool s1p0 = d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0;
+    if (!s1p0 || d.W % 4 != 0 || d.W < 4 || env_force_generic()) return false;
+    b.N = d.N; b.T = d.T; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
+    for (int nb = 1; nb <= d.H; ++nb) {
+        if (d.H % nb) continue;
+        const int bh = d.H / nb, co = bh * b.W4, ci = (bh + 1) * b.W4;
+        if (ci > 4 * kBlock) continue;
+        if (rounds_for(co) != rounds_for(ci)) continue;
+        b.nbands = nb; b.BH = bh;
+        return true;
+    }
+    return false;
+}
+inline int rounds_of(const BDims& b) { return rounds_for((b.BH + 1) * b.W4); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline size_t interp_ring_bytes(const BDims& b, int D) { return (size_t)(D + 1) * ((b.BH + 1) * b.W4 + 1) * 16; }
+inline size_t bwd_ring_bytes(const BDims& b, int DG, int DX) {
+    return ((size_t)(DG + 1) * ((b.BH + 1) * b.W4 + 1) + (size_t)DX * (b.BH * b.W4 + 1)) * 16;
+}
 
 template <bool NEGATE, int D>
-inline void launch_interp_d(const float* src, const float* shift, float* dst, const SDims& s, hipStream_t stream) {
-    const size_t lds = ring_bytes(s, D);
-    const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);
-    switch ((s.cells + kBlock - 1) / kBlock) {
-        case 1: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 1, D>), grid, block, lds, stream, src, shift, dst, s); break;
-        case 2: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 2, D>), grid, block, lds, stream, src, shift, dst, s); break;
-        case 3: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 3, D>), grid, block, lds, stream, src, shift, dst, s); break;
-        default: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 4, D>), grid, block, lds, stream, src, shift, dst, s); break;
+inline void launch_interp_d(const float* src, const float* shift, float* dst, const BDims& b, hipStream_t stream) {
+    const size_t lds = interp_ring_bytes(b, D);
+    const dim3 grid((unsigned)(b.N * b.C * b.nbands)), block(kBlock);
+    switch (rounds_of(b)) {
+        case 1: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 1, D>), grid, block, lds, stream, src, shift, dst, b); break;
+        case 2: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 2, D>), grid, block, lds, stream, src, shift, dst, b); break;
+        case 3: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 3, D>), grid, block, lds, stream, src, shift, dst, b); break;
+        default: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 4, D>), grid, block, lds, stream, src, shift, dst, b); break;
     }
 }
 
-inline int env_depth() {   // RK_DMA = 0 (register-staged kernels), 1..3 = planes in flight per column
-    static const int v = [] { const char* e = getenv("RK_DMA"); return e ? atoi(e) : 2; }();
-    return v;
-}
-
+// forward / d(x)-only; false = not handled here.  RK_DMA = planes in flight per column (1..3), 0 disables.
 template <bool NEGATE>
-inline bool launch_interp(const float* src, const float* shift, float* dst, const SDims& s, hipStream_t stream) {
-    switch (env_depth()) {
-        case 1: launch_interp_d<NEGATE, 1>(src, shift, dst, s, stream); return true;
-        case 2: launch_interp_d<NEGATE, 2>(src, shift, dst, s, stream); return true;
-        case 3: launch_interp_d<NEGATE, 3>(src, shift, dst, s, stream); return true;
-        default: return false;
-    }
-}
-
-inline size_t bwd_ring_bytes(const SDims& s, int D) { return (size_t)(2 * D + 1) * (s.cells + 1) * 16; }
-
-template <bool WRITE_GX, int D>
-inline void launch_bwd_d(const float* x, const float* shift, const float* gy, float* gx, float* ws, const SDims& s,
-                         const Dims3& d, hipStream_t stream) {
-    const size_t lds = bwd_ring_bytes(s, D);
-    const dim3 grid((unsigned)(s.N * s.C)), block(kBlock);
-    switch ((s.cells + kBlock - 1) / kBlock) {
-        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, D>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, D>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, D>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, D>), grid, block, lds, stream, x, shift, gy, gx, ws, s, d); break;
-    }
-}
-
-inline int env_bwd_depth() {   // RK_DMA_BWD = 0 (register-staged kernel), 1..3 = planes in flight per stream
-    static const int v = [] { const char* e = getenv("RK_DMA_BWD"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
-// d(shift) partials (+ d(x) when gx != nullptr); false = not handled here
-inline bool launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* ws, const SDims& s,
-                       const Dims3& d, hipStream_t stream) {
-    const int D = env_bwd_depth();
-    if (D < 1 || D > 3 || bwd_ring_bytes(s, D) + 64 > 160 * 1024) return false;
-    if (gx) {
-        if (D == 1) launch_bwd_d<true, 1>(x, shift, gy, gx, ws, s, d, stream);
-        else if (D == 2) launch_bwd_d<true, 2>(x, shift, gy, gx, ws, s, d, stream);
-        else launch_bwd_d<true, 3>(x, shift, gy, gx, ws, s, d, stream);
-    } else {
-        if (D == 1) launch_bwd_d<false, 1>(x, shift, gy, gx, ws, s, d, stream);
-        else if (D == 2) launch_bwd_d<false, 2>(x, shift, gy, gx, ws, s, d, stream);
-        else launch_bwd_d<false, 3>(x, shift, gy, gx, ws, s, d, stream);
-    }
+inline bool launch_interp(const float* src, const float* shift, float* dst, const Dims3& d, hipStream_t stream) {
+    static const int depth = env_int("RK_DMA", 2);
+    BDims b;
+    if (depth < 1 || depth > 3 || !make_bdims(b, d) || !aligned16(src) || !aligned16(dst)) return false;
+    if (interp_ring_bytes(b, depth) > 64 * 1024) return false;
+    if (depth == 1) launch_interp_d<NEGATE, 1>(src, shift, dst, b, stream);
+    else if (depth == 2) launch_interp_d<NEGATE, 2>(src, shift, dst, b, stream);
+    else launch_interp_d<NEGATE, 3>(src, shift, dst, b, stream);
     return true;
+}
+
+template <bool WRITE_GX, int DG, int DX>
+inline void launch_bwd_d(const float* x, const float* shift, const float* gy, float* gx, float* ws, const BDims& b,
+                         const Dims3& d, hipStream_t stream) {
+    const size_t lds = bwd_ring_bytes(b, DG, DX);
+    const dim3 grid((unsigned)(b.N * b.C * b.nbands)), block(kBlock);
+    switch (rounds_of(b)) {
+        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
+        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
+        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
+        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
+    }
+}
+
+// d(shift) partials (+ d(x) when gx != nullptr) into ws[C][3][P]; returns P (0 = not handled here).
+// RK_DMA_BWD = "<DG><DX>" planes in flight for gy / x: 11 (default), 21 or 22; 0 disables.
+inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* ws, const Dims3& d,
+                      hipStream_t stream) {
+    static const int depth = env_int("RK_DMA_BWD", 11);
+    BDims b;
+    if (depth <= 0 || !make_bdims(b, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
+    const int DG = depth / 10, DX = depth % 10;
+    if (!((DG == 1 && DX == 1) || (DG == 2 && DX == 1) || (DG == 2 && DX == 2))) return 0;
+    if (bwd_ring_bytes(b, DG, DX) > 64 * 1024) return 0;
+#define RK_BWD_CASE(G, X)                                                                          \
+    if (DG == G && DX == X) {                                                                      \
+        if (gx) launch_bwd_d<true, G, X>(x, shift, gy, gx, ws, b, d, stream);                      \
+        else launch_bwd_d<false, G, X>(x, shift, gy, gx, ws, b, d, stream);                        \
+    }
+    RK_BWD_CASE(1, 1) RK_BWD_CASE(2, 1) RK_BWD_CASE(2, 2)
+#undef RK_BWD_CASE
+    return b.N * b.nbands;
 }
 
 }  // namespace dma3d
