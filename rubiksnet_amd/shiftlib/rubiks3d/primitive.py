@@ -168,4 +168,11 @@ def rubiks_shift_3d(x, shift, stride=1, padding=0, normalize_grad=True, normaliz
         normalize_t_factor = T / H
     else:
         assert isinstance(normalize_t_factor, (int, float))
+    if x.dtype in (torch.float16, torch.bfloat16):
+        # autocast hands half activations to an fp32 parameter.  The reference's 3D op exists in fp32/fp64 only
+        # (primitive.py:66-75): run it in fp32 and hand back the caller's dtype (the explicit-dtype primitives
+        # below still raise for half inputs, as the reference does).
+        y = RubiksShift3DFunc.apply(x.float(), shift.float(), stride, padding, normalize_grad, normalize_t_factor,
+                                    quantize)
+        return y.to(x.dtype)
     return RubiksShift3DFunc.apply(x, shift, stride, padding, normalize_grad, normalize_t_factor, quantize)

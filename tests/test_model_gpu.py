@@ -1,0 +1,92 @@
+"""GPU tests of the callers of the hot path: RubiksNet end to end on the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_installation_smoke_large():
+    """The reference's scripts/test_installation.py: Large, 42 classes, randn(2,8,3,224,224) -> [2,42]."""
+    from rubiksnet_amd import RubiksNet
+
+    torch.manual_seed(0)
+    net = RubiksNet(tier="large", num_classes=42, num_frames=8, verbose=False).to(DEV)
+    video = torch.randn((2, 8, 3, 224, 224), device=DEV)
+    out = net(video)
+    assert out.shape == (2, 42) and torch.isfinite(out).all()
+
+
+def test_tiny_overfits_random_batch():
+    """README.md:104-106 of the reference: the loss should fall on random data."""
+    from rubiksnet_amd import RubiksNet, dp
+
+    torch.manual_seed(0)
+    net = RubiksNet("tiny", 5, verbose=False).to(DEV)
+    opt = dp.make_optimizer(net, lr=0.01, lr_shift_mult=0.1, kind="sgd")
+    clips = torch.randn(4, 8, 3, 224, 224, device=DEV)
+    labels = torch.tensor([0, 1, 2, 3], device=DEV)
+    losses = [float(dp.train_step(net, opt, clips, labels)) for _ in range(12)]
+    assert losses[-1] < 0.6 * losses[0], losses
+    shifts = [p for n, p in net.named_parameters() if n.endswith("shift")]
+    assert len(shifts) == 17 and all(p.grad is not None and torch.isfinite(p.grad).all() for p in shifts)
+    # every replica-local shift gradient is L2-normalised per channel (K5)
+    g = shifts[3].grad
+    norms = g.norm(dim=0)
+    assert torch.allclose(norms[norms > 0], torch.ones_like(norms[norms > 0]), atol=1e-4)
+
+
+def test_model_shift_layers_match_oracle(oracle):
+    """Every RubiksShift3D inside RubiksNet-Tiny (all 9 distinct shapes incl. stride (1,2,2), 112x112 bands,
+    14x14 and 7x7 planes) reproduces the oracle on the activations it actually sees."""
+    from rubiksnet_amd import RubiksNet
+    from rubiksnet_amd.shiftlib import RubiksShift3D
+
+    torch.manual_seed(1)
+    net = RubiksNet("tiny", 7, verbose=False).to(DEV).eval()
+    seen = {}
+
+    def hook(mod, inp, out):
+        key = (tuple(inp[0].shape), tuple(mod.stride))
+        if key not in seen:
+            seen[key] = (inp[0].detach().cpu().numpy(), mod.shift.detach().cpu().numpy(), mod.stride, mod.padding,
+                         out.detach().cpu().numpy())
+
+    hs = [m.register_forward_hook(hook) for m in net.modules() if isinstance(m, RubiksShift3D)]
+    with torch.no_grad():
+        net(torch.randn(1, 8, 3, 224, 224, device=DEV))
+    for h in hs:
+        h.remove()
+    assert len(seen) == 9
+    for (shape, stride), (x, shift, s, p, y) in seen.items():
+        np.testing.assert_array_equal(y, oracle.rk3d_forward(x, shift, s, p), err_msg=str((shape, stride)))
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_aq_variant_trains(amp):
+    """BASELINE configs[4]: the attention-quantized variant (2D shift + AttentionShift), fp32 and bf16 autocast."""
+    from rubiksnet_amd import RubiksNet, dp
+
+    torch.manual_seed(0)
+    net = RubiksNet("tiny", 6, variant="rubiks3d-aq", verbose=False).to(DEV)
+    opt = dp.make_optimizer(net, lr=1e-3)
+    clips = torch.randn(2, 8, 3, 224, 224, device=DEV)
+    labels = torch.tensor([1, 4], device=DEV)
+    with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+        loss = dp.train_step(net, opt, clips, labels)
+    assert torch.isfinite(loss)
+    att = [p for n, p in net.named_parameters() if n.endswith("conv2.0.weight")]
+    assert len(att) == 17 and all(p.grad is not None and torch.isfinite(p.grad).all() for p in att)
+
+
+def test_rubiks3d_variant_under_autocast():
+    from rubiksnet_amd import RubiksNet
+
+    torch.manual_seed(0)
+    net = RubiksNet("tiny", 6, verbose=False).to(DEV)
+    clips = torch.randn(1, 8, 3, 224, 224, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(clips)
+    out.float().sum().backward()
+    assert torch.isfinite(out.float()).all()
