@@ -4,6 +4,7 @@
 #include "rk3d_generic.hpp"
 #include "rk3d_stream.hpp"
 #include "rk3d_dma.hpp"
+#include "rk3d_column.hpp"
 
 #include <type_traits>
 
@@ -49,6 +50,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
     }
     if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
+    if (col3d::supported(d, quantize)) return col3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);
     const unsigned grid = grid_for(d, (long long)d.N * d.To * d.C);
     if (quantize)
@@ -84,6 +86,12 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
     }
     if (stream3d::backward_supported<T>(d, quantize, x, gy, gx))
         return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
+    if (gshift && col3d::supported(d, quantize)) {
+        const int P = col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream);
+        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(kBlock), 0, stream, (const T*)ws, gshift, d.C, P,
+                           normalize_grad, t_factor);
+        return launch_status();
+    }
 
     if (gshift) {   // rubiks.cpp:324-358
         T* part = (T*)ws;
@@ -112,11 +120,15 @@ extern "C" {
 
 size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH,
                                      int pW, int elem_size) {
-    (void)W; (void)sH; (void)sW; (void)pH; (void)pW;
+    (void)sH; (void)sW; (void)pH; (void)pW;
     if (N <= 0 || T <= 0 || C <= 0 || sT <= 0 || pT < 0) return 0;
     // partials part[C][3][P]: P = N*To for the generic kernels, N*nbands (row bands) for the streaming ones
     size_t per_n = (size_t)out_len(T, sT, pT);
-    if (H > 0 && (size_t)H > per_n) per_n = (size_t)H;    // nbands <= H
+    if (H > 0 && (size_t)H > per_n) per_n = (size_t)H;    // row bands: nbands <= H
+    if (H > 0 && W > 0) {                                 // column kernels: 256-element chunks at most
+        const size_t chunks = ((size_t)H * (size_t)W + 255) / 256;
+        if (chunks > per_n) per_n = chunks;
+    }
     const size_t P = (size_t)N * per_n;
     return (size_t)C * 3 * P * (size_t)elem_size;
 }

@@ -1,0 +1,266 @@
+// rk3d_column.hpp -- RubiksShift3D "column" kernels: any spatial stride / padding, any H x W,
+// fp32 and fp64, temporal stride 1 / pad 0, quantize off.
+//
+// These take every layer of the networks that the LDS-DMA kernels (rk3d_dma.hpp) do not:
+// the four stride-(1,2,2) down-sampling layers of each net, and the 14x14 / 7x7 planes
+// (W % 4 != 0), where the per-plane generic kernels spend their time on set-up (one 196-element
+// plane per workgroup: 6-15 % of the HBM roofline at [32,8,288,14,14]).
+//
+// Same T-walk as the streaming kernels -- a group of E threads owns one (n, c) column (or one
+// 1024-element chunk of it) and walks t, so the channel's shift, the per-element tap offsets and
+// validity masks are computed once, and the H/W-interpolated field of a source plane is reused by
+// the two outputs it feeds (registers).  The taps are per-element global loads served by L1/L2
+// (consecutive lanes -> consecutive addresses of one plane), so no LDS tile, no alignment or
+// width restrictions.
+//   forward : y[to] = (1-rT) B(to+flT) + rT B(to+flT+1),  B = bilinear of the 4 taps of a plane
+//             -- the reference's expression tree (rubiks3d_kernels.cu:193-203), bit-identical.
+//   backward: adjoint form on the INPUT side with the negated shift (fl', r'), tap (j,k) of an
+//             input element exists iff (h+pH+fl'H+j) % sH == 0 etc. (rubiks3d_kernels.cu:586-589):
+//             gx[t] = (1-r'T) Q(t+fl'T) + r'T Q(t+fl'T+1) (tree of :709-719, bit-identical), and
+//             gT = sum x (Q(t0) - Q(t0+1)),  gH = sum x ((1-r'T) QH(t0) + r'T QH(t0+1)),  gW alike,
+//             with QH / QW the row / column differences of the same taps.  One partial per
+//             (n, c, chunk): part[c][3][P], P = N * nchunks; k3d_finalize sums them (no atomics).
+// Channels with an exactly-integer shift component take the per-element reference formulation
+// (shared with the generic kernels) for the whole column.
+#pragma once
+#include "rk3d_generic.hpp"
+
+namespace rk {
+namespace col3d {
+
+// elements per thread M: 1 for planes that fit one group of threads (14x14, 7x7), else 4 (chunk = E * M elements)
+
+struct CDims {
+    Dims3 d;
+    int E, logE;          // threads per column group (64/128/256)
+    int nchunks;          // chunks per plane
+    int M;                // elements per thread
+};
+
+struct ColId { int n, c, chunk; bool valid; };
+
+__device__ __forceinline__ ColId my_column(const CDims& cd, int& e) {
+    const int sub = threadIdx.x >> cd.logE;
+    e = threadIdx.x & (cd.E - 1);
+    const long long id = (long long)blockIdx.x * (kBlock >> cd.logE) + sub;     // (n, c, chunk) flattened
+    ColId r;
+    r.valid = id < (long long)cd.d.N * cd.d.C * cd.nchunks;
+    const long long q = r.valid ? id : 0;
+    r.chunk = (int)(q % cd.nchunks);
+    const long long col = q / cd.nchunks;
+    r.c = (int)(col % cd.d.C);
+    r.n = (int)(col / cd.d.C);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <typename T, int kM>
+__global__ __launch_bounds__(kBlock) void k3d_forward_column(const T* __restrict__ x, const T* __restrict__ shift,
+                                                             T* __restrict__ y, CDims cd) {
+    const Dims3& d = cd.d;
+    int e;
+    const ColId id = my_column(cd, e);
+    if (!id.valid) return;
+    const Frac<T> fT = split_shift(shift[id.c]);
+    const Frac<T> fH = split_shift(shift[d.C + id.c]);
+    const Frac<T> fW = split_shift(shift[2 * d.C + id.c]);
+    const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
+    const size_t tsi = (size_t)d.C * HW, tso = (size_t)d.C * HWo;
+    const T* xc = x + ((size_t)id.n * d.T * d.C + id.c) * HW;        // (n, t = 0, c)
+    T* yc = y + ((size_t)id.n * d.To * d.C + id.c) * HWo;
+
+    // per element: flat offset of tap (0,0) in a source plane and validity of the 4 taps
+    int o00[kM], oidx[kM];
+    unsigned mask[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) {
+        const int i = id.chunk * cd.E * kM + m * cd.E + e;
+        oidx[m] = i < HWo ? i : -1;
+        const int ii = i < HWo ? i : 0;
+        const int ho = ii / d.Wo, wo = ii - ho * d.Wo;
+        const int h0 = ho * d.sH - d.pH + fH.fl, w0 = wo * d.sW - d.pW + fW.fl;
+        const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h0 + 1 >= 0 && h0 + 1 < d.H;
+        const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w0 + 1 >= 0 && w0 + 1 < d.W;
+        o00[m] = h0 * d.W + w0;
+        mask[m] = (i < HWo) ? ((mh0 && mw0 ? 1u : 0u) | (mh0 && mw1 ? 2u : 0u) | (mh1 && mw0 ? 4u : 0u) |
+                               (mh1 && mw1 ? 8u : 0u)) : 0u;
+    }
+    const T rT = fT.r, rH = fH.r, rW = fW.r;
+    T Bprev[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) Bprev[m] = 0;
+
+    const int t_first = fT.fl, t_last = d.T + fT.fl;                 // source plane index; T+1 steps
+    for (int t = t_first; t <= t_last; ++t) {
+        const bool valid = t >= 0 && t < d.T;
+        const T* p = xc + (valid ? (size_t)t * tsi : 0);
+        const int to = t - fT.fl - 1;
+        const bool emit = to >= 0 && to < d.To;
+        T* out = yc + (emit ? (size_t)to * tso : 0);
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+            T q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+            if (valid) {
+                const unsigned mk = mask[m];
+                if (mk & 1u) q00 = p[o00[m]];
+                if (mk & 2u) q01 = p[o00[m] + 1];
+                if (mk & 4u) q10 = p[o00[m] + d.W];
+                if (mk & 8u) q11 = p[o00[m] + d.W + 1];
+            }
+            const T B = (1 - rH) * (q00 * (1 - rW) + q01 * rW) + rH * (q10 * (1 - rW) + q11 * rW);
+            if (emit && oidx[m] >= 0) out[oidx[m]] = (1 - rT) * Bprev[m] + rT * B;
+            Bprev[m] = B;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- backward
+template <typename T, bool WRITE_GX, int kM>
+__global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restrict__ x, const T* __restrict__ shift,
+                                                              const T* __restrict__ gy, T* __restrict__ gx,
+                                                              T* __restrict__ part, CDims cd) {
+    __shared__ T red[3][kBlock / kWave];
+    const Dims3& d = cd.d;
+    int e;
+    const ColId id = my_column(cd, e);
+    T accT = 0, accH = 0, accW = 0;
+    if (id.valid) {
+        const T s0 = shift[id.c], s1 = shift[d.C + id.c], s2 = shift[2 * d.C + id.c];
+        if (split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0) {
+            // integer component: the reference's per-element formulation; chunk 0 does the whole column
+            if (id.chunk == 0) {
+                if (WRITE_GX)
+                    for (int t = 0; t < d.T; ++t) backward_input_plane<T, false>(shift, gy, gx, d, id.n, t, id.c, e, cd.E);
+                for (int to = 0; to < d.To; ++to)
+                    shift_grad_plane<T>(x, shift, gy, d, id.n, to, id.c, e, cd.E, accT, accH, accW);
+            }
+        } else {
+            const Frac<T> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r'
+            const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
+            const size_t tsi = (size_t)d.C * HW, tso = (size_t)d.C * HWo;
+            const T* xc = x + ((size_t)id.n * d.T * d.C + id.c) * HW;
+            const T* gc = gy + ((size_t)id.n * d.To * d.C + id.c) * HWo;
+            T* oc = WRITE_GX ? gx + ((size_t)id.n * d.T * d.C + id.c) * HW : nullptr;
+
+            // per INPUT element: gy offsets of the 4 taps (row-major in the output plane), -1 = no such tap
+            int tap[kM][4], iidx[kM];
+#pragma unroll
+            for (int m = 0; m < kM; ++m) {
+                const int i = id.chunk * cd.E * kM + m * cd.E + e;
+                iidx[m] = i < HW ? i : -1;
+                const int ii = i < HW ? i : 0;
+                const int h = ii / d.W, w = ii - h * d.W;
+                const int r0 = unmap(h + d.pH + fH.fl, d.sH, d.Ho), r1 = unmap(h + d.pH + fH.fl + 1, d.sH, d.Ho);
+                const int c0 = unmap(w + d.pW + fW.fl, d.sW, d.Wo), c1 = unmap(w + d.pW + fW.fl + 1, d.sW, d.Wo);
+                const bool live = i < HW;
+                tap[m][0] = (live && r0 >= 0 && c0 >= 0) ? r0 * d.Wo + c0 : -1;
+                tap[m][1] = (live && r0 >= 0 && c1 >= 0) ? r0 * d.Wo + c1 : -1;
+                tap[m][2] = (live && r1 >= 0 && c0 >= 0) ? r1 * d.Wo + c0 : -1;
+                tap[m][3] = (live && r1 >= 0 && c1 >= 0) ? r1 * d.Wo + c1 : -1;
+            }
+            const T rT = fT.r, rH = fH.r, rW = fW.r;
+            T xa[kM], xb[kM], Qprev[kM];
+            T sT = 0, sH = 0, sW = 0;
+#pragma unroll
+            for (int m = 0; m < kM; ++m) {
+                xa[m] = 0; Qprev[m] = 0;
+                xb[m] = iidx[m] >= 0 ? xc[iidx[m]] : (T)0;             // x[0]
+            }
+            // step on gy plane tg; to = tg - fl'T - 1 is the input plane whose gx is completed
+            const int t_first = fT.fl, t_last = d.T + fT.fl;
+            for (int tg = t_first; tg <= t_last; ++tg) {
+                const bool valid = tg >= 0 && tg < d.To;
+                const T* p = gc + (valid ? (size_t)tg * tso : 0);
+                const int to = tg - fT.fl - 1;                           // -1 .. T-1
+                const bool emit = WRITE_GX && to >= 0;
+                T* out = WRITE_GX ? oc + (emit ? (size_t)to * tsi : 0) : nullptr;
+                const bool has_next = to + 2 < d.T;
+                const T* xn = xc + (has_next ? (size_t)(to + 2) * tsi : 0);
+#pragma unroll
+                for (int m = 0; m < kM; ++m) {
+                    T q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+                    if (valid) {
+                        if (tap[m][0] >= 0) q00 = p[tap[m][0]];
+                        if (tap[m][1] >= 0) q01 = p[tap[m][1]];
+                        if (tap[m][2] >= 0) q10 = p[tap[m][2]];
+                        if (tap[m][3] >= 0) q11 = p[tap[m][3]];
+                    }
+                    const T la = q00 * (1 - rW) + q01 * rW, lb = q10 * (1 - rW) + q11 * rW;
+                    const T Q = (1 - rH) * la + rH * lb;                 // the reference's tree, contraction off
+                    const T QH = la - lb;
+                    const T QW = ((1 - rH) * q00 + rH * q10) - ((1 - rH) * q01 + rH * q11);
+                    const T dx = xb[m] - xa[m];
+                    const T mx = (1 - rT) * xb[m] + rT * xa[m];
+                    sT += Q * dx;
+                    sH += QH * mx;
+                    sW += QW * mx;
+                    if (WRITE_GX) {
+                        if (emit && iidx[m] >= 0) out[iidx[m]] = (1 - rT) * Qprev[m] + rT * Q;
+                        Qprev[m] = Q;
+                    }
+                    xa[m] = xb[m];
+                    xb[m] = (has_next && iidx[m] >= 0) ? xn[iidx[m]] : (T)0;
+                }
+            }
+            accT = sT; accH = sH; accW = sW;
+        }
+    }
+    accT = group_sum(accT, cd.E, red[0]);
+    accH = group_sum(accH, cd.E, red[1]);
+    accW = group_sum(accW, cd.E, red[2]);
+    if (id.valid && e == 0) {
+        const int P = d.N * cd.nchunks;
+        T* o = part + (size_t)id.c * 3 * P + (size_t)id.n * cd.nchunks + id.chunk;
+        o[0] = accT;
+        o[P] = accH;
+        o[2 * P] = accW;
+    }
+}
+
+// ----------------------------------------------------------------------------------- host side
+inline bool supported(const Dims3& d, int quantize) {
+    static const bool off = [] { const char* e = getenv("RK_COLUMN"); return e && e[0] == '0'; }();
+    return !off && !quantize && d.sT == 1 && d.pT == 0;
+}
+
+// plane_elems: the plane the threads index (output plane for forward, input plane for backward)
+inline CDims make_cdims(const Dims3& d, int plane_elems) {
+    CDims cd;
+    cd.d = d;
+    cd.E = pow2_at_least(plane_elems, kWave, kBlock);
+    cd.logE = (cd.E == 64) ? 6 : (cd.E == 128 ? 7 : 8);
+    cd.M = plane_elems <= cd.E ? 1 : 4;
+    cd.nchunks = (plane_elems + cd.E * cd.M - 1) / (cd.E * cd.M);
+    return cd;
+}
+inline unsigned grid_of(const CDims& cd) {
+    const long long groups = (long long)cd.d.N * cd.d.C * cd.nchunks;
+    const int per_block = kBlock / cd.E;
+    return (unsigned)((groups + per_block - 1) / per_block);
+}
+
+template <typename T>
+inline int launch_forward(const T* x, const T* shift, T* y, const Dims3& d, hipStream_t stream) {
+    const CDims cd = make_cdims(d, d.Ho * d.Wo);
+    if (cd.M == 1)
+        hipLaunchKernelGGL((k3d_forward_column<T, 1>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+    else
+        hipLaunchKernelGGL((k3d_forward_column<T, 4>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+    return launch_status();
+}
+
+// returns P (partials per channel)
+template <typename T>
+inline int launch_backward(const T* x, const T* shift, const T* gy, T* gx, T* ws, const Dims3& d,
+                           hipStream_t stream) {
+    const CDims cd = make_cdims(d, d.H * d.W);
+#define RK_COL_BWD(GX, MM) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM>), dim3(grid_of(cd)), dim3(kBlock), 0, \
+                                              stream, x, shift, gy, gx, ws, cd)
+    if (gx) { if (cd.M == 1) RK_COL_BWD(true, 1); else RK_COL_BWD(true, 4); }
+    else { if (cd.M == 1) RK_COL_BWD(false, 1); else RK_COL_BWD(false, 4); }
+#undef RK_COL_BWD
+    return d.N * cd.nchunks;
+}
+
+}  // namespace col3d
+}  // namespace rk
