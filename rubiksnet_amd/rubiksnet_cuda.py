@@ -76,6 +76,8 @@ def _forward3d(dtype, sfx, input, shift, strides, paddings, quantize, output):
     want = (N, L.rk_out_len(T, s[0], p[0]), C, L.rk_out_len(H, s[1], p[1]), L.rk_out_len(W, s[2], p[2]))
     if tuple(output.shape) != want:
         raise RuntimeError("output has shape %s, expected %s" % (tuple(output.shape), want))
+    if input.numel() == 0 or output.numel() == 0:
+        return 0          # empty batch: the reference launches over zero elements (rubiks3d_kernels.cu:34-36)
     with torch.cuda.device(dev):
         rc = getattr(L, "rk3d_forward_" + sfx)(
             input.data_ptr(), shift.data_ptr(), output.data_ptr(), N, T, C, H, W, *s, *p,
@@ -103,6 +105,10 @@ def _backward3d(dtype, sfx, input, shift, output_grad, strides, paddings, input_
         raise RuntimeError("input_grad must have the shape of input")
     if shift_grad is not None and tuple(shift_grad.shape) != (3, C):
         raise RuntimeError("shift_grad must be [3, C]")
+    if input.numel() == 0 or output_grad.numel() == 0:
+        if shift_grad is not None:
+            shift_grad.zero_()   # addmv_ over an empty scratch gives zeros (rubiks.cpp:344-345)
+        return 0
     with torch.cuda.device(dev):
         ws_bytes = L.rk3d_backward_workspace_bytes(N, T, C, H, W, *s, *p, input.element_size())
         ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev) if shift_grad is not None else None
@@ -162,6 +168,8 @@ def rubiks2d_forward(input, shift, strides, paddings, quantize, output):
     if tuple(output.shape) != want:
         raise RuntimeError("output has shape %s, expected %s" % (tuple(output.shape), want))
     sfx = _sfx2d(input)
+    if input.numel() == 0 or output.numel() == 0:
+        return 0
     with torch.cuda.device(dev):
         rc = getattr(L, "rk2d_forward_" + sfx)(
             input.data_ptr(), shift.data_ptr(), output.data_ptr(), N, C, H, W, *s, *p,
@@ -185,6 +193,10 @@ def rubiks2d_backward(upstream_grad, input, shift, strides, paddings, normalize_
     if tuple(upstream_grad.shape) != want:
         raise RuntimeError("upstream_grad has shape %s, expected %s" % (tuple(upstream_grad.shape), want))
     sfx = _sfx2d(input)
+    if input.numel() == 0 or upstream_grad.numel() == 0:
+        if enable_shift_grad:
+            shift_grad.zero_()
+        return 0
     with torch.cuda.device(dev):
         ws_bytes = L.rk2d_backward_workspace_bytes(N, C, H, W, *s, *p, input.element_size())
         ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)

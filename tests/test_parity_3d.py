@@ -238,3 +238,19 @@ def test_backward_halves_match_fused(oracle, kind):
     scale = max(1.0, float(np.abs(raw_ref).max()))
     np.testing.assert_allclose(to_np(gs_f), raw_ref, rtol=0, atol=1e-5 * scale)
     np.testing.assert_allclose(to_np(gs_only), raw_ref, rtol=0, atol=1e-5 * scale)
+
+
+def test_empty_batch_and_single_element(oracle):
+    """Edge sizes: N = 0 (the reference launches over zero elements and returns an empty tensor) and 1x1x1 planes."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d, rubiks_shift_3d_forward
+
+    shn = np.array([[0.3, -0.2], [0.1, 0.7], [-0.4, 0.2]], np.float32)
+    sh = to_dev(shn)
+    y = rubiks_shift_3d_forward(torch.zeros(0, 4, 2, 5, 5, device="cuda:0"), sh, 1, 0)
+    assert y.shape == (0, 4, 2, 5, 5)
+    x = torch.zeros(0, 4, 2, 5, 5, device="cuda:0", requires_grad=True)
+    shp = sh.clone().requires_grad_(True)
+    rubiks_shift_3d(x, shp).sum().backward()
+    assert x.grad.shape == x.shape and torch.equal(shp.grad, torch.zeros_like(shp))
+    x1 = np.full((1, 1, 2, 1, 1), 2.0, np.float32)        # T = H = W = 1: at most one tap is in range
+    np.testing.assert_array_equal(to_np(rubiks_shift_3d_forward(to_dev(x1), sh, 1, 0)), oracle.rk3d_forward(x1, shn))
