@@ -227,9 +227,13 @@ inline bool supported(const Dims3& d, int quantize) {
 inline CDims make_cdims(const Dims3& d, int plane_elems) {
     CDims cd;
     cd.d = d;
-    cd.E = pow2_at_least(plane_elems, kWave, kBlock);
+    // <= 64 elements: one wave, 1 element per thread; <= 256: one wave, up to 4 elements per thread (4 independent
+    // chains per thread, wave-only reduction, 4x fewer threads to set up); larger: 256 threads x 4 elements per chunk
+    static const int small_e = [] { const char* e = getenv("RK_COL_SMALL_E"); return e ? atoi(e) : 256; }();
+    if (plane_elems <= kWave) { cd.E = kWave; cd.M = 1; }
+    else if (plane_elems <= kBlock) { cd.E = small_e; cd.M = (plane_elems <= small_e) ? 1 : 4; }
+    else { cd.E = kBlock; cd.M = 4; }
     cd.logE = (cd.E == 64) ? 6 : (cd.E == 128 ? 7 : 8);
-    cd.M = plane_elems <= cd.E ? 1 : 4;
     cd.nchunks = (plane_elems + cd.E * cd.M - 1) / (cd.E * cd.M);
     return cd;
 }

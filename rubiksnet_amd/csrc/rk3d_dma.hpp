@@ -37,176 +37,12 @@
 // Loads and stores are non-temporal: every plane is read once by one CU and every output written
 // once.  Measured on [32,8,64,56,56]: nt stores + nt loads 197 us fwd+bwd vs 216 us without.
 #pragma once
-#include "rk3d_stream.hpp"
+#include "rk_dma.hpp"
 
 namespace rk {
 namespace dma3d {
 
-using stream3d::lds_b128;
-
-struct BDims {
-    int N, T, C, H, W, W4;
-    int BH, nbands;          // output rows per band (H % BH == 0), bands per plane
-};
-
-__device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
-
-__device__ __forceinline__ void stream_store(float4* p, const float4& v) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
-}
-
-// One wave-instruction of LDS-DMA, saddr form: lane l copies 16 B from (sbase + voff_l) to LDS byte
-// address lds_dst + 16*l.  The s_waitcnt lgkmcnt(0) orders it behind this wave's earlier LDS reads of
-// the slot being refilled (and covers the M0 write -> use hazard).
-__device__ __forceinline__ void dma16s(const void* sbase_uniform, int voff, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "global_load_lds_dwordx4 %1, %2 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
-        : "memory");
-}
-
-#define RK_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-// wait until at most n VMEM ops of this wave are outstanding (n wave-uniform; clamped down = stricter)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n < 0 ? 0 : (n > 32 ? 32 : n)) {
-        RK_VMCNT_CASE(0) RK_VMCNT_CASE(1) RK_VMCNT_CASE(2) RK_VMCNT_CASE(3) RK_VMCNT_CASE(4)
-        RK_VMCNT_CASE(5) RK_VMCNT_CASE(6) RK_VMCNT_CASE(7) RK_VMCNT_CASE(8) RK_VMCNT_CASE(9)
-        RK_VMCNT_CASE(10) RK_VMCNT_CASE(11) RK_VMCNT_CASE(12) RK_VMCNT_CASE(13) RK_VMCNT_CASE(14)
-        RK_VMCNT_CASE(15) RK_VMCNT_CASE(16) RK_VMCNT_CASE(17) RK_VMCNT_CASE(18) RK_VMCNT_CASE(19)
-        RK_VMCNT_CASE(20) RK_VMCNT_CASE(21) RK_VMCNT_CASE(22) RK_VMCNT_CASE(23) RK_VMCNT_CASE(24)
-        RK_VMCNT_CASE(25) RK_VMCNT_CASE(26) RK_VMCNT_CASE(27) RK_VMCNT_CASE(28) RK_VMCNT_CASE(29)
-        RK_VMCNT_CASE(30) RK_VMCNT_CASE(31) RK_VMCNT_CASE(32)
-    }
-}
-#undef RK_VMCNT_CASE
-
-// compile-time tap selection: the 5 consecutive values starting OFF floats into the aligned pair (q0, q1)
-template <int OFF> __device__ __forceinline__ float tap(const float4& q0, const float4& q1, int k) {
-    const int j = OFF + k;   // 0..7, constant after unrolling
-    return j == 0 ? q0.x : j == 1 ? q0.y : j == 2 ? q0.z : j == 3 ? q0.w : j == 4 ? q1.x : j == 5 ? q1.y
-         : j == 6 ? q1.z : q1.w;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-workgroup band geometry (wave-uniform) and per-thread cell geometry.
-struct Band {
-    int cells_out;               // output float4 cells of this band (BH * W4)
-    int out0;                    // float4 index of the band's first output cell inside a plane
-    int cells_in;                // tap-slot cells: (BH + 1) * W4
-    int src0;                    // float4 index (may be negative) of the slot's cell 0 inside a source plane
-    int s_lo, s_hi;              // slot cells [s_lo, s_hi) hold real source rows; the rest stay zero
-};
-
-__device__ __forceinline__ Band make_band(const BDims& d, int band, int flH) {
-    Band b;
-    b.cells_out = d.BH * d.W4;
-    b.out0 = band * d.BH * d.W4;
-    b.cells_in = (d.BH + 1) * d.W4;
-    const int r0 = band * d.BH + flH;                     // source row held by slot row 0
-    b.src0 = r0 * d.W4;
-    int j_lo = r0 < 0 ? -r0 : 0;                          // first slot row inside the plane
-    j_lo = j_lo > d.BH + 1 ? d.BH + 1 : j_lo;
-    int j_hi = d.H - r0;                                  // first slot row past the plane
-    j_hi = j_hi < 0 ? 0 : (j_hi > d.BH + 1 ? d.BH + 1 : j_hi);
-    b.s_lo = j_lo * d.W4;
-    b.s_hi = j_hi > j_lo ? j_hi * d.W4 : b.s_lo;
-    return b;
-}
-
-template <int ROUNDS> struct BCells {
-    int off0;                                            // tid * 16: byte offset of cell `tid`; round i adds 4096 i
-    int a0[ROUNDS], a1[ROUNDS], b0[ROUNDS], b1[ROUNDS];  // tap float4 indices into a tap slot (zero cell if outside)
-    bool in_act[ROUNDS];                                 // this lane DMAs tap-slot cell tid + 256 i
-    bool tail_live;                                      // this lane owns an output cell in the last round
-    bool tail_on;                                        // ... and this WAVE has at least one such lane (uniform)
-    int xown;                                            // last round: own float4 index in an x slot, or its zero cell
-    int n_tap_wave;                                      // tap-plane DMA instructions per plane for this wave (uniform)
-    int n_out_wave;                                      // output stores / x DMA instructions per plane for this wave
-};
-
-template <int ROUNDS>
-__device__ __forceinline__ void make_bcells(BCells<ROUNDS>& cs, const BDims& d, const Band& b, int group_shift) {
-    cs.off0 = (int)threadIdx.x * 16;
-    int n_tap = 0;
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        const int o = (int)threadIdx.x + kBlock * i;
-        const bool live = o < b.cells_out;
-        const int oc = live ? o : 0;
-        const int j = oc / d.W4, w4 = oc - j * d.W4;     // band-local output row, column group
-        const int ga = w4 + group_shift, gb = ga + 1;
-        const bool ga_ok = ga >= 0 && ga < d.W4, gb_ok = gb >= 0 && gb < d.W4;
-        const int zero = b.cells_in;                     // dead lanes read zeros everywhere
-        cs.a0[i] = (live && ga_ok) ? j * d.W4 + ga : zero;
-        cs.a1[i] = (live && gb_ok) ? j * d.W4 + gb : zero;
-        cs.b0[i] = (live && ga_ok) ? (j + 1) * d.W4 + ga : zero;
-        cs.b1[i] = (live && gb_ok) ? (j + 1) * d.W4 + gb : zero;
-        cs.in_act[i] = o >= b.s_lo && o < b.s_hi;
-        n_tap += (__ballot(cs.in_act[i]) != 0ull) ? 1 : 0;
-        if (i == ROUNDS - 1) { cs.tail_live = live; cs.xown = live ? o : b.cells_out; }
-    }
-    cs.tail_on = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~(kWave - 1))) + kBlock * (ROUNDS - 1) < b.cells_out;
-    cs.n_tap_wave = __builtin_amdgcn_readfirstlane(n_tap);
-    cs.n_out_wave = cs.tail_on ? ROUNDS : ROUNDS - 1;
-}
-
-// DMA the band of a tap plane (uniform pointer to slot cell 0's source, may lie before the plane) into a slot
-template <int ROUNDS>
-__device__ __forceinline__ void dma_taps(const float* src0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
-    const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i)
-        if (cs.in_act[i]) dma16s(src0, cs.off0 + 4096 * i, dst + 4096u * i);
-}
-// zero the same cells instead (the plane lies outside [0, T))
-template <int ROUNDS>
-__device__ __forceinline__ void zero_taps(float4* slot, const BCells<ROUNDS>& cs) {
-    char* base = reinterpret_cast<char*>(slot) + cs.off0;
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i)
-        if (cs.in_act[i]) *reinterpret_cast<float4*>(base + 4096 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-// DMA the thread's own output-aligned cells of a plane (uniform pointer to the band's first cell)
-template <int ROUNDS>
-__device__ __forceinline__ void dma_own(const float* band0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
-    const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
-#pragma unroll
-    for (int i = 0; i + 1 < ROUNDS; ++i) dma16s(band0, cs.off0 + 4096 * i, dst + 4096u * i);
-    if (cs.tail_on && cs.tail_live) dma16s(band0, cs.off0 + 4096 * (ROUNDS - 1), dst + 4096u * (ROUNDS - 1));
-}
-template <int ROUNDS>
-__device__ __forceinline__ void zero_own(float4* slot, const BCells<ROUNDS>& cs) {
-    char* base = reinterpret_cast<char*>(slot) + cs.off0;
-#pragma unroll
-    for (int i = 0; i + 1 < ROUNDS; ++i) *reinterpret_cast<float4*>(base + 4096 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cs.tail_live) *reinterpret_cast<float4*>(base + 4096 * (ROUNDS - 1)) = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// once per kernel: zero cell of every slot + the slot rows that lie outside the plane
-template <int ROUNDS>
-__device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slot_f4, const Band& b,
-                                               const BCells<ROUNDS>& cs) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nslots; ++s) {
-        float4* slot = ring + s * slot_f4;
-        if (threadIdx.x == 0) slot[b.cells_in] = z;
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            const int o = (int)threadIdx.x + kBlock * i;
-            if (o < b.cells_in && !cs.in_act[i]) slot[o] = z;
-        }
-    }
-}
+using namespace dma;
 
 // ---------------------------------------------------------------------------------------------
 // Forward (NEGATE = false: src = x, dst = y) and d(x) alone (NEGATE = true: src = gy, dst = gx).
@@ -516,39 +352,13 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host side: band choice and launchers.
-inline bool env_force_generic() {
-    static const bool v = [] { const char* e = getenv("RK_FORCE_GENERIC"); return e && e[0] == '1'; }();
-    return v;
-}
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-inline int rounds_for(int cells) { return (cells + kBlock - 1) / kBlock; }
-
-// Equal bands with (BH + 1) * W4 <= 1024 cells and the same number of rounds on the tap side and on the
-// output side (so rounds 0..ROUNDS-2 are full).  false = shape not handled by the DMA kernels.
+// Host side: launchers.
+// false = shape not handled by the DMA kernels
 inline bool make_bdims(BDims& b, const Dims3& d) {
     const bool s1p0 = d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0;
     if (!s1p0 || d.W % 4 != 0 || d.W < 4 || env_force_generic()) return false;
     b.N = d.N; b.T = d.T; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
-    for (int nb = 1; nb <= d.H; ++nb) {
-        if (d.H % nb) continue;
-        const int bh = d.H / nb, co = bh * b.W4, ci = (bh + 1) * b.W4;
-        if (ci > 4 * kBlock) continue;
-        if (rounds_for(co) != rounds_for(ci)) continue;
-        b.nbands = nb; b.BH = bh;
-        return true;
-    }
-    return false;
-}
-inline int rounds_of(const BDims& b) { return rounds_for((b.BH + 1) * b.W4); }
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-inline size_t interp_ring_bytes(const BDims& b, int D) { return (size_t)(D + 1) * ((b.BH + 1) * b.W4 + 1) * 16; }
-inline size_t bwd_ring_bytes(const BDims& b, int DG, int DX) {
-    return ((size_t)(DG + 1) * ((b.BH + 1) * b.W4 + 1) + (size_t)DX * (b.BH * b.W4 + 1)) * 16;
+    return choose_bands(b);
 }
 
 template <bool NEGATE, int D>

@@ -38,6 +38,8 @@ def special_shifts(rng, D, C, dtype, kind):
         s = rng.choice([-1.5, -0.5, 0.5, 1.5, 0.25], size=(D, C))
     elif kind == "oob":          # everything lands outside
         s = rng.choice([-40.0, 37.5, 100.25], size=(D, C))
+    elif kind == "tiny":         # around the 2-D operator's 1e-7 "is an integer" tolerance
+        s = rng.choice([1e-8, -1e-8, 3e-8, -3e-8, 8e-8, -8e-8, 1e-7, 1.2e-7, -1.2e-7, 1.0 + 1.2e-7, 0.3], size=(D, C))
     else:
         raise ValueError(kind)
     return s.astype(dtype)

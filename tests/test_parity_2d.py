@@ -14,6 +14,11 @@ SHAPES = [
     (1, 4, 10, 7, (1, 3), (2, 0)),
     (16, 9, 7, 7, 1, 0),
     (2, 3, 56, 56, 1, 0),
+    # streaming kernels (stride 1, pad 0, W % 4 == 0): frame groups with a ragged last group, row bands
+    (20, 6, 28, 28, 1, 0),
+    (9, 4, 12, 16, 1, 0),
+    (5, 3, 112, 112, 1, 0),
+    (70, 512, 4, 8, 1, 0),
 ]
 
 
@@ -30,7 +35,7 @@ def _bwd(gy, x, shift, s, p, q, normalize=True, enable=True):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("quantize", [False, True])
-@pytest.mark.parametrize("kind", ["generic", "wide", "integer", "half", "oob"])
+@pytest.mark.parametrize("kind", ["generic", "wide", "integer", "half", "oob", "tiny"])
 @pytest.mark.parametrize("cfg", SHAPES)
 def test_forward_and_input_grad_bit_exact(oracle, cfg, kind, quantize, dtype):
     N, C, H, W, s, p = cfg
@@ -46,7 +51,7 @@ def test_forward_and_input_grad_bit_exact(oracle, cfg, kind, quantize, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("kind", ["generic", "wide", "integer"])
+@pytest.mark.parametrize("kind", ["generic", "wide", "integer", "tiny"])
 @pytest.mark.parametrize("cfg", SHAPES)
 def test_shift_grad_matches_fp64_oracle(oracle, cfg, kind, dtype):
     N, C, H, W, s, p = cfg
@@ -74,13 +79,14 @@ def test_quantize_leaves_user_buffer_untouched_out_of_range(oracle):
     assert (y[0, 0, 2:] == -7.0).all()
 
 
-def test_enable_shift_grad_false_and_module(oracle):
+@pytest.mark.parametrize("shape", [(2, 18, 9, 9), (6, 18, 12, 12)])   # generic kernels / streaming kernels
+def test_enable_shift_grad_false_and_module(oracle, shape):
     from rubiksnet_amd.shiftlib import RubiksShift2D
 
     rng = np.random.default_rng(3)
-    x = rand(rng, (2, 18, 9, 9), np.float32)
+    x = rand(rng, shape, np.float32)
     gy = rand(rng, x.shape, np.float32)
-    shift = special_shifts(rng, 2, 18, np.float32, "generic")
+    shift = special_shifts(rng, 2, 18, np.float32, "integer")
     gx, gs = _bwd(gy, x, shift, 1, 0, False, enable=False)
     assert (gs == 0).all()
     gx_ref, _ = oracle.rk2d_backward(gy, x, shift, 1, 0, enable_shift_grad=False)
