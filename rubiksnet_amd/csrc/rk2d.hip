@@ -11,6 +11,7 @@
 #include <type_traits>
 #include "rk2d_generic.hpp"
 #include "rk2d_dma.hpp"
+#include "rk2d_stage.hpp"
 
 using namespace rk;
 using namespace rk::g2d;
@@ -55,6 +56,8 @@ int forward2(const void* x_, const void* shift_, void* y_, int N, int C, int H, 
     hipStream_t stream = (hipStream_t)stream_;
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && dma2d::launch_interp2<false>(x, shift, y, d, stream)) return launch_status();
+    } else if constexpr (!std::is_same<T, double>::value) {
+        if (!quantize && stage2d::launch_interp2<T, false>(x, shift, y, d, stream)) return launch_status();
     }
     set_group2(d, d.Ho * d.Wo);
     if (quantize)
@@ -84,6 +87,16 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
             if (!enable_shift_grad) {
                 if (dma2d::launch_interp2<true>(gy, shift, gx, d, stream)) return launch_status();
             } else if (const int P = dma2d::launch_backward2(gy, x, shift, gx, (float*)ws, d, stream)) {
+                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gshift, C, P,
+                                   normalize_grad);
+                return launch_status();
+            }
+        }
+    } else if constexpr (!std::is_same<T, double>::value) {
+        if (!quantize) {
+            if (!enable_shift_grad) {
+                if (stage2d::launch_interp2<T, true>(gy, shift, gx, d, stream)) return launch_status();
+            } else if (const int P = stage2d::launch_backward2<T>(gy, x, shift, gx, (float*)ws, d, stream)) {
                 hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gshift, C, P,
                                    normalize_grad);
                 return launch_status();

@@ -1,0 +1,319 @@
+// rk2d_stage.hpp -- RubiksShift2D streaming kernels for the 16-bit storage types (f16, bf16), stride 1 /
+// pad 0, W % 4 == 0.  Same decomposition and the same fp32 arithmetic as rk2d_dma.hpp (workgroup = channel
+// x row band x group of frames; cells of 4 elements; fp32 tap slots in LDS with a shared zero cell;
+// compile-time tap offset), but the planes cannot be DMA'd: they have to be widened to fp32 on the way
+// into LDS.  So the feed is register-staged -- each thread loads the 8-byte cells it is responsible for
+// one plane ahead (two for gy), and deposits them, converted, into the other tap slot right after the
+// step's single barrier -- and outputs are rounded once to the storage type and stored as 8-byte cells.
+// x (needed at the thread's own cells only) never touches LDS.
+//
+// Results are bit-identical to the per-element kernels of rk2d_generic.hpp for these types: identical
+// fp32 expression trees (contraction off), one rounding on store.
+#pragma once
+#include "rk2d_generic.hpp"
+#include "rk2d_dma.hpp"
+
+namespace rk {
+namespace stage2d {
+
+using namespace dma;
+using dma2d::FDims;
+using g2d::Dims2;
+
+// 4 consecutive 16-bit elements <-> float4
+template <typename T> struct Cell4;
+template <> struct Cell4<__hip_bfloat16> {
+    __device__ static __forceinline__ float4 widen(const uint2& r) {
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                           __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    }
+    __device__ static __forceinline__ unsigned bits(float v) {
+        return (unsigned)__builtin_bit_cast(unsigned short, __float2bfloat16(v));
+    }
+    __device__ static __forceinline__ uint2 narrow(float a, float b, float c, float d) {
+        return make_uint2(bits(a) | (bits(b) << 16), bits(c) | (bits(d) << 16));
+    }
+};
+template <> struct Cell4<__half> {
+    __device__ static __forceinline__ float4 widen(const uint2& r) {
+        const float2 lo = __half22float2(__builtin_bit_cast(__half2, r.x));
+        const float2 hi = __half22float2(__builtin_bit_cast(__half2, r.y));
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    __device__ static __forceinline__ unsigned bits(float v) {
+        return (unsigned)__builtin_bit_cast(unsigned short, __float2half(v));
+    }
+    __device__ static __forceinline__ uint2 narrow(float a, float b, float c, float d) {
+        return make_uint2(bits(a) | (bits(b) << 16), bits(c) | (bits(d) << 16));
+    }
+};
+
+__device__ __forceinline__ uint2 load_cell(const void* p) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void store_cell(void* p, const uint2& v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x2*>(p));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward (src = x) and d(x) alone (src = gy, negated shift).  sp / dp: frame 0 of the group, this channel.
+template <typename T, int ROUNDS, int OFF>
+__device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __restrict__ dp, float4* ring,
+                                             const BDims& d, const Band& b, const Frac<float>& fH,
+                                             const Frac<float>& fW, size_t fstride, int nf) {
+    const int slot_f4 = b.cells_in + 1;
+    BCells<ROUNDS> cs;
+    make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
+    init_tap_slots<ROUNDS>(ring, 2, slot_f4, b, cs);
+
+    const float rH = fH.r, rW = fW.r;
+    const float uH = 1 - rH, uW = 1 - rW;
+    // byte offset of this thread's cell `tid` (8 bytes per cell); round i adds 2048 i
+    const char* src0 = reinterpret_cast<const char*>(sp + (ptrdiff_t)b.src0 * 4) + threadIdx.x * 8;
+    char* out0 = reinterpret_cast<char*>(dp + (size_t)b.out0 * 4) + threadIdx.x * 8;
+    const size_t fbytes = fstride * sizeof(T);
+
+    uint2 stash[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) stash[i] = make_uint2(0u, 0u);
+    auto fetch = [&](int k) {
+        const char* p = src0 + (size_t)k * fbytes;
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i)
+            if (cs.in_act[i]) stash[i] = load_cell(p + 2048 * i);
+    };
+    auto deposit = [&](float4* slot) {
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i)
+            if (cs.in_act[i]) slot[threadIdx.x + kBlock * i] = Cell4<T>::widen(stash[i]);
+    };
+    auto round = [&](int i, const float4* cur, char* out, bool store) {
+        const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
+        const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
+        float q[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)                               // interp2d, rubiks2d_kernels.cu:60-66
+            q[m] = tap<OFF>(qa0, qa1, m) * uH * uW + tap<OFF>(qa0, qa1, m + 1) * uH * rW +
+                   tap<OFF>(qb0, qb1, m) * rH * uW + tap<OFF>(qb0, qb1, m + 1) * rH * rW;
+        if (store) store_cell(out + 2048 * i, Cell4<T>::narrow(q[0], q[1], q[2], q[3]));
+    };
+
+    fetch(0);
+    deposit(ring);
+    if (nf > 1) fetch(1);
+#pragma nounroll
+    for (int k = 0; k < nf; ++k) {
+        __syncthreads();                                           // frame k deposited; frame k-1 retired
+        float4* cur = ring + (k & 1) * slot_f4;
+        if (k + 1 < nf) deposit(ring + ((k + 1) & 1) * slot_f4);
+        if (k + 2 < nf) fetch(k + 2);
+        char* out = out0 + (size_t)k * fbytes;
+#pragma unroll
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, out, true);
+        if (cs.tail_on) round(ROUNDS - 1, cur, out, cs.tail_live);
+    }
+}
+
+template <typename T, bool NEGATE, int ROUNDS>
+__global__ __launch_bounds__(kBlock) void k2d_stage_interp(const T* __restrict__ src, const T* __restrict__ shift,
+                                                           T* __restrict__ dst, FDims fd) {
+    extern __shared__ __attribute__((aligned(16))) float4 ring[];
+    const BDims& d = fd.b;
+    const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
+    const int c = col % d.C, g = col / d.C;
+    float sH = ld(shift + c), sW = ld(shift + d.C + c);
+    if (NEGATE) { sH = -sH; sW = -sW; }
+    const Frac<float> fH = split_shift(sH), fW = split_shift(sW);
+    const int HW = d.H * d.W;
+    const size_t fstride = (size_t)d.C * HW;
+    const int f0 = g * fd.FG;
+    const int nf = min(fd.FG, fd.frames - f0);
+    const T* sp = src + ((size_t)f0 * d.C + c) * HW;
+    T* dp = dst + ((size_t)f0 * d.C + c) * HW;
+    const Band b = make_band(d, band, fH.fl);
+
+    if (NEGATE && sH == 0 && sW == 0) {                            // rubiks2d_kernels.cu:322-329: plain copy
+        for (int k = 0; k < nf; ++k)
+            for (int cell = threadIdx.x; cell < b.cells_out; cell += kBlock)
+                reinterpret_cast<uint2*>(dp + (size_t)k * fstride)[b.out0 + cell] =
+                    reinterpret_cast<const uint2*>(sp + (size_t)k * fstride)[b.out0 + cell];
+        return;
+    }
+    switch (((fW.fl % 4) + 4) % 4) {                               // wave-uniform
+        case 0: interp2_loop<T, ROUNDS, 0>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
+        case 1: interp2_loop<T, ROUNDS, 1>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
+        case 2: interp2_loop<T, ROUNDS, 2>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
+        default: interp2_loop<T, ROUNDS, 3>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward: d(x) + d(shift) partials in one pass (adjoint form, see rk2d_dma.hpp).
+template <typename T, int ROUNDS, int OFF>
+__device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T* __restrict__ gp,
+                                               T* __restrict__ op, float4* ring, const BDims& d, const Band& b,
+                                               const Frac<float>& fH, const Frac<float>& fW, size_t fstride, int nf,
+                                               float& accH, float& accW) {
+    const int slot_f4 = b.cells_in + 1;
+    BCells<ROUNDS> cs;
+    make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
+    init_tap_slots<ROUNDS>(ring, 2, slot_f4, b, cs);
+
+    const float rH = fH.r, rW = fW.r;
+    const float uH = 1 - rH, uW = 1 - rW;
+    const char* gsrc0 = reinterpret_cast<const char*>(gp + (ptrdiff_t)b.src0 * 4) + threadIdx.x * 8;
+    // own cells; the last round's dead lanes re-read their round-0 cell and discard it
+    const char* xsrc0 = reinterpret_cast<const char*>(xp + (size_t)b.out0 * 4) + threadIdx.x * 8;
+    const int xtail = cs.tail_live ? 2048 * (ROUNDS - 1) : 0;
+    char* out0 = reinterpret_cast<char*>(op + (size_t)b.out0 * 4) + threadIdx.x * 8;
+    const size_t fbytes = fstride * sizeof(T);
+
+    uint2 gstash[ROUNDS], xstash[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) gstash[i] = xstash[i] = make_uint2(0u, 0u);
+    auto fetch_g = [&](int k) {
+        const char* p = gsrc0 + (size_t)k * fbytes;
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i)
+            if (cs.in_act[i]) gstash[i] = load_cell(p + 2048 * i);
+    };
+    auto fetch_x = [&](int k) {
+        const char* p = xsrc0 + (size_t)k * fbytes;
+#pragma unroll
+        for (int i = 0; i + 1 < ROUNDS; ++i) xstash[i] = load_cell(p + 2048 * i);
+        if (cs.tail_on) xstash[ROUNDS - 1] = load_cell(p + xtail);
+    };
+    auto deposit = [&](float4* slot) {
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i)
+            if (cs.in_act[i]) slot[threadIdx.x + kBlock * i] = Cell4<T>::widen(gstash[i]);
+    };
+
+    float sH = 0.f, sW = 0.f;
+    auto round = [&](int i, const float4* cur, const float4& xv4, char* out, bool live) {
+        const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
+        const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float col[5], q[4];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) col[m] = fmaf(uH, tap<OFF>(qa0, qa1, m), rH * tap<OFF>(qb0, qb1, m));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float a0 = tap<OFF>(qa0, qa1, m), a1 = tap<OFF>(qa0, qa1, m + 1);
+            const float b0 = tap<OFF>(qb0, qb1, m), b1 = tap<OFF>(qb0, qb1, m + 1);
+            q[m] = a0 * uH * uW + a1 * uH * rW + b0 * rH * uW + b1 * rH * rW;     // K8: interp2d, contraction off
+            const float la = fmaf(a0, uW, a1 * rW), lb = fmaf(b0, uW, b1 * rW);
+            sH = fmaf(la - lb, xv[m], sH);
+            sW = fmaf(col[m] - col[m + 1], xv[m], sW);
+        }
+        if (live) store_cell(out + 2048 * i, Cell4<T>::narrow(q[0], q[1], q[2], q[3]));
+    };
+
+    fetch_g(0);
+    fetch_x(0);
+    deposit(ring);
+    if (nf > 1) fetch_g(1);
+#pragma nounroll
+    for (int k = 0; k < nf; ++k) {
+        __syncthreads();                                           // gy[k] deposited; step k-1 retired
+        float4* cur = ring + (k & 1) * slot_f4;
+        float4 xv[ROUNDS];
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) xv[i] = Cell4<T>::widen(xstash[i]);
+        if (!cs.tail_live) xv[ROUNDS - 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 1 < nf) { deposit(ring + ((k + 1) & 1) * slot_f4); fetch_x(k + 1); }
+        if (k + 2 < nf) fetch_g(k + 2);
+        char* out = out0 + (size_t)k * fbytes;
+#pragma unroll
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, true);
+        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, cs.tail_live);
+    }
+    accH = sH; accW = sW;
+}
+
+template <typename T, int ROUNDS>
+__global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict__ gy, const T* __restrict__ x,
+                                                             const T* __restrict__ shift, T* __restrict__ gx,
+                                                             float* __restrict__ part, FDims fd, Dims2 gd) {
+    extern __shared__ __attribute__((aligned(16))) float4 ring[];
+    __shared__ float red[2][kBlock / kWave];
+    const BDims& d = fd.b;
+    const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
+    const int c = col % d.C, g = col / d.C;
+    const float s0 = ld(shift + c), s1 = ld(shift + d.C + c);
+    const int f0 = g * fd.FG;
+    const int nf = min(fd.FG, fd.frames - f0);
+    float accH = 0.f, accW = 0.f;
+
+    if (split_shift(s0).r < 1e-7f || split_shift(s1).r < 1e-7f) {   // rubiks2d_kernels.cu:189-200, per element
+        if (band == 0)
+            for (int k = 0; k < nf; ++k) {
+                g2d::backward_input_plane2<T, false>(gy, shift, gx, gd, f0 + k, c, threadIdx.x, kBlock);
+                g2d::shift_grad_plane2<T>(gy, x, shift, gd, f0 + k, c, threadIdx.x, kBlock, accH, accW);
+            }
+    } else {
+        const Frac<float> fH = split_shift(-s0), fW = split_shift(-s1);       // fl', r'
+        const int HW = d.H * d.W;
+        const size_t fstride = (size_t)d.C * HW;
+        const size_t base = ((size_t)f0 * d.C + c) * HW;
+        const Band b = make_band(d, band, fH.fl);
+        switch (((fW.fl % 4) + 4) % 4) {
+            case 0: backward2_loop<T, ROUNDS, 0>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
+            case 1: backward2_loop<T, ROUNDS, 1>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
+            case 2: backward2_loop<T, ROUNDS, 2>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
+            default: backward2_loop<T, ROUNDS, 3>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
+        }
+    }
+
+    accH = group_sum(accH, kBlock, red[0]);
+    accW = group_sum(accW, kBlock, red[1]);
+    if (threadIdx.x == 0) {
+        const int P = fd.ngroups * d.nbands;
+        float* o = part + (size_t)c * 2 * P + (size_t)g * d.nbands + band;
+        o[0] = accH;
+        o[P] = accW;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+inline size_t ring_bytes(const BDims& b) { return (size_t)2 * ((b.BH + 1) * b.W4 + 1) * 16; }
+
+template <typename T, bool NEGATE>
+inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d, hipStream_t stream) {
+    FDims f;
+    if (!dma2d::make_fdims(f, d) || !aligned8(src) || !aligned8(dst)) return false;
+    const size_t lds = ring_bytes(f.b);
+    const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
+    switch (rounds_of(f.b)) {
+        case 1: hipLaunchKernelGGL((k2d_stage_interp<T, NEGATE, 1>), grid, block, lds, stream, src, shift, dst, f); break;
+        case 2: hipLaunchKernelGGL((k2d_stage_interp<T, NEGATE, 2>), grid, block, lds, stream, src, shift, dst, f); break;
+        case 3: hipLaunchKernelGGL((k2d_stage_interp<T, NEGATE, 3>), grid, block, lds, stream, src, shift, dst, f); break;
+        default: hipLaunchKernelGGL((k2d_stage_interp<T, NEGATE, 4>), grid, block, lds, stream, src, shift, dst, f); break;
+    }
+    return true;
+}
+
+// d(x) + d(shift) partials into ws[C][2][P]; returns P (0 = not handled here)
+template <typename T>
+inline int launch_backward2(const T* gy, const T* x, const T* shift, T* gx, float* ws, const Dims2& d,
+                            hipStream_t stream) {
+    FDims f;
+    if (!dma2d::make_fdims(f, d) || !aligned8(gy) || !aligned8(x) || !aligned8(gx)) return 0;
+    const size_t lds = ring_bytes(f.b);
+    const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
+    switch (rounds_of(f.b)) {
+        case 1: hipLaunchKernelGGL((k2d_stage_backward<T, 1>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
+        case 2: hipLaunchKernelGGL((k2d_stage_backward<T, 2>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
+        case 3: hipLaunchKernelGGL((k2d_stage_backward<T, 3>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
+        default: hipLaunchKernelGGL((k2d_stage_backward<T, 4>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
+    }
+    return f.ngroups * f.b.nbands;
+}
+
+}  // namespace stage2d
+}  // namespace rk

@@ -100,6 +100,36 @@ def test_enable_shift_grad_false_and_module(oracle, shape):
 
 
 @pytest.mark.parametrize("tdtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["generic", "wide", "integer", "tiny"])
+@pytest.mark.parametrize("shape", [(4, 12, 14, 14), (20, 6, 28, 28), (3, 5, 56, 56), (5, 3, 112, 112), (9, 4, 12, 16)])
+def test_half_types_are_the_fp32_oracle_rounded_once(oracle, shape, kind, tdtype):
+    """f16 / bf16 storage: the arithmetic is the fp32 operator's, rounded once on store.  So y and d(x)
+    must equal the fp32 oracle on the widened inputs, rounded to the storage type -- bit for bit -- on the
+    per-element kernels (W % 4 != 0) and on the streaming ones alike."""
+    from rubiksnet_amd.shiftlib.rubiks2d.primitive import rubiks2d_backward, rubiks2d_forward
+
+    rng = np.random.default_rng(seed_of(shape, kind, str(tdtype)))
+    C = shape[1]
+    x = torch.from_numpy(rand(rng, shape, np.float32)).to(tdtype)
+    shift = torch.from_numpy(special_shifts(rng, 2, C, np.float32, kind)).to(tdtype)
+    gy = torch.from_numpy(rand(rng, shape, np.float32)).to(tdtype)
+    xf, sf, gf = x.float().numpy(), shift.float().numpy(), gy.float().numpy()
+    y = rubiks2d_forward(x.cuda(), shift.cuda(), 1, 0)
+    assert y.dtype == tdtype
+    assert torch.equal(y.cpu(), torch.from_numpy(oracle.rk2d_forward(xf, sf, 1, 0)).to(tdtype))
+    gx, gs = rubiks2d_backward(gy.cuda(), x.cuda(), shift.cuda(), 1, 0, normalize_grad=False)
+    gx_ref, _ = oracle.rk2d_backward(gf, xf, sf, 1, 0)
+    assert torch.equal(gx.cpu(), torch.from_numpy(gx_ref).to(tdtype))
+    _, gs_ref = oracle.rk2d_backward(gf.astype(np.float64), xf.astype(np.float64), sf.astype(np.float64), 1, 0,
+                                     normalize_grad=False)
+    eps = 2e-3 if tdtype == torch.float16 else 1.6e-2
+    scale = max(1.0, float(np.abs(gs_ref).max()))
+    np.testing.assert_allclose(gs.float().cpu().numpy(), gs_ref, rtol=0, atol=eps * scale)
+    gx2, gs2 = rubiks2d_backward(gy.cuda(), x.cuda(), shift.cuda(), 1, 0, enable_shift_grad=False)
+    assert torch.equal(gx2, gx) and (gs2 == 0).all()
+
+
+@pytest.mark.parametrize("tdtype", [torch.float16, torch.bfloat16])
 def test_half_types_close_to_fp32_oracle(oracle, tdtype):
     """f16 (reference dispatches it, rubiks2d_kernels.cu:422) and bf16: computed in fp32, rounded on
     store -> compare with the fp32 oracle on the rounded inputs at the storage type's precision."""
