@@ -37,7 +37,8 @@ void set_group2(Dims2& d, int plane_elems) {
 
 // bytes of d(shift) partials: [C][2][P], P = N for the generic kernels
 size_t workspace2(const Dims2& d, size_t elem) {
-    const int P = dma2d::backward2_partials(d);
+    // the smaller group size gives the larger partial count: an upper bound for every storage type
+    const int P = dma2d::backward2_partials(d, dma2d::kFramesF32 < dma2d::kFrames16 ? dma2d::kFramesF32 : dma2d::kFrames16);
     return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * elem;
 }
 

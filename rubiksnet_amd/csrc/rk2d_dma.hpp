@@ -16,8 +16,13 @@
 //     dL/dsW = sum_x x * (col'[k] - col'[k+1]),   col'[k] = (1-r'H) gy(rowA, k) + r'H gy(rowB, k),
 // so only gy needs taps and x is read at the thread's own cells: one pass, 12 B per element.
 // Channels whose shift is within 1e-7 of an integer in H or W take the reference's central-difference
-// branch (:189-253): those (rare) channels run the per-element code of rk2d_generic.hpp inside the
-// same kernel.
+// branch (:189-253).  A central difference is the mean of the one-sided differences on either side, and
+// in the adjoint form a one-sided difference at an integer shift is the SAME streaming sum evaluated with
+// remainder 0 and floor fl' (one side) or fl' - 1 (the other).  So such a channel simply walks its
+// frames two or three times with different floors (d(x) is stored on the first walk) -- about 2-3x the
+// cost of an ordinary channel, instead of a per-element fallback that would serialise ~200 dependent
+// loads per thread per plane in one workgroup (measured: ONE integer channel took [256,64,56,56] bf16
+// from 81 us to 843 us).  ShiftNet-style "group" initialisation makes every channel integer.
 #pragma once
 #include "rk2d_generic.hpp"
 #include "rk_dma.hpp"
@@ -133,13 +138,40 @@ __global__ __launch_bounds__(kBlock) void k2d_dma_interp(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Which walks over the frames a channel needs (wave-uniform).  (sH, sW): negated shift as d(shift) sees it --
+// a component within 1e-7 above an integer i counts as exactly i (rubiks2d_kernels.cu:189-200), i.e.
+// (fl', r') = (-i, 0).  Walk 0 uses (sH, sW); walk 1 (H integer) lowers the H floor by one, walk 2 (W integer)
+// the W floor: the mean of walk 0 and walk 1 / 2 is the reference's central difference.  (gH, gW): the negated
+// shift as d(x) sees it (K8 has no tolerance); when it differs from (sH, sW) d(x) gets a walk of its own.
+struct IntegerPlan {
+    Frac<float> sH, sW, gH, gW;
+    bool hint, wint, separate_gx;
+    __device__ __forceinline__ bool walk_on(int walk) const { return walk == 0 || (walk == 1 ? hint : wint); }
+};
+__device__ __forceinline__ IntegerPlan plan_walks(float s0, float s1) {
+    IntegerPlan p;
+    const Frac<float> u0 = split_shift(s0), u1 = split_shift(s1);
+    p.hint = u0.r < 1e-7f;
+    p.wint = u1.r < 1e-7f;
+    p.gH = split_shift(-s0);
+    p.gW = split_shift(-s1);
+    p.sH = p.gH;
+    p.sW = p.gW;
+    if (p.hint) { p.sH.fl = -u0.fl; p.sH.r = 0.f; }
+    if (p.wint) { p.sW.fl = -u1.fl; p.sW.r = 0.f; }
+    p.separate_gx = p.sH.fl != p.gH.fl || p.sH.r != p.gH.r || p.sW.fl != p.gW.fl || p.sW.r != p.gW.r;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward: d(x) + d(shift) partials in one pass.  part[c][2][P], P = ngroups * nbands.
-template <int ROUNDS, int DG, int DX, int OFF>
+template <int ROUNDS, int DG, int DX, int OFF, bool WRITE_GX>
 __device__ __forceinline__ void backward2_loop(const float* __restrict__ xp, const float* __restrict__ gp,
                                                float* __restrict__ op, float4* ring, const BDims& d, const Band& b,
                                                const Frac<float>& fH, const Frac<float>& fW, size_t fstride, int nf,
                                                float& accH, float& accW) {
     static_assert(DG >= DX && DX >= 1, "gy runs at least as far ahead as x");
+    __syncthreads();                                              // a previous walk may still be reading the ring
     constexpr int RG = DG + 1, RX = DX;
     const int gslot_f4 = b.cells_in + 1, xslot_f4 = b.cells_out + 1;
     BCells<ROUNDS> cs;
@@ -199,6 +231,7 @@ __device__ __forceinline__ void backward2_loop(const float* __restrict__ xp, con
             stream_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off0 + 4096 * i),
                          make_float4(q[0], q[1], q[2], q[3]));
     };
+    const int n_store_wave = WRITE_GX ? cs.n_out_wave : 0;
 
     int gslot = 0, xslot = 0;
 #pragma nounroll
@@ -221,9 +254,9 @@ __device__ __forceinline__ void backward2_loop(const float* __restrict__ xp, con
         const float4* cur = gring + gslot * gslot_f4;
         float4* out = reinterpret_cast<float4*>(out0 + (size_t)k * fstride);
 #pragma unroll
-        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, true);
-        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, cs.tail_live);
-        issued += cs.n_out_wave;
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, WRITE_GX);
+        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, WRITE_GX && cs.tail_live);
+        issued += n_store_wave;
         if (++gslot == RG) gslot = 0;
         if (++xslot == RX) xslot = 0;
     }
@@ -238,35 +271,62 @@ __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restri
                                                            FDims fd, Dims2 gd) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[2][kBlock / kWave];
+    (void)gd;
     const BDims& d = fd.b;
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
     const int c = col % d.C, g = col / d.C;
     const float s0 = shift[c], s1 = shift[d.C + c];
     const int f0 = g * fd.FG;
     const int nf = min(fd.FG, fd.frames - f0);
-    float accH = 0.f, accW = 0.f;
 
-    if (split_shift(s0).r < 1e-7f || split_shift(s1).r < 1e-7f) {
-        // within 1e-7 of an integer (rubiks2d_kernels.cu:189-200): central differences, per element.
-        // Band 0 does the group's whole planes; the other bands contribute zero partials.
-        if (band == 0)
-            for (int k = 0; k < nf; ++k) {
-                g2d::backward_input_plane2<float, false>(gy, shift, gx, gd, f0 + k, c, threadIdx.x, kBlock);
-                g2d::shift_grad_plane2<float>(gy, x, shift, gd, f0 + k, c, threadIdx.x, kBlock, accH, accW);
-            }
-    } else {
-        const Frac<float> fH = split_shift(-s0), fW = split_shift(-s1);       // fl', r'
-        const int HW = d.H * d.W;
-        const size_t fstride = (size_t)d.C * HW;
-        const size_t base = ((size_t)f0 * d.C + c) * HW;
-        const Band b = make_band(d, band, fH.fl);
-        switch (((fW.fl % 4) + 4) % 4) {
-            case 0: backward2_loop<ROUNDS, DG, DX, 0>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
-            case 1: backward2_loop<ROUNDS, DG, DX, 1>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
-            case 2: backward2_loop<ROUNDS, DG, DX, 2>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
-            default: backward2_loop<ROUNDS, DG, DX, 3>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
+    const int HW = d.H * d.W;
+    const size_t fstride = (size_t)d.C * HW;
+    const size_t base = ((size_t)f0 * d.C + c) * HW;
+    const IntegerPlan plan = plan_walks(s0, s1);
+    if (plan.separate_gx) {                                       // |r| < 1e-7 but not 0: K8 keeps the true remainder
+        const Band b = make_band(d, band, plan.gH.fl);
+        switch (((plan.gW.fl % 4) + 4) % 4) {
+            case 0: interp2_loop<ROUNDS, 1, 0>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
+            case 1: interp2_loop<ROUNDS, 1, 1>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
+            case 2: interp2_loop<ROUNDS, 1, 2>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
+            default: interp2_loop<ROUNDS, 1, 3>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
         }
     }
+    float sumH0 = 0.f, sumW0 = 0.f, sumH1 = 0.f, sumW2 = 0.f;
+    if (!plan.separate_gx) {                                      // walk 0 with d(x): every ordinary channel ends here
+        const Frac<float> fH = plan.sH, fW = plan.sW;
+        const Band b = make_band(d, band, fH.fl);
+        float aH = 0.f, aW = 0.f;
+        switch (((fW.fl % 4) + 4) % 4) {
+            case 0: backward2_loop<ROUNDS, DG, DX, 0, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            case 1: backward2_loop<ROUNDS, DG, DX, 1, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            case 2: backward2_loop<ROUNDS, DG, DX, 2, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            default: backward2_loop<ROUNDS, DG, DX, 3, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+        }
+        sumH0 = aH; sumW0 = aW;
+    }
+    if (plan.separate_gx || plan.hint || plan.wint) {
+#pragma nounroll
+        for (int walk = plan.separate_gx ? 0 : 1; walk < 3; ++walk) {   // sums only
+            if (!plan.walk_on(walk)) continue;
+            Frac<float> fH = plan.sH, fW = plan.sW;
+            if (walk == 1) fH.fl -= 1;
+            if (walk == 2) fW.fl -= 1;
+            const Band b = make_band(d, band, fH.fl);
+            float aH = 0.f, aW = 0.f;
+            switch (((fW.fl % 4) + 4) % 4) {
+                case 0: backward2_loop<ROUNDS, DG, DX, 0, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                case 1: backward2_loop<ROUNDS, DG, DX, 1, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                case 2: backward2_loop<ROUNDS, DG, DX, 2, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                default: backward2_loop<ROUNDS, DG, DX, 3, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            }
+            if (walk == 0) { sumH0 = aH; sumW0 = aW; }
+            else if (walk == 1) sumH1 = aH;
+            else sumW2 = aW;
+        }
+    }
+    float accH = plan.hint ? 0.5f * (sumH0 + sumH1) : sumH0;
+    float accW = plan.wint ? 0.5f * (sumW0 + sumW2) : sumW0;
 
     accH = group_sum(accH, kBlock, red[0]);
     accW = group_sum(accW, kBlock, red[1]);
@@ -281,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // Host side.
 // false = shape not handled here (stride / padding / W % 4 / RK_FORCE_GENERIC / RK_DMA2D=0)
-inline bool make_fdims(FDims& f, const Dims2& d) {
+inline bool make_fdims(FDims& f, const Dims2& d, int frames_per_group) {
     static const int on = env_int("RK_DMA2D", 1);
     const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
     if (!on || !s1p0 || d.W % 4 != 0 || d.W < 4 || env_force_generic()) return false;
@@ -289,21 +349,22 @@ inline bool make_fdims(FDims& f, const Dims2& d) {
     b.N = 1; b.T = d.N; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
     if (!choose_bands(b)) return false;
     f.frames = d.N;
-    // frames per workgroup: as many as keep >= ~4 workgroups per CU in flight, between 4 and 16
     static const int fg_env = env_int("RK_DMA2D_FG", 0);
-    int fg = 16;
-    while (fg > 4 && (long long)((d.N + fg - 1) / fg) * d.C * b.nbands < 2048) fg /= 2;
-    if (fg_env > 0) fg = fg_env;
+    const int fg = fg_env > 0 ? fg_env : frames_per_group;
     f.FG = fg < d.N ? fg : d.N;
     f.ngroups = (d.N + f.FG - 1) / f.FG;
     return true;
 }
+// Frames per workgroup, measured on [256,64,56,56] (fwd / bwd us): fp32 DMA kernels 1: 72/133, 2: 70/108,
+// 4: 73/111, 8: 76/114, 16: 73/115 -- many short-lived workgroups keep the read/write mix of the chip even;
+// the register-staged 16-bit kernels (deeper per-workgroup prologue) 2: 49/96, 4: 45/85, 8: 46/81, 16: 44/81.
+constexpr int kFramesF32 = 2, kFrames16 = 8;
 
 template <bool NEGATE>
 inline bool launch_interp2(const float* src, const float* shift, float* dst, const Dims2& d, hipStream_t stream) {
     constexpr int D = 2;
     FDims f;
-    if (!make_fdims(f, d) || !aligned16(src) || !aligned16(dst)) return false;
+    if (!make_fdims(f, d, kFramesF32) || !aligned16(src) || !aligned16(dst)) return false;
     const size_t lds = interp_ring_bytes(f.b, D);
     if (lds > 64 * 1024) return false;
     const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
@@ -317,9 +378,9 @@ inline bool launch_interp2(const float* src, const float* shift, float* dst, con
 }
 
 // partials per channel the fused backward writes for this shape (0 = shape not handled here)
-inline int backward2_partials(const Dims2& d) {
+inline int backward2_partials(const Dims2& d, int frames_per_group) {
     FDims f;
-    return make_fdims(f, d) ? f.ngroups * f.b.nbands : 0;
+    return make_fdims(f, d, frames_per_group) ? f.ngroups * f.b.nbands : 0;
 }
 
 // d(x) + d(shift) partials into ws[C][2][P]; returns P (0 = not handled here)
@@ -327,7 +388,7 @@ inline int launch_backward2(const float* gy, const float* x, const float* shift,
                             const Dims2& d, hipStream_t stream) {
     constexpr int DG = 1, DX = 1;
     FDims f;
-    if (!make_fdims(f, d) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return 0;
+    if (!make_fdims(f, d, kFramesF32) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return 0;
     const size_t lds = bwd_ring_bytes(f.b, DG, DX);
     if (lds > 64 * 1024) return 0;
     const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);

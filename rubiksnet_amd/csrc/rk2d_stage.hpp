@@ -68,7 +68,7 @@ __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __rest
     const int slot_f4 = b.cells_in + 1;
     BCells<ROUNDS> cs;
     make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
-    init_tap_slots<ROUNDS>(ring, 2, slot_f4, b, cs);
+    init_tap_slots<ROUNDS>(ring, 2, slot_f4, b, cs);   // (first use of the ring in a kernel: no barrier needed before)
 
     const float rH = fH.r, rW = fW.r;
     const float uH = 1 - rH, uW = 1 - rW;
@@ -153,11 +153,12 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_interp(const T* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // Backward: d(x) + d(shift) partials in one pass (adjoint form, see rk2d_dma.hpp).
-template <typename T, int ROUNDS, int OFF>
+template <typename T, int ROUNDS, int OFF, bool WRITE_GX>
 __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T* __restrict__ gp,
                                                T* __restrict__ op, float4* ring, const BDims& d, const Band& b,
                                                const Frac<float>& fH, const Frac<float>& fW, size_t fstride, int nf,
                                                float& accH, float& accW) {
+    __syncthreads();                                              // a previous walk may still be reading the ring
     const int slot_f4 = b.cells_in + 1;
     BCells<ROUNDS> cs;
     make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
@@ -229,8 +230,8 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
         if (k + 2 < nf) fetch_g(k + 2);
         char* out = out0 + (size_t)k * fbytes;
 #pragma unroll
-        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, true);
-        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, cs.tail_live);
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, WRITE_GX);
+        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, WRITE_GX && cs.tail_live);
     }
     accH = sH; accW = sW;
 }
@@ -247,27 +248,56 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict
     const float s0 = ld(shift + c), s1 = ld(shift + d.C + c);
     const int f0 = g * fd.FG;
     const int nf = min(fd.FG, fd.frames - f0);
-    float accH = 0.f, accW = 0.f;
+    (void)gd;
 
-    if (split_shift(s0).r < 1e-7f || split_shift(s1).r < 1e-7f) {   // rubiks2d_kernels.cu:189-200, per element
-        if (band == 0)
-            for (int k = 0; k < nf; ++k) {
-                g2d::backward_input_plane2<T, false>(gy, shift, gx, gd, f0 + k, c, threadIdx.x, kBlock);
-                g2d::shift_grad_plane2<T>(gy, x, shift, gd, f0 + k, c, threadIdx.x, kBlock, accH, accW);
-            }
-    } else {
-        const Frac<float> fH = split_shift(-s0), fW = split_shift(-s1);       // fl', r'
-        const int HW = d.H * d.W;
-        const size_t fstride = (size_t)d.C * HW;
-        const size_t base = ((size_t)f0 * d.C + c) * HW;
-        const Band b = make_band(d, band, fH.fl);
-        switch (((fW.fl % 4) + 4) % 4) {
-            case 0: backward2_loop<T, ROUNDS, 0>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
-            case 1: backward2_loop<T, ROUNDS, 1>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
-            case 2: backward2_loop<T, ROUNDS, 2>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
-            default: backward2_loop<T, ROUNDS, 3>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, accH, accW); break;
+    const int HW = d.H * d.W;
+    const size_t fstride = (size_t)d.C * HW;
+    const size_t base = ((size_t)f0 * d.C + c) * HW;
+    const dma2d::IntegerPlan plan = dma2d::plan_walks(s0, s1);   // integer shifts: see rk2d_dma.hpp
+    if (plan.separate_gx) {
+        const Band b = make_band(d, band, plan.gH.fl);
+        switch (((plan.gW.fl % 4) + 4) % 4) {
+            case 0: interp2_loop<T, ROUNDS, 0>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
+            case 1: interp2_loop<T, ROUNDS, 1>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
+            case 2: interp2_loop<T, ROUNDS, 2>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
+            default: interp2_loop<T, ROUNDS, 3>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
         }
     }
+    float sumH0 = 0.f, sumW0 = 0.f, sumH1 = 0.f, sumW2 = 0.f;
+    if (!plan.separate_gx) {                                      // walk 0 with d(x): every ordinary channel ends here
+        const Frac<float> fH = plan.sH, fW = plan.sW;
+        const Band b = make_band(d, band, fH.fl);
+        float aH = 0.f, aW = 0.f;
+        switch (((fW.fl % 4) + 4) % 4) {
+            case 0: backward2_loop<T, ROUNDS, 0, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            case 1: backward2_loop<T, ROUNDS, 1, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            case 2: backward2_loop<T, ROUNDS, 2, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            default: backward2_loop<T, ROUNDS, 3, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+        }
+        sumH0 = aH; sumW0 = aW;
+    }
+    if (plan.separate_gx || plan.hint || plan.wint) {
+#pragma nounroll
+        for (int walk = plan.separate_gx ? 0 : 1; walk < 3; ++walk) {   // sums only
+            if (!plan.walk_on(walk)) continue;
+            Frac<float> fH = plan.sH, fW = plan.sW;
+            if (walk == 1) fH.fl -= 1;
+            if (walk == 2) fW.fl -= 1;
+            const Band b = make_band(d, band, fH.fl);
+            float aH = 0.f, aW = 0.f;
+            switch (((fW.fl % 4) + 4) % 4) {
+                case 0: backward2_loop<T, ROUNDS, 0, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                case 1: backward2_loop<T, ROUNDS, 1, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                case 2: backward2_loop<T, ROUNDS, 2, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                default: backward2_loop<T, ROUNDS, 3, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            }
+            if (walk == 0) { sumH0 = aH; sumW0 = aW; }
+            else if (walk == 1) sumH1 = aH;
+            else sumW2 = aW;
+        }
+    }
+    float accH = plan.hint ? 0.5f * (sumH0 + sumH1) : sumH0;
+    float accW = plan.wint ? 0.5f * (sumW0 + sumW2) : sumW0;
 
     accH = group_sum(accH, kBlock, red[0]);
     accW = group_sum(accW, kBlock, red[1]);
@@ -286,7 +316,7 @@ inline size_t ring_bytes(const BDims& b) { return (size_t)2 * ((b.BH + 1) * b.W4
 template <typename T, bool NEGATE>
 inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d, hipStream_t stream) {
     FDims f;
-    if (!dma2d::make_fdims(f, d) || !aligned8(src) || !aligned8(dst)) return false;
+    if (!dma2d::make_fdims(f, d, dma2d::kFrames16) || !aligned8(src) || !aligned8(dst)) return false;
     const size_t lds = ring_bytes(f.b);
     const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
     switch (rounds_of(f.b)) {
@@ -303,7 +333,7 @@ template <typename T>
 inline int launch_backward2(const T* gy, const T* x, const T* shift, T* gx, float* ws, const Dims2& d,
                             hipStream_t stream) {
     FDims f;
-    if (!dma2d::make_fdims(f, d) || !aligned8(gy) || !aligned8(x) || !aligned8(gx)) return 0;
+    if (!dma2d::make_fdims(f, d, dma2d::kFrames16) || !aligned8(gy) || !aligned8(x) || !aligned8(gx)) return 0;
     const size_t lds = ring_bytes(f.b);
     const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
     switch (rounds_of(f.b)) {

@@ -38,16 +38,6 @@ struct SDims {
     int W4, Wp, cells;                 // W/4, W+4, H*W/4
 };
 
-// A full, aligned ds_read_b128.  The empty asm makes all four components "used", so the compiler
-// cannot narrow the access to the components one switch-case of pick5 needs: narrowed b32/b64 reads
-// at a 16 B lane stride are 4-way / 2-way bank conflicts (66% of LDS cycles in the first profile),
-// b128 at a 16 B stride is conflict-free.
-__device__ __forceinline__ float4 lds_b128(const float4* p) {
-    float4 v = *p;
-    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-    return v;
-}
-
 // the 5 consecutive values starting `off` floats into the aligned pair (q0, q1); off is wave-uniform
 __device__ __forceinline__ void pick5(const float4& q0, const float4& q1, int off, float (&v)[5]) {
     switch (off) {

@@ -56,6 +56,16 @@ template <typename A> __device__ __forceinline__ A group_sum(A v, int group, A* 
 // ---- host helpers ----------------------------------------------------------------
 inline int out_len(int in, int stride, int pad) { return (in + 2 * pad - 1) / stride + 1; }
 
+// A full, aligned ds_read_b128.  The empty asm makes all four components "used", so the compiler
+// cannot narrow the access to the components one switch-case of pick5 needs: narrowed b32/b64 reads
+// at a 16 B lane stride are 4-way / 2-way bank conflicts (66% of LDS cycles in the first profile),
+// b128 at a 16 B stride is conflict-free.
+__device__ __forceinline__ float4 lds_b128(const float4* p) {
+    float4 v = *p;
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RK_OK : RK_ERR_LAUNCH; }
 
 inline int pow2_at_least(int v, int lo, int hi) {

@@ -3,13 +3,11 @@
 // with a shared zero cell, compile-time tap selection, and the host-side band choice.  See rk3d_dma.hpp
 // for the description of the scheme.
 #pragma once
-#include "rk3d_stream.hpp"
+#include "rk3d_generic.hpp"
 
 namespace rk {
 namespace dma {
 
-
-using stream3d::lds_b128;
 
 struct BDims {
     int N, T, C, H, W, W4;
@@ -190,7 +188,8 @@ inline int rounds_for(int cells) { return (cells + kBlock - 1) / kBlock; }
 // Equal bands with (BH + 1) * W4 <= 1024 cells and the same number of rounds on the tap side and on the
 // output side (so rounds 0..ROUNDS-2 are full).  Needs b.H and b.W4; false = no such banding.
 inline bool choose_bands(BDims& b) {
-    for (int nb = 1; nb <= b.H; ++nb) {
+    static const int min_bands = env_int("RK_MIN_BANDS", 1);
+    for (int nb = min_bands; nb <= b.H; ++nb) {
         if (b.H % nb) continue;
         const int bh = b.H / nb, co = bh * b.W4, ci = (bh + 1) * b.W4;
         if (ci > 4 * kBlock) continue;

@@ -8,6 +8,8 @@ from rubiksnet_amd import rubiksnet_cuda, _native
 from rubiksnet_amd.attention_shift import temporal_shift3
 
 dev = torch.device("cuda:0")
+torch.manual_seed(0)
+N_INTEGER = int(os.environ.get("PROF_INTEGER_CHANNELS", "0"))   # channels given an exactly-integer shift
 def timeit(fn, iters=30):
     ev = []
     for it in range(iters):
@@ -26,7 +28,9 @@ def run(shape, dtype, stride=1):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         gy = torch.empty((NT, C, Ho, Wo), device=dev, dtype=dtype).uniform_(-1, 1)
         sets.append((x, gy, torch.empty_like(gy), torch.empty_like(x)))
-    shift = (torch.rand(2, C, device=dev) * 2 - 1).to(dtype)
+    shift = (torch.rand(2, C, device=dev) * 1.9 - 0.95).to(dtype)
+    shift[(shift - shift.round()).abs() < 1e-3] = 0.37
+    shift[:, :N_INTEGER] = 1.0
     gs = torch.empty_like(shift)
     nin, nout = sets[0][0].numel(), sets[0][1].numel()
     tf = timeit(lambda i: rubiksnet_cuda.rubiks2d_forward(sets[i % 4][0], shift, [stride] * 2, [0, 0], False, sets[i % 4][2]))
@@ -44,6 +48,9 @@ def run(shape, dtype, stride=1):
         print("tshift3 %-19s %-8s   : fwd %7.1f us %5.0f GB/s | fwd+bwd %7.1f us %5.0f GB/s (8+12 B/elem fp32-equivalent)" % (
             shape, str(dtype).split(".")[1], tf * 1e6, 2 * es * nin / tf / 1e9, tfb * 1e6, 5 * es * nin / tfb / 1e9))
 
+if len(sys.argv) > 1:      # python tools/prof_2d.py N C H W [dtype]
+    run(tuple(int(v) for v in sys.argv[1:5]), getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32)
+    sys.exit(0)
 for shape in [(256, 64, 56, 56), (256, 288, 14, 14), (256, 54, 112, 112)]:
     for dt in (torch.float32, torch.bfloat16):
         run(shape, dt)
