@@ -10,10 +10,15 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$root/include" -I"$here"
        -Wall -Wno-unused-function -Wno-implicit-fallthrough)
 objs=()
+pids=()
 for src in rk_misc rk3d rk2d rk_tshift; do
+  rm -f "$here/$src.o"
   "$HIPCC" "${FLAGS[@]}" ${RK_EXTRA_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
+  pids+=($!)
   objs+=("$here/$src.o")
 done
-wait
+for pid in "${pids[@]}"; do
+  wait "$pid" || { echo "build.sh: a compile failed" >&2; exit 1; }   # a bare `wait` would swallow the status
+done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/librubiks_hip.so" "${objs[@]}"
 echo "built $here/librubiks_hip.so"

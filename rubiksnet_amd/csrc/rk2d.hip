@@ -88,7 +88,7 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
             if (!enable_shift_grad) {
                 if (dma2d::launch_interp2<true>(gy, shift, gx, d, stream)) return launch_status();
             } else if (const int P = dma2d::launch_backward2(gy, x, shift, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gshift, C, P,
+                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(P)), 0, stream, (const CT*)ws, gshift, C, P,
                                    normalize_grad);
                 return launch_status();
             }
@@ -98,7 +98,7 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
             if (!enable_shift_grad) {
                 if (stage2d::launch_interp2<T, true>(gy, shift, gx, d, stream)) return launch_status();
             } else if (const int P = stage2d::launch_backward2<T>(gy, x, shift, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gshift, C, P,
+                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(P)), 0, stream, (const CT*)ws, gshift, C, P,
                                    normalize_grad);
                 return launch_status();
             }
@@ -108,7 +108,7 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
         CT* part = (CT*)ws;
         set_group2(d, d.Ho * d.Wo);
         hipLaunchKernelGGL((k2d_backward_shift<T>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, x, shift, part, d);
-        hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(kBlock), 0, stream, (const CT*)part, gshift, C, N,
+        hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(N)), 0, stream, (const CT*)part, gshift, C, N,
                            normalize_grad);
     }
     set_group2(d, d.H * d.W);                                             // rubiks.cpp:151-153

@@ -182,8 +182,8 @@ __global__ __launch_bounds__(kBlock) void k2d_finalize(const typename Compute<T>
     const CT* p = part + (size_t)c * 2 * P;
     double s[2] = {0, 0};
     for (int k = 0; k < 2; ++k)
-        for (int i = threadIdx.x; i < P; i += kBlock) s[k] += (double)p[(size_t)k * P + i];
-    for (int k = 0; k < 2; ++k) s[k] = group_sum(s[k], kBlock, red[k]);
+        for (int i = threadIdx.x; i < P; i += blockDim.x) s[k] += (double)p[(size_t)k * P + i];
+    for (int k = 0; k < 2; ++k) s[k] = group_sum(s[k], (int)blockDim.x, red[k]);
     if (threadIdx.x == 0) {
         CT gH = (CT)s[0], gW = (CT)s[1];
         if (normalize) {

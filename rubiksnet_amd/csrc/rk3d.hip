@@ -76,7 +76,7 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && gshift) {
             if (const int P = dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(kBlock), 0, stream, (const float*)ws, gshift,
+                hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const float*)ws, gshift,
                                    d.C, P, normalize_grad, t_factor);
                 return launch_status();
             }
@@ -88,7 +88,7 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
     if (gshift && col3d::supported(d, quantize)) {
         const int P = col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream);
-        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(kBlock), 0, stream, (const T*)ws, gshift, d.C, P,
+        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const T*)ws, gshift, d.C, P,
                            normalize_grad, t_factor);
         return launch_status();
     }
@@ -98,7 +98,7 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         set_group(d, d.Ho * d.Wo);
         hipLaunchKernelGGL((k3d_backward_shift_generic<T>), dim3(grid_for(d, (long long)d.N * d.To * d.C)),
                            dim3(kBlock), 0, stream, x, shift, gy, part, d);
-        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(kBlock), 0, stream, (const T*)part, gshift, d.C,
+        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(finalize_block(d.N * d.To)), 0, stream, (const T*)part, gshift, d.C,
                            d.N * d.To, normalize_grad, t_factor);
     }
     if (gx) {       // rubiks.cpp:363-376

@@ -297,7 +297,8 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_shift_generic(const T* __
 }
 
 // ------------------------------------------------------------- row-sum + K5 (fused)
-// One workgroup per channel: fixed-order fp64 sum of the P partials of each component
+// One workgroup per channel (finalize_block(P) threads: a single wave -- no barriers -- when P <= 64):
+// fixed-order fp64 sum of the P partials of each component
 // (replaces the addmv_ row-sum, rubiks.cpp:344-345), then rubiks3d_kernels.cu:932-960.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k3d_finalize(const T* __restrict__ part, T* __restrict__ gshift,
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(kBlock) void k3d_finalize(const T* __restrict__ par
     const T* p = part + (size_t)c * 3 * P;
     double s[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k)
-        for (int i = threadIdx.x; i < P; i += kBlock) s[k] += (double)p[(size_t)k * P + i];
-    for (int k = 0; k < 3; ++k) s[k] = group_sum(s[k], kBlock, red[k]);
+        for (int i = threadIdx.x; i < P; i += blockDim.x) s[k] += (double)p[(size_t)k * P + i];
+    for (int k = 0; k < 3; ++k) s[k] = group_sum(s[k], (int)blockDim.x, red[k]);
     if (threadIdx.x == 0) {
         T gT = (T)s[0], gH = (T)s[1], gW = (T)s[2];
         if (normalize) {

@@ -414,7 +414,7 @@ inline int launch_backward<float>(const float* x, const float* shift, const floa
     if (gshift) {
         if (gx) launch_bwd<true>(x, shift, gy, gx, ws, s, d, stream);
         else launch_bwd<false>(x, shift, gy, nullptr, ws, s, d, stream);
-        hipLaunchKernelGGL((k3d_finalize<float>), dim3(s.C), dim3(kBlock), 0, stream, (const float*)ws, gshift, s.C,
+        hipLaunchKernelGGL((k3d_finalize<float>), dim3(s.C), dim3(finalize_block(s.N)), 0, stream, (const float*)ws, gshift, s.C,
                            s.N, normalize, t_factor);
     } else if (gx) {
         launch_interp<true>(gy, shift, gx, s, stream);

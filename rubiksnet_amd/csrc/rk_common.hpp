@@ -68,6 +68,9 @@ __device__ __forceinline__ float4 lds_b128(const float4* p) {
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RK_OK : RK_ERR_LAUNCH; }
 
+// threads of a finalize workgroup for P partials per channel
+inline int finalize_block(int P) { return P <= kWave ? kWave : kBlock; }
+
 inline int pow2_at_least(int v, int lo, int hi) {
     int p = lo;
     while (p < v && p < hi) p <<= 1;
