@@ -156,6 +156,32 @@ RK_DECL_TAP(bf16, void, float)
 
 size_t rk_tshift3_backward_workspace_bytes(int NT, int n_segment, int C, int HW);
 
+/* ---- BatchNorm2d (+ ReLU) of the backbone blocks -- widening row f3 of SURVEY 8(f) ----------------
+ * Replaces the reference's nn.BatchNorm2d followed by nn.ReLU(inplace=True)
+ * (rubiksnet/backbone.py:50-53 BN2d; :129 relu(bn1(x)), :131 relu(bn2(conv2(.))), :196 relu(bn_last(x))),
+ * i.e. torch.nn.functional.batch_norm + relu on an NCHW tensor.
+ *   x, y, dy, dx : [F, C, P] contiguous (F = N*T frames, P = H*W), f32 or bf16; parameters / statistics are f32.
+ *   training != 0: batch statistics (biased variance for the normalisation); save_mean / save_invstd [C] are
+ *                  written for the backward; running_mean / running_var (both or neither) are updated as
+ *                  r = (1 - momentum) r + momentum * stat, with the UNBIASED variance, as torch does.
+ *                  Needs ws of rk_bn_workspace_bytes(F, C, P) bytes.
+ *   training == 0: y = relu?(gamma (x - running_mean) / sqrt(running_var + eps) + beta); save_*, ws unused.
+ *   backward     : gradients of the training-mode forward; the ReLU mask is recomputed from x.
+ *   relu != 0 fuses the ReLU (and its backward).                                                         */
+size_t rk_bn_workspace_bytes(int F, int C, int P);
+#define RK_DECL_BN(SFX, CTYPE)                                                                                   \
+    int rk_bn_relu_forward_##SFX(const CTYPE* x, const float* gamma, const float* beta, float* running_mean,     \
+                                 float* running_var, float* save_mean, float* save_invstd, CTYPE* y, int F,      \
+                                 int C, int P, float eps, float momentum, int relu, int training, void* ws,     \
+                                 size_t ws_bytes, rk_stream_t stream);                                           \
+    int rk_bn_relu_backward_##SFX(const CTYPE* dy, const CTYPE* x, const float* gamma, const float* beta,        \
+                                  const float* save_mean, const float* save_invstd, CTYPE* dx, float* dgamma,    \
+                                  float* dbeta, int F, int C, int P, int relu, void* ws, size_t ws_bytes,        \
+                                  rk_stream_t stream);
+RK_DECL_BN(f32, float)
+RK_DECL_BN(bf16, void)
+#undef RK_DECL_BN
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,12 @@ SIGNATURES = {
     "rk3d_backward_f64": (_i, [_p] * 5 + _DIMS3 + [_i, ctypes.c_double, _i, _p, _sz, _p]),
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
     "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_bn_workspace_bytes": (_sz, [_i, _i, _i]),
 }
+for _sfx in ("f32", "bf16"):
+    SIGNATURES["rk_bn_relu_forward_" + _sfx] = (
+        _i, [_p] * 8 + [_i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _i, _p, _sz, _p])
+    SIGNATURES["rk_bn_relu_backward_" + _sfx] = (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _sz, _p])
 for _sfx in ("f32", "f64", "f16", "bf16"):
     SIGNATURES["rk2d_forward_" + _sfx] = (_i, [_p, _p, _p] + _DIMS2 + [_i, _p])
     SIGNATURES["rk2d_backward_" + _sfx] = (_i, [_p] * 5 + _DIMS2 + [_i, _i, _i, _p, _sz, _p])

@@ -1,7 +1,8 @@
 """2D pre-activation residual backbone built from RubiksShift blocks.
 
-Counterpart of rubiksnet/backbone.py:14-235.  Everything except the shift is stock PyTorch
-(conv / BN / Linear run on MIOpen / hipBLASLt under PyTorch-ROCm).  Module and attribute
+Counterpart of rubiksnet/backbone.py:14-235.  Convolutions and Linear are stock PyTorch (MIOpen /
+hipBLASLt under PyTorch-ROCm); the BatchNorm2d modules are stock too, but each `relu(bn(x))` pair is
+evaluated by one fused HIP operator on GPU tensors (fused_bn.py; `RK_FUSED_BN=0` restores the stock pair).  Module and attribute
 names (`conv1`, `layer0..4`, `bn1`, `conv2`, `bn2`, `as3`, `se`, `conv3`, `shortcut`,
 `bn_last`, `avgpool`, `fc`) are the reference's, so state dicts are interchangeable.
 """
@@ -9,6 +10,7 @@ import math
 
 import torch.nn as nn
 
+from .fused_bn import bn_relu
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 
 __all__ = ["RubiksNetBackbone", "RubiksShiftBlock", "SELayer"]
@@ -110,9 +112,9 @@ class RubiksShiftBlock(nn.Module):
             self.shortcut = nn.Identity()
 
     def forward(self, x):
-        out = self.relu(self.bn1(x))
+        out = bn_relu(self.bn1, x)          # relu(bn(.)) as one operator on GPU tensors (fused_bn.py)
         shortcut = x if isinstance(self.shortcut, nn.Identity) else self.shortcut(out)
-        out = self.relu(self.bn2(self.conv2(out)))
+        out = bn_relu(self.bn2, self.conv2(out))
         out = self.as3(out)
         if self.se:
             out = self.se(out)
@@ -159,7 +161,7 @@ class RubiksNetBackbone(nn.Module):
         x = self.conv1(x)
         for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)
-        x = self.relu(self.bn_last(x))
+        x = bn_relu(self.bn_last, x)
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))
 

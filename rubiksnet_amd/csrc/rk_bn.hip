@@ -1,0 +1,338 @@
+// rk_bn.hip -- fused BatchNorm2d (+ ReLU) for the pre-activation blocks of the backbone (SURVEY 8(f) f3:
+// "remaining block glue as fused elementwise kernels").  Every BatchNorm2d of the network is followed by a
+// ReLU (rubiksnet/backbone.py:129-131, :196); with stock kernels the pair costs BN (MIOpen: 1.1 TB/s
+// effective forward, 2.4 TB/s backward on the Tiny train step) + an elementwise ReLU pass each way, 39 % +
+// 7.5 % of the step.  Here:
+//   training forward : k_bn_stats  (read x)              -> per-(channel, frame group) shifted sums
+//                      k_bn_apply  (read x, write y)     -> each workgroup re-derives its channel's mean / var
+//                                                            from the partials (fixed order, fp64), applies
+//                                                            y = max(a x + b, 0); group 0 also writes the saved
+//                                                            mean / invstd and updates the running statistics
+//   backward         : k_bn_bwd_reduce (read dy, x)      -> partial sum(dz), sum(dz * xhat), dz = dy * [y > 0]
+//                      k_bn_bwd_dx     (read dy, x, write dx; group 0 writes dgamma, dbeta)
+//   eval forward     : k_bn_apply with the running statistics
+// 12 B/elem forward, 20 B/elem backward (fp32), no atomics (deterministic), the ReLU mask is recomputed from
+// x with the forward's own expression (nothing but x is saved for backward).
+// Layout: x [F, C, P] (NCHW with F = N*T frames, P = H*W); a workgroup owns (channel c, group of FB frames)
+// and sweeps its FB planes as 16-byte cells when P % 4 == 0 (every plane of the networks but 7x7).
+// Variance: sums of (x - K) and (x - K)^2 with K = x[0, c, 0], combined in fp64 -- the shifted-data form, immune
+// to the E[x^2] - mean^2 cancellation.  Parameters and statistics are fp32 whatever the storage type.
+#include "rk_common.hpp"
+
+using namespace rk;
+
+namespace {
+
+struct BnDims {
+    int F, C, P;        // frames, channels, plane elements
+    int FB, G;          // frames per workgroup, groups per channel
+};
+
+template <typename T, int VEC> struct Pack;
+template <> struct Pack<float, 4> {
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Pack<__hip_bfloat16, 4> {
+    __device__ static __forceinline__ void load(const __hip_bfloat16* p, float (&v)[4]) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+    __device__ static __forceinline__ unsigned bits(float f) {
+        return (unsigned)__builtin_bit_cast(unsigned short, __float2bfloat16(f));
+    }
+    __device__ static __forceinline__ void store(__hip_bfloat16* p, const float (&v)[4]) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(bits(v[0]) | (bits(v[1]) << 16), bits(v[2]) | (bits(v[3]) << 16));
+    }
+};
+template <typename T> struct Pack<T, 1> {
+    __device__ static __forceinline__ void load(const T* p, float (&v)[1]) { v[0] = ld(p); }
+    __device__ static __forceinline__ void store(T* p, const float (&v)[1]) { st(p, v[0]); }
+};
+
+struct Where { int c, g, f0, nf; };
+__device__ __forceinline__ Where where_am_i(const BnDims& d) {
+    Where w;
+    w.c = blockIdx.x % d.C;                   // channel fastest: consecutive workgroups sweep memory in order
+    w.g = blockIdx.x / d.C;
+    w.f0 = w.g * d.FB;
+    w.nf = min(d.FB, d.F - w.f0);
+    return w;
+}
+
+// visit the workgroup's elements VEC at a time: fn(element offset into the tensor)
+template <int VEC, typename Fn>
+__device__ __forceinline__ void sweep(const BnDims& d, const Where& w, Fn fn) {
+    const int PV = d.P / VEC;
+    const int total = w.nf * PV;
+    const size_t base = ((size_t)w.f0 * d.C + w.c) * d.P;
+    const size_t fstride = (size_t)d.C * d.P;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < total; j += kBlock) {
+        const int fr = j / PV, i = j - fr * PV;
+        fn(base + (size_t)fr * fstride + (size_t)i * VEC);
+    }
+}
+
+// fixed-order fp64 sum of the channel's G partial pairs; every workgroup of the channel gets identical values
+__device__ __forceinline__ void channel_sums(const float* __restrict__ part, int c, int G, double (&out)[2],
+                                             double (*smem)[2]) {
+    double a = 0, b = 0;
+    if (threadIdx.x < kWave) {
+        const float* p = part + (size_t)c * G * 2;
+        for (int i = threadIdx.x; i < G; i += kWave) { a += (double)p[2 * i]; b += (double)p[2 * i + 1]; }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (threadIdx.x == 0) { smem[0][0] = a; smem[0][1] = b; }
+    }
+    __syncthreads();
+    out[0] = smem[0][0];
+    out[1] = smem[0][1];
+}
+
+__device__ __forceinline__ void block_pair_sum(float a, float b, float* out, float (*red)[kBlock / kWave]) {
+    a = group_sum(a, kBlock, red[0]);
+    b = group_sum(b, kBlock, red[1]);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_bn_stats(const T* __restrict__ x, float* __restrict__ part, BnDims d) {
+    __shared__ float red[2][kBlock / kWave];
+    const Where w = where_am_i(d);
+    const float K = ld(x + (size_t)w.c * d.P);
+    float s = 0.f, q = 0.f;
+    sweep<VEC>(d, w, [&](size_t o) {
+        float v[VEC];
+        Pack<T, VEC>::load(x + o, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float t = v[e] - K; s += t; q = fmaf(t, t, q); }
+    });
+    block_pair_sum(s, q, part + ((size_t)w.c * d.G + w.g) * 2, red);
+}
+
+// a, b of y = a x + b, identical in forward and backward (the ReLU mask depends on it)
+__device__ __forceinline__ void affine(float gamma, float beta, float mean, float invstd, float& a, float& b) {
+    a = gamma * invstd;
+    b = fmaf(-mean, a, beta);
+}
+
+template <typename T, int VEC, bool RELU, bool TRAIN>
+__global__ __launch_bounds__(kBlock) void k_bn_apply(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ part,
+                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                     T* __restrict__ y, BnDims d, float eps, float momentum) {
+    __shared__ double sm[1][2];
+    const Where w = where_am_i(d);
+    float mean, invstd;
+    if (TRAIN) {
+        double S[2];
+        channel_sums(part, w.c, d.G, S, sm);
+        const double M = (double)d.F * d.P;
+        const double ms = S[0] / M;
+        double var = S[1] / M - ms * ms;
+        var = var < 0 ? 0 : var;
+        mean = (float)((double)ld(x + (size_t)w.c * d.P) + ms);
+        invstd = 1.0f / sqrtf((float)var + eps);
+        if (w.g == 0 && threadIdx.x == 0) {
+            save_mean[w.c] = mean;
+            save_invstd[w.c] = invstd;
+            if (running_mean) {                                       // torch: unbiased variance in the running estimate
+                const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
+                running_mean[w.c] = (1.f - momentum) * running_mean[w.c] + momentum * mean;
+                running_var[w.c] = (1.f - momentum) * running_var[w.c] + momentum * unbiased;
+            }
+        }
+    } else {
+        mean = running_mean[w.c];
+        invstd = 1.0f / sqrtf(running_var[w.c] + eps);
+    }
+    float a, b;
+    affine(gamma[w.c], beta[w.c], mean, invstd, a, b);
+    sweep<VEC>(d, w, [&](size_t o) {
+        float v[VEC];
+        Pack<T, VEC>::load(x + o, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float t = fmaf(a, v[e], b);
+            v[e] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        Pack<T, VEC>::store(y + o, v);
+    });
+}
+
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd,
+                                                          float* __restrict__ part, BnDims d) {
+    __shared__ float red[2][kBlock / kWave];
+    const Where w = where_am_i(d);
+    const float mean = save_mean[w.c], invstd = save_invstd[w.c];
+    float a, b;
+    affine(gamma[w.c], beta[w.c], mean, invstd, a, b);
+    float s1 = 0.f, s2 = 0.f;
+    sweep<VEC>(d, w, [&](size_t o) {
+        float xv[VEC], gv[VEC];
+        Pack<T, VEC>::load(x + o, xv);
+        Pack<T, VEC>::load(dy + o, gv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float dz = (RELU && fmaf(a, xv[e], b) <= 0.f) ? 0.f : gv[e];
+            s1 += dz;
+            s2 = fmaf(dz, (xv[e] - mean) * invstd, s2);
+        }
+    });
+    block_pair_sum(s1, s2, part + ((size_t)w.c * d.G + w.g) * 2, red);
+}
+
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_invstd,
+                                                      const float* __restrict__ part, T* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, BnDims d) {
+    __shared__ double sm[1][2];
+    const Where w = where_am_i(d);
+    double S[2];
+    channel_sums(part, w.c, d.G, S, sm);
+    if (w.g == 0 && threadIdx.x == 0) {
+        dbeta[w.c] = (float)S[0];
+        dgamma[w.c] = (float)S[1];
+    }
+    const double M = (double)d.F * d.P;
+    const float k1 = (float)(S[0] / M), k2 = (float)(S[1] / M);
+    const float mean = save_mean[w.c], invstd = save_invstd[w.c];
+    float a, b;
+    affine(gamma[w.c], beta[w.c], mean, invstd, a, b);
+    sweep<VEC>(d, w, [&](size_t o) {
+        float xv[VEC], gv[VEC];
+        Pack<T, VEC>::load(x + o, xv);
+        Pack<T, VEC>::load(dy + o, gv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float dz = (RELU && fmaf(a, xv[e], b) <= 0.f) ? 0.f : gv[e];
+            const float xh = (xv[e] - mean) * invstd;
+            gv[e] = a * (dz - k1 - xh * k2);
+        }
+        Pack<T, VEC>::store(dx + o, gv);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+int make_bn(BnDims& d, int F, int C, int P) {
+    if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;
+    if ((long long)F * C * P > 0x7fffffffLL * 4) return RK_ERR_BAD_DIMS;
+    static const int chunk = [] { const char* e = getenv("RK_BN_CHUNK"); return e ? atoi(e) : 12288; }();
+    d.F = F; d.C = C; d.P = P;
+    int fb = (chunk + P - 1) / P;
+    fb = fb < 1 ? 1 : (fb > F ? F : fb);
+    d.FB = fb;
+    d.G = (F + fb - 1) / fb;
+    return RK_OK;
+}
+unsigned grid_bn(const BnDims& d) { return (unsigned)((long long)d.C * d.G); }
+size_t ws_bn(const BnDims& d) { return (size_t)d.C * d.G * 2 * sizeof(float); }
+template <typename T> bool vec4_ok(const BnDims& d, const void* a, const void* b, const void* c = nullptr) {
+    const uintptr_t m = 4 * sizeof(T) - 1;
+    return d.P % 4 == 0 && !((uintptr_t)a & m) && !((uintptr_t)b & m) && !((uintptr_t)c & m);
+}
+
+template <typename T>
+int bn_forward(const void* x_, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               float* save_mean, float* save_invstd, void* y_, int F, int C, int P, float eps, float momentum,
+               int relu, int training, void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    const T* x = (const T*)x_; T* y = (T*)y_;
+    if (!x || !y || !gamma || !beta) return RK_ERR_NULL_POINTER;
+    if (training ? (!save_mean || !save_invstd) : (!running_mean || !running_var)) return RK_ERR_NULL_POINTER;
+    if (training && ((running_mean == nullptr) != (running_var == nullptr))) return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    if (training && (!ws || ws_bytes < ws_bn(d))) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid(grid_bn(d)), block(kBlock);
+    float* part = (float*)ws;
+    const bool v4 = vec4_ok<T>(d, x, y);
+#define RK_BN_APPLY(VEC, RELU, TRAIN)                                                                              \
+    hipLaunchKernelGGL((k_bn_apply<T, VEC, RELU, TRAIN>), grid, block, 0, stream, x, gamma, beta, (const float*)part, \
+                       running_mean, running_var, save_mean, save_invstd, y, d, eps, momentum)
+    if (training) {
+        if (v4) hipLaunchKernelGGL((k_bn_stats<T, 4>), grid, block, 0, stream, x, part, d);
+        else hipLaunchKernelGGL((k_bn_stats<T, 1>), grid, block, 0, stream, x, part, d);
+        if (v4) { if (relu) RK_BN_APPLY(4, true, true); else RK_BN_APPLY(4, false, true); }
+        else { if (relu) RK_BN_APPLY(1, true, true); else RK_BN_APPLY(1, false, true); }
+    } else {
+        if (v4) { if (relu) RK_BN_APPLY(4, true, false); else RK_BN_APPLY(4, false, false); }
+        else { if (relu) RK_BN_APPLY(1, true, false); else RK_BN_APPLY(1, false, false); }
+    }
+#undef RK_BN_APPLY
+    return launch_status();
+}
+
+template <typename T>
+int bn_backward(const void* dy_, const void* x_, const float* gamma, const float* beta, const float* save_mean,
+                const float* save_invstd, void* dx_, float* dgamma, float* dbeta, int F, int C, int P, int relu,
+                void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    const T* dy = (const T*)dy_; const T* x = (const T*)x_; T* dx = (T*)dx_;
+    if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta)
+        return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    if (!ws || ws_bytes < ws_bn(d)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid(grid_bn(d)), block(kBlock);
+    float* part = (float*)ws;
+    const bool v4 = vec4_ok<T>(d, x, dy, dx);
+#define RK_BN_BWD(VEC, RELU)                                                                                       \
+    do {                                                                                                           \
+        hipLaunchKernelGGL((k_bn_bwd_reduce<T, VEC, RELU>), grid, block, 0, stream, dy, x, gamma, beta, save_mean,  \
+                           save_invstd, part, d);                                                                  \
+        hipLaunchKernelGGL((k_bn_bwd_dx<T, VEC, RELU>), grid, block, 0, stream, dy, x, gamma, beta, save_mean,      \
+                           save_invstd, (const float*)part, dx, dgamma, dbeta, d);                                 \
+    } while (0)
+    if (v4) { if (relu) RK_BN_BWD(4, true); else RK_BN_BWD(4, false); }
+    else { if (relu) RK_BN_BWD(1, true); else RK_BN_BWD(1, false); }
+#undef RK_BN_BWD
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk_bn_workspace_bytes(int F, int C, int P) {
+    BnDims d;
+    return make_bn(d, F, C, P) ? 0 : ws_bn(d);
+}
+
+#define RK_DEF_BN(SFX, TYPE, CTYPE)                                                                               \
+    int rk_bn_relu_forward_##SFX(const CTYPE* x, const float* gamma, const float* beta, float* running_mean,      \
+                                 float* running_var, float* save_mean, float* save_invstd, CTYPE* y, int F,       \
+                                 int C, int P, float eps, float momentum, int relu, int training, void* ws,      \
+                                 size_t ws_bytes, rk_stream_t stream) {                                           \
+        return bn_forward<TYPE>(x, gamma, beta, running_mean, running_var, save_mean, save_invstd, y, F, C, P,    \
+                                eps, momentum, relu, training, ws, ws_bytes, stream);                             \
+    }                                                                                                             \
+    int rk_bn_relu_backward_##SFX(const CTYPE* dy, const CTYPE* x, const float* gamma, const float* beta,         \
+                                  const float* save_mean, const float* save_invstd, CTYPE* dx, float* dgamma,     \
+                                  float* dbeta, int F, int C, int P, int relu, void* ws, size_t ws_bytes,         \
+                                  rk_stream_t stream) {                                                           \
+        return bn_backward<TYPE>(dy, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, F, C, P, relu,    \
+                                 ws, ws_bytes, stream);                                                           \
+    }
+RK_DEF_BN(f32, float, float)
+RK_DEF_BN(bf16, __hip_bfloat16, void)
+#undef RK_DEF_BN
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""BatchNorm2d + ReLU as one HIP operator (librubiks_hip: rk_bn_relu_*), SURVEY 8(f) row f3.
+
+Every BatchNorm2d of the backbone is followed by `nn.ReLU(inplace=True)` (rubiksnet/backbone.py:129-131,
+:196).  `bn_relu(bn, x)` computes `relu(bn(x))` for an ordinary `nn.BatchNorm2d` module -- its parameters,
+buffers, momentum / eps / training flag and state-dict stay exactly what they are -- through the fused kernels
+when x is a CUDA fp32 / bf16 NCHW tensor, and through `F.relu(bn(x))` (stock PyTorch) otherwise (CPU tensors
+of the gloo tests, other dtypes, eval mode with gradients).  `RK_FUSED_BN=0` forces the stock path.
+
+Training forward: 12 B/elem (stats pass + normalise pass), backward: 20 B/elem, nothing saved but x and the
+[C] mean / invstd (stock: BN saves x, ReLU saves its output).
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _native
+
+__all__ = ["bn_relu", "fused_bn_enabled"]
+
+_SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+def fused_bn_enabled():
+    return os.environ.get("RK_FUSED_BN", "1") != "0"
+
+
+def _ws(L, Fr, C, P, dev):
+    nbytes = int(L.rk_bn_workspace_bytes(Fr, C, P))
+    return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev), nbytes
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _BNReLUTrain(torch.autograd.Function):
+    """y = relu?(batch_norm(x)) with batch statistics; updates running_mean / running_var in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        L = _native.lib()
+        Fr, C, H, W = x.shape
+        P = H * W
+        dev = x.device
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws, nbytes = _ws(L, Fr, C, P, dev)
+            rc = getattr(L, "rk_bn_relu_forward_" + _SFX[x.dtype])(
+                x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                save_mean.data_ptr(), save_invstd.data_ptr(), y.data_ptr(), Fr, C, P, float(eps), float(momentum),
+                int(relu), 1, ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_bn_relu_forward")
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+        ctx.relu = relu
+        return y            # (running_mean / running_var are buffers updated in place by the kernel, as F.batch_norm does)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        L = _native.lib()
+        Fr, C, H, W = x.shape
+        P = H * W
+        dev = x.device
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws, nbytes = _ws(L, Fr, C, P, dev)
+            rc = getattr(L, "rk_bn_relu_backward_" + _SFX[x.dtype])(
+                dy.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), save_mean.data_ptr(),
+                save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, P,
+                int(ctx.relu), ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_bn_relu_backward")
+        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None
+
+
+def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):
+    L = _native.lib()
+    Fr, C, H, W = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = getattr(L, "rk_bn_relu_forward_" + _SFX[x.dtype])(
+            x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+            None, None, y.data_ptr(), Fr, C, H * W, float(eps), 0.0, int(relu), 0, None, 0,
+            torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "rk_bn_relu_forward")
+    return y
+
+
+def _fusable(bn, x):
+    return (
+        fused_bn_enabled()
+        and isinstance(bn, torch.nn.BatchNorm2d)
+        and x.is_cuda and x.dim() == 4 and x.dtype in _SFX and x.numel() > 0
+        and bn.affine and bn.weight.dtype == torch.float32
+        and (bn.running_mean is None or bn.running_mean.dtype == torch.float32)
+    )
+
+
+def bn_relu(bn, x, relu=True):
+    """`relu(bn(x))` (or `bn(x)` with relu=False) for an nn.BatchNorm2d module `bn`."""
+    if not _fusable(bn, x):
+        y = bn(x)
+        return F.relu(y, inplace=True) if relu else y
+    use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
+    x = x.contiguous()
+    if use_batch_stats:
+        # nn.BatchNorm2d.forward's bookkeeping (torch/nn/modules/batchnorm.py): count the batch, pick the factor
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
+        rv = bn.running_var if (bn.training and bn.track_running_stats) else None
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu)
+    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+        y = bn(x)                                  # frozen-statistics fine-tuning: stock kernels
+        return F.relu(y, inplace=True) if relu else y
+    return _eval_forward(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)

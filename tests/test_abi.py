@@ -17,7 +17,8 @@ def declared_symbols():
     names = set(re.findall(r"\b(rk[0-9a-z_]*?)\s*\(", text))
     names = {n for n in names if not n.endswith("_")}
     for macro, templ in (("RK_DECL_2D", ["rk2d_forward_%s", "rk2d_backward_%s"]),
-                         ("RK_DECL_TAP", ["rk_tshift3_forward_%s", "rk_tshift3_backward_%s"])):
+                         ("RK_DECL_TAP", ["rk_tshift3_forward_%s", "rk_tshift3_backward_%s"]),
+                         ("RK_DECL_BN", ["rk_bn_relu_forward_%s", "rk_bn_relu_backward_%s"])):
         for sfx in re.findall(macro + r"\((\w+),", text):
             if sfx != "SFX":
                 names.update(t % sfx for t in templ)
@@ -43,6 +44,8 @@ def test_version_shape_helper_and_error_strings():
     assert L.rk3d_backward_workspace_bytes(32, 8, 64, 56, 56, 1, 1, 1, 0, 0, 0, 4) == 64 * 3 * 32 * 56 * 4  # per clip: max(To, H, ceil(H*W/256)) partials
     assert L.rk2d_backward_workspace_bytes(4, 10, 7, 7, 1, 1, 0, 0, 4) == 10 * 2 * 4 * 4
     assert L.rk_tshift3_backward_workspace_bytes(16, 8, 5, 49) == 5 * 3 * 2 * 8
+    assert L.rk_bn_workspace_bytes(256, 54, 56 * 56) == 54 * 64 * 2 * 4      # 4 frames per workgroup -> 64 groups
+    assert L.rk_bn_workspace_bytes(0, 54, 49) == 0
 
 
 def test_argument_validation_without_a_device():
@@ -51,6 +54,9 @@ def test_argument_validation_without_a_device():
     one = ctypes.c_void_p(16)     # non-NULL dummy; never dereferenced on these paths
     dims = (2, 8, 4, 6, 6)
     assert L.rk3d_forward_f32(None, one, one, *dims, 1, 1, 1, 0, 0, 0, 0, None) == -1
+    assert L.rk_bn_relu_forward_f32(one, one, one, one, one, None, None, one, 4, 3, 16, 1e-5, 0.1, 1, 1, one, 1 << 20, None) == -1
+    assert L.rk_bn_relu_forward_f32(one, one, one, one, one, one, one, one, 4, 3, 16, 1e-5, 0.1, 1, 1, None, 0, None) == -4
+    assert L.rk_bn_relu_backward_bf16(one, one, one, one, one, one, one, one, one, 4, 0, 16, 1, one, 1 << 20, None) == -2
     assert L.rk3d_forward_f32(one, one, one, 0, 8, 4, 6, 6, 1, 1, 1, 0, 0, 0, 0, None) == -2
     assert L.rk3d_forward_f64(one, one, one, *dims, 1, 0, 1, 0, 0, 0, 0, None) == -3
     assert L.rk3d_forward_f32(one, one, one, *dims, 1, 1, 1, 0, -1, 0, 0, None) == -3

@@ -1,0 +1,145 @@
+"""GPU parity: fused BatchNorm2d(+ReLU) (rk_bn_relu_*) versus torch's own batch_norm + relu on the CPU in fp64 --
+the pair the reference's blocks are built from (rubiksnet/backbone.py:50-53, :129-131, :196)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (8, 6, 12, 12),      # P % 4 == 0, one frame group
+    (5, 3, 7, 7),        # 7x7 planes: element-wise path
+    (20, 54, 28, 28),    # two frame groups, the second one ragged
+    (3, 4, 56, 56),      # one frame per group
+    (1, 2, 2, 2),
+]
+
+
+def _make(shape, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.7 + torch.randn(1, C, 1, 1, generator=g) * 3).to(dtype)
+    dy = torch.randn(shape, generator=g).to(dtype)
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    return x, dy, bn
+
+
+def _reference(bn, x, dy, relu, training):
+    """torch CPU, fp64: F.batch_norm + relu, the ops nn.BatchNorm2d / nn.ReLU run."""
+    ref = copy.deepcopy(bn).double()
+    ref.train(training)
+    xr = x.double().requires_grad_(True)
+    y = ref(xr)
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.double())
+    return y.detach(), xr.grad, ref.weight.grad, ref.bias.grad, ref
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_training_forward_backward_and_running_stats(shape, relu):
+    from rubiksnet_amd.fused_bn import bn_relu
+
+    x, dy, bn = _make(shape, seed=sum(shape))
+    y_ref, dx_ref, dw_ref, db_ref, ref = _reference(bn, x, dy, relu, True)
+    dev = copy.deepcopy(bn).cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    y = bn_relu(dev, xd, relu=relu)
+    y.backward(dy.cuda())
+    tol = dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.numpy(), **tol)
+    scale = max(1.0, float(dx_ref.abs().max()))
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), dx_ref.numpy(), rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(dev.weight.grad.cpu().numpy(), dw_ref.numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(dw_ref.abs().max())))
+    np.testing.assert_allclose(dev.bias.grad.cpu().numpy(), db_ref.numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(db_ref.abs().max())))
+    np.testing.assert_allclose(dev.running_mean.cpu().numpy(), ref.running_mean.numpy(), **tol)
+    np.testing.assert_allclose(dev.running_var.cpu().numpy(), ref.running_var.numpy(), **tol)
+    assert int(dev.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", SHAPES[:3])
+def test_eval_forward_uses_running_statistics(shape):
+    from rubiksnet_amd.fused_bn import bn_relu
+
+    x, dy, bn = _make(shape, seed=7)
+    dev = copy.deepcopy(bn).cuda().eval()
+    with torch.no_grad():
+        y = bn_relu(dev, x.cuda())
+        y_ref = F.relu(bn.double().eval()(x.double()))
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert int(dev.num_batches_tracked) == 0
+
+
+def test_cumulative_average_and_no_running_stats():
+    from rubiksnet_amd.fused_bn import bn_relu
+
+    x, dy, _ = _make((6, 4, 8, 8), seed=1)
+    for kwargs in ({"momentum": None}, {"track_running_stats": False}):
+        ref = nn.BatchNorm2d(4, **kwargs).double()
+        dev = nn.BatchNorm2d(4, **kwargs).cuda()
+        for _ in range(2):
+            y_ref = F.relu(ref(x.double()))
+            y = bn_relu(dev, x.cuda())
+        np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+        if ref.running_mean is not None:
+            np.testing.assert_allclose(dev.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(dev.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_large_mean_does_not_cancel():
+    """|mean| >> std: E[x^2] - mean^2 in fp32 would lose the variance; the shifted sums do not."""
+    from rubiksnet_amd.fused_bn import bn_relu
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, 3, 14, 14, generator=g) * 0.01 + 300.0
+    bn = nn.BatchNorm2d(3)
+    y_ref = F.relu(copy.deepcopy(bn).double()(x.double()))
+    y = bn_relu(bn.cuda(), x.cuda())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=0, atol=2e-2)   # x itself carries 3e-5 / 0.01 of noise
+
+
+def test_bf16_storage():
+    from rubiksnet_amd.fused_bn import bn_relu
+
+    x, dy, bn = _make((8, 6, 12, 12), seed=3, dtype=torch.bfloat16)
+    y_ref, dx_ref, dw_ref, db_ref, _ = _reference(bn, x.float(), dy.float(), True, True)
+    dev = copy.deepcopy(bn).cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    y = bn_relu(dev, xd)
+    assert y.dtype == torch.bfloat16
+    y.backward(dy.cuda())
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), y_ref.numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), dx_ref.numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(dev.weight.grad.cpu().numpy(), dw_ref.numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(dev.bias.grad.cpu().numpy(), db_ref.numpy(), rtol=1e-3, atol=1e-2)
+
+
+def test_block_matches_stock_batchnorm(monkeypatch):
+    """A whole RubiksShift block, fused BN+ReLU against the stock nn.BatchNorm2d + ReLU pair."""
+    from rubiksnet_amd import RubiksNet, fused_bn
+
+    torch.manual_seed(0)
+    net = RubiksNet("tiny", 11, verbose=False).cuda().train()
+    block = net.backbone.layer1[0]
+    x = torch.randn(16, block.bn1.num_features, 28, 28, device="cuda")
+    outs = []
+    for enabled in (True, False):
+        monkeypatch.setenv("RK_FUSED_BN", "1" if enabled else "0")
+        assert fused_bn.fused_bn_enabled() is enabled
+        blk = copy.deepcopy(block)
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        y.square().mean().backward()
+        outs.append((y.detach(), xi.grad, blk.bn2.weight.grad, blk.bn1.running_var.clone()))
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())))

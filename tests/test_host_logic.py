@@ -166,3 +166,23 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".sh")):
                 text = open(os.path.join(dp, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "librubiks_oracle" not in text, f
+
+
+def test_bn_relu_on_cpu_is_the_stock_pair():
+    """fused_bn.bn_relu leaves non-GPU tensors to nn.BatchNorm2d + relu (the gloo tests train on the CPU)."""
+    import copy
+
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from rubiksnet_amd.fused_bn import bn_relu
+
+    torch.manual_seed(0)
+    bn = nn.BatchNorm2d(5)
+    ref = copy.deepcopy(bn)
+    x = torch.randn(4, 5, 6, 6)
+    assert torch.equal(bn_relu(bn, x), F.relu(ref(x)))
+    assert torch.equal(bn.running_var, ref.running_var) and int(bn.num_batches_tracked) == 1
+    bn.eval(); ref.eval()
+    assert torch.equal(bn_relu(bn, x, relu=False), ref(x))
