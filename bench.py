@@ -128,14 +128,12 @@ def pmc_traffic(kernel_substr):
     (tools/pmc.sh + tools/make_profile_summary.py: separate rocprofv3 --pmc passes, FETCH_SIZE doubled)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        data = json.load(f)
-    for name, rec in data.items():
-        if kernel_substr in name:
-            return rec["hbm_bytes"], "%s :: %s" % (os.path.relpath(files[-1], ROOT), name)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        with open(path) as f:
+            data = json.load(f)
+        for name, rec in data.items():
+            if kernel_substr in name:
+                return rec["hbm_bytes"], "%s :: %s" % (os.path.relpath(path, ROOT), name)
     return None, None
 
 
@@ -233,7 +231,7 @@ def main():
     if env.is_main and env.world_size == 1 and not args.no_cpu:
         cpu = cpu_baseline()
 
-    traffic, traffic_src = pmc_traffic("backward")
+    traffic, traffic_src = pmc_traffic("k3d_dma_backward")
     rk2d = op2d_bench(env) if env.is_main else None
 
     if env.is_main:

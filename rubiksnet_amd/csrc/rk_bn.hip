@@ -19,9 +19,8 @@
 // to the E[x^2] - mean^2 cancellation.  Parameters and statistics are fp32 whatever the storage type.
 #include "rk_common.hpp"
 
-using namespace rk;
-
-namespace {
+namespace rk {
+namespace bn {
 
 struct BnDims {
     int F, C, P;        // frames, channels, plane elements
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
 int make_bn(BnDims& d, int F, int C, int P) {
     if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;
     if ((long long)F * C * P > 0x7fffffffLL * 4) return RK_ERR_BAD_DIMS;
-    static const int chunk = [] { const char* e = getenv("RK_BN_CHUNK"); return e ? atoi(e) : 12288; }();
+    static const int chunk = [] { const char* e = getenv("RK_BN_CHUNK"); return e ? atoi(e) : 8192; }();
     d.F = F; d.C = C; d.P = P;
     int fb = (chunk + P - 1) / P;
     fb = fb < 1 ? 1 : (fb > F ? F : fb);
@@ -307,7 +306,11 @@ int bn_backward(const void* dy_, const void* x_, const float* gamma, const float
     return launch_status();
 }
 
-}  // namespace
+}  // namespace bn
+}  // namespace rk
+
+using namespace rk;
+using namespace rk::bn;
 
 extern "C" {
 

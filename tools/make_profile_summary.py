@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Condense rocprofv3 outputs under gpurun_out/ into small tracked files under profiles/.
 
-    python tools/make_profile_summary.py <round-tag> <kernel-stats-dir> [<pmc-dir>]
+    python tools/make_profile_summary.py <tag> <kernel-stats-dir | -> [<pmc-dir>]
 """
 import collections
 import csv
@@ -27,16 +27,17 @@ def main():
     pdir = sys.argv[3] if len(sys.argv) > 3 else None
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(kdir, "*kernel_stats.csv"))[0]
-    rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
-                        r["MaxNs"], r["StdDev"]])
+    if kdir != "-":
+        stats = glob.glob(os.path.join(kdir, "*kernel_stats.csv"))[0]
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
     bj = os.path.join(kdir, "bench.json")
-    if os.path.exists(bj) and os.path.getsize(bj):
+    if kdir != "-" and os.path.exists(bj) and os.path.getsize(bj):
         with open(os.path.join(out, "%s_bench_under_rocprof.json" % tag), "w") as f:
             f.write(open(bj).read())
     if pdir:

@@ -46,3 +46,6 @@ if "aq" in which: run("tiny-aq fp32 train", variant="rubiks3d-aq")
 if "aqbf16" in which: run("tiny-aq bf16-autocast train", variant="rubiks3d-aq", amp=torch.bfloat16)
 if "large" in which: run("large fp32 train batch 16", tier="large", batch=16)
 if "eval" in which: run("tiny fp32 eval batch 64", batch=64, eval_=True)
+if "large32" in which: run("large fp32 train batch 32", tier="large", batch=32)
+if "largeaq" in which: run("large-aq bf16-autocast train batch 32", tier="large", variant="rubiks3d-aq", batch=32, amp=torch.bfloat16)
+if "largeeval" in which: run("large fp32 eval batch 64", tier="large", batch=64, eval_=True)
