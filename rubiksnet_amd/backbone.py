@@ -11,6 +11,7 @@ import math
 import torch.nn as nn
 
 from .fused_bn import bn_relu
+from .pointwise import conv1x1
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 
 __all__ = ["RubiksNetBackbone", "RubiksShiftBlock", "SELayer"]
@@ -113,12 +114,12 @@ class RubiksShiftBlock(nn.Module):
 
     def forward(self, x):
         out = bn_relu(self.bn1, x)          # relu(bn(.)) as one operator on GPU tensors (fused_bn.py)
-        shortcut = x if isinstance(self.shortcut, nn.Identity) else self.shortcut(out)
-        out = bn_relu(self.bn2, self.conv2(out))
+        shortcut = x if isinstance(self.shortcut, nn.Identity) else conv1x1(self.shortcut, out)
+        out = bn_relu(self.bn2, conv1x1(self.conv2, out))
         out = self.as3(out)
         if self.se:
             out = self.se(out)
-        out = self.conv3(out)
+        out = conv1x1(self.conv3, out)
         out += shortcut
         return out
 

@@ -1,0 +1,61 @@
+"""GPU parity: the NCHW MFMA 1x1-convolution GEMM (rk_pw_gemm_f32, pointwise.conv1x1) against
+torch.nn.functional.conv2d evaluated in fp64 on the CPU -- the op the reference's Conv1x1 layers run
+(rubiksnet/backbone.py:44-45)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [   # frames, Cin, Cout, H, W
+    (3, 6, 10, 4, 4),          # tiny: one partial tile
+    (5, 54, 54, 8, 8),         # K = 54 = 3 x 18
+    (4, 24, 54, 12, 12),       # K = 24 = 2 x 12
+    (2, 54, 108, 28, 28),      # M > 64: two waves along M
+    (3, 216, 432, 6, 6),       # M > 256: two row tiles; K = 12 x 18
+    (7, 64, 40, 10, 14),       # K = 4 x 16, ragged columns
+    (2, 50, 22, 6, 6),         # K = 50: padded last chunk
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_and_gradients(monkeypatch, case):
+    from rubiksnet_amd.pointwise import conv1x1
+
+    monkeypatch.setenv("RK_PW", "all")
+    Fr, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(Fr, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    dy = torch.randn(Fr, Cout, H, W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(dy.double())
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xd = x.cuda().requires_grad_(True)
+    y = conv1x1(conv, xd)
+    assert y.grad_fn is not None and "Conv1x1Func" in type(y.grad_fn).__name__      # the HIP path ran
+    y.backward(dy.cuda())
+    for got, ref in ((y, yr), (xd.grad, xr.grad), (conv.weight.grad, wr.grad)):
+        ref = ref.detach()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6 * max(1.0, float(ref.abs().max())) * Cin ** 0.5)
+
+
+def test_ineligible_layers_take_the_stock_path(monkeypatch):
+    from rubiksnet_amd.pointwise import conv1x1
+
+    monkeypatch.setenv("RK_PW", "all")
+    x = torch.randn(2, 6, 7, 7, device="cuda", requires_grad=True)          # 49 pixels: P % 4 != 0
+    conv = nn.Conv2d(6, 8, 1, bias=False).cuda()
+    y = conv1x1(conv, x)
+    assert "Conv1x1Func" not in type(y.grad_fn).__name__
+    assert torch.equal(y, conv(x))
+    s2 = nn.Conv2d(6, 8, 1, stride=2, bias=False).cuda()                    # strided shortcut
+    assert torch.equal(conv1x1(s2, x), s2(x))
+    monkeypatch.setenv("RK_PW", "0")
+    x4 = torch.randn(2, 6, 8, 8, device="cuda", requires_grad=True)
+    assert "Conv1x1Func" not in type(conv1x1(conv, x4).grad_fn).__name__
