@@ -190,6 +190,11 @@ RK_DECL_BN(bf16, void)
  *                    d(input): A = weight read as [K=Cout][M=Cin], a_is_mk = 0, X = d(output).            */
 int rk_pw_gemm_f32(const float* A, const float* X, float* Y, int F, int K, int M, int P, int a_is_mk,
                    rk_stream_t stream);
+/*   rk_pw_wgrad_f32: d(weight)[M][K] = sum_f dY[f] X[f]^T, dY [F,M,P], X [F,K,P]; ws of
+ *                    rk_pw_wgrad_workspace_bytes() bytes holds per-chunk partials (summed in a fixed order).   */
+size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P);
+int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
+                    size_t ws_bytes, rk_stream_t stream);
 
 #ifdef __cplusplus
 }

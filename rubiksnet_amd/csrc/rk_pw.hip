@@ -53,9 +53,9 @@ struct AStage {
     }
 };
 
-// kKC: K chunk (even); the launcher picks one that divides K when it can, so that no MFMA runs on padding
+// kKC: K chunk (12 or 16: the launcher picks the one that pads K less)
 template <int WM, int kKC>
-__global__ __launch_bounds__(kBlock, (kKC > 16 ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const float* __restrict__ X,
+__global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const float* __restrict__ X,
                                                     float* __restrict__ Y, PwDims d) {
     constexpr int MT = 64 * WM, WN = 4 / WM;
     __shared__ float As[2][kKC * MT];
@@ -123,6 +123,180 @@ __global__ __launch_bounds__(kBlock, (kKC > 16 ? 1 : 2)) void k_pw_gemm(const fl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// d(weight):  dW[m][k] = sum over pixels n = (f, p) of dY[f][m][p] * X[f][k][p].
+// The reduction index is the contiguous one, so both MFMA operands are "transposed" with respect to memory
+// (lane <-> channel): tiles of 64 channels x 32 pixels are loaded with 16-byte loads along the pixels and
+// passed through LDS (column index XOR-swizzled with the row: fragment reads are bank-conflict free).  A wave is an independent
+// task -- (64-row block of dY, 64-row block of X, range of pixels) -> a 64 x 64 partial product in 64
+// accumulator registers; the 4 waves of a workgroup take 4 consecutive tasks.  Partials go to
+// ws[chunk][M][K] (no atomics); k_pw_wgrad_reduce sums the chunks in a fixed order.
+constexpr int kNB = 32;                  // pixels per staged tile
+__device__ __forceinline__ int tile_at(int row, int col) { return row * kNB + (col ^ (row & (kNB - 1))); }
+
+struct WgDims {
+    int F, K, M, P;
+    long long ntot;
+    int MB, KB;                          // 64-row blocks of dY / X
+    int S;                               // pixel chunks
+    int chunk;                           // pixels per chunk (multiple of kNB)
+};
+
+// one lane's share of a 64 x 32 tile: 8 float4 (row = 8 j + lane / 8, pixels 4 (lane % 8) ..+3)
+__device__ __forceinline__ void wg_fetch(const float* __restrict__ T, int rows, int r0, int P, long long n0,
+                                         long long nend, int Ftot, float4 (&v)[8], int Cdim) {
+    const int lane = threadIdx.x & 63;
+    const long long n = n0 + 4 * (lane & 7);
+    const bool nok = n < nend;
+    const long long nc = nok ? n : 0;
+    const int f = (int)(nc / P), p = (int)(nc - (long long)f * P);
+    const float* base = T + ((size_t)f * Cdim) * P + p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 8 * j + (lane >> 3);
+        v[j] = (nok && r < rows) ? *reinterpret_cast<const float4*>(base + (size_t)r * P)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = 8 * j + (lane >> 3), col = 4 * (lane & 7);
+        tile[tile_at(row, col)] = v[j].x; tile[tile_at(row, col + 1)] = v[j].y;
+        tile[tile_at(row, col + 2)] = v[j].z; tile[tile_at(row, col + 3)] = v[j].w;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pw_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
+                                                     float* __restrict__ ws, WgDims d) {
+    __shared__ float tiles[4][2][64 * kNB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    // workgroup -> (pixel chunk, group of up to 4 (mb, kb) blocks); with fewer than 4 blocks in the group the
+    // spare waves split the chunk's pixels and their accumulators are summed through LDS at the end
+    const int nmk = d.MB * d.KB;
+    const int bpw = nmk < 4 ? nmk : 4;                          // blocks per workgroup: 1, 2 (or 3), 4
+    const int sub = 4 / bpw;                                    // pixel sub-chunks per workgroup: 4, 2, 1, 1
+    const int groups = (nmk + bpw - 1) / bpw;
+    const int chunk = blockIdx.x / groups, grp = blockIdx.x - chunk * groups;
+    const int blk = wave % bpw, subc = wave / bpw;
+    const int mk = grp * bpw + blk;
+    const bool live = mk < nmk && subc < sub;
+    const int mkc = live ? mk : 0;
+    const int mb = mkc / d.KB, kb = mkc - mb * d.KB;
+    const int per = d.chunk / sub;                              // multiple of kNB (make_wg)
+    const long long n0 = (long long)chunk * d.chunk + (long long)subc * per;
+    long long nend = n0 + per;
+    nend = nend < d.ntot ? nend : d.ntot;
+    if (!live) nend = n0;                                       // dead wave: zeros
+    float* ta = tiles[wave][0];
+    float* tb = tiles[wave][1];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 va[8], vb[8];
+    wg_fetch(dY, d.M, 64 * mb, d.P, n0, nend, d.F, va, d.M);
+    wg_fetch(X, d.K, 64 * kb, d.P, n0, nend, d.F, vb, d.K);
+    const int steps = per / kNB;                                // same for every wave: barriers stay uniform
+#pragma nounroll
+    for (int it = 0; it < steps; ++it) {
+        __syncthreads();                                        // previous tile fully consumed
+        wg_deposit(ta, va);
+        wg_deposit(tb, vb);
+        __syncthreads();
+        const long long nn = n0 + (long long)(it + 1) * kNB;
+        wg_fetch(dY, d.M, 64 * mb, d.P, nn, nend, d.F, va, d.M);       // next tile, in flight during the MFMAs
+        wg_fetch(X, d.K, 64 * kb, d.P, nn, nend, d.F, vb, d.K);
+#pragma unroll
+        for (int s = 0; s < kNB / 2; ++s) {
+            const float a0 = ta[tile_at(l31, 2 * s + kh)], a1 = ta[tile_at(32 + l31, 2 * s + kh)];
+            const float b0 = tb[tile_at(l31, 2 * s + kh)], b1 = tb[tile_at(32 + l31, 2 * s + kh)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // sum the sub-chunk waves of each block into its subc == 0 wave (fixed order), through the tile memory
+    __syncthreads();
+    if (sub > 1) {
+        float* mine = &tiles[wave][0][0];                       // 64 x 64 floats = this wave's two tiles
+        if (subc > 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (subc == 0) {
+            for (int o = 1; o < sub; ++o) {
+                const float* other = &tiles[blk + o * bpw][0][0];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] += other[((a * 2 + b) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (live && subc == 0) {
+        float* out = ws + (size_t)chunk * d.M * d.K;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = 64 * mb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int gk = 64 * kb + 32 * b + l31;
+                    if (gm < d.M && gk < d.K) out[(size_t)gm * d.K + gk] = acc[a][b][r];
+                }
+    }
+}
+
+// out[part][i] = sum of in[c][i] over the chunks c of this part (c = part, part + parts, ...): coalesced in i,
+// fixed order.  Launched twice: S chunks -> kRed parts -> 1.
+constexpr int kRed = 32;
+__global__ __launch_bounds__(kBlock) void k_pw_wgrad_reduce(const float* __restrict__ in, float* __restrict__ out,
+                                                            int MK, int S, int parts) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int part = blockIdx.y;
+    if (i >= MK) return;
+    float s = 0.f;
+    for (int c = part; c < S; c += parts) s += in[(size_t)c * MK + i];
+    out[(size_t)part * MK + i] = s;
+}
+
+inline int make_wg(WgDims& d, int F, int K, int M, int P) {
+    if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0) return RK_ERR_BAD_DIMS;
+    d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
+    d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
+    // ~1536 wave tasks (6 per CU), but keep the partials (S * M * K floats, written and read once) under a
+    // quarter of the operands' bytes
+    static const int want_env = [] { const char* e = getenv("RK_PW_WG_TASKS"); return e ? atoi(e) : 1536; }();
+    const int nmk = d.MB * d.KB;
+    long long S = want_env / (nmk < 4 ? 4 : nmk);                   // one partial per workgroup-chunk
+    const long long cap = ((long long)(M + K) * d.ntot) / (4LL * M * K);
+    if (S > cap) S = cap;
+    if (S < 1) S = 1;
+    long long chunk = (d.ntot + S - 1) / S;
+    chunk = (chunk + 4 * kNB - 1) / (4 * kNB) * (4 * kNB);          // splits into 1, 2 or 4 sub-chunks of whole tiles
+    d.chunk = (int)chunk;
+    d.S = (int)((d.ntot + chunk - 1) / chunk);
+    return RK_OK;
+}
+
 }  // namespace pw
 }  // namespace rk
 
@@ -147,16 +321,45 @@ int rk_pw_gemm_f32(const float* A, const float* X, float* Y, int F, int K, int M
     const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
     hipStream_t stream = (hipStream_t)stream_;
     static const int kc_env = [] { const char* e = getenv("RK_PW_KC"); return e ? atoi(e) : 0; }();
-    int kc = 16;
-    for (int cand : {18, 16, 12, 6}) if (K % cand == 0) { kc = cand; break; }
-    if (kc_env == 6 || kc_env == 12 || kc_env == 16 || kc_env == 18) kc = kc_env;
+    // chunk of 12 or 16 (2 waves per SIMD; 18 needs too many registers): the one that pads K less
+    int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;
+    if (kc_env == 12 || kc_env == 16) kc = kc_env;
 #define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<WMV, KCV>), grid, block, 0, stream, A, X, Y, d)
-#define RK_PW_KC(WMV) do { if (kc == 18) RK_PW_GO(WMV, 18); else if (kc == 12) RK_PW_GO(WMV, 12); else if (kc == 6) RK_PW_GO(WMV, 6); else RK_PW_GO(WMV, 16); } while (0)
+#define RK_PW_KC(WMV) do { if (kc == 12) RK_PW_GO(WMV, 12); else RK_PW_GO(WMV, 16); } while (0)
     if (wm == 1) RK_PW_KC(1);
     else if (wm == 2) RK_PW_KC(2);
     else RK_PW_KC(4);
 #undef RK_PW_KC
 #undef RK_PW_GO
+    return launch_status();
+}
+
+size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P) {
+    WgDims d;
+    return make_wg(d, F, K, M, P) ? 0 : (size_t)(d.S + kRed) * M * K * sizeof(float);
+}
+
+// dW[M][K] = sum_f dY[f] X[f]^T.  dY [F,M,P], X [F,K,P] fp32, P % 4 == 0, 16-byte aligned.
+int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
+                    size_t ws_bytes, rk_stream_t stream_) {
+    if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
+    WgDims d;
+    if (int rc = make_wg(d, F, K, M, P)) return rc;
+    if (((uintptr_t)X & 15) || ((uintptr_t)dY & 15)) return RK_ERR_BAD_DIMS;
+    if (!ws || ws_bytes < (size_t)(d.S + kRed) * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nmk = d.MB * d.KB, bpw = nmk < 4 ? nmk : 4, groups = (nmk + bpw - 1) / bpw;
+    float* part = (float*)ws;
+    float* part2 = part + (size_t)d.S * M * K;
+    const int MK = M * K;
+    const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_pw_wgrad, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    if (d.S > kRed) {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
+    } else {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
+    }
     return launch_status();
 }
 

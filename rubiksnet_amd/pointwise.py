@@ -1,11 +1,13 @@
 """1x1 convolutions of the backbone through librubiks_hip's NCHW MFMA GEMM (rk_pw_gemm_f32), SURVEY 8(f) f1.
 
 `conv1x1(conv, x)` evaluates an ordinary bias-free `nn.Conv2d(kernel_size=1, stride=1)` module -- the module,
-its weight, its state-dict key stay what they are.  The HIP path takes the layers it wins on (fp32, large
-planes: the memory-bound 112x112 / 56x56 stages, where MIOpen's NHWC implicit GEMM pays for two layout
-transposes); everything else -- other dtypes, small planes, CPU tensors -- goes to `conv(x)` (MIOpen / stock).
-`RK_PW=0` disables the HIP path, `RK_PW=all` forces it wherever the kernel's constraints allow.
-Forward and d(input) are the HIP GEMM; d(weight) is still aten's convolution_backward.
+its weight, its state-dict key stay what they are.  For fp32 GPU tensors with H*W % 4 == 0 and even channel
+counts, d(weight) always runs on the HIP kernel (2.6x / 2.3x / 2.0x / 1.25x MIOpen's at 56x56 / 54->108 / 28x28 /
+14x14: MIOpen's NHWC implicit GEMM needs two layout transposes), and forward / d(input) do where they win -- the
+memory-bound 112x112 / 56x56 stages; elsewhere they stay on aten (MIOpen).  Other dtypes, 7x7 planes, strided
+shortcuts, CPU tensors: `conv(x)`.  `RK_PW=0` disables the HIP path, `RK_PW=all` forces the HIP GEMM wherever
+the kernel's constraints allow.
+Forward, d(input) and d(weight) are HIP MFMA kernels (`RK_PW_WGRAD=0`: d(weight) through aten / MIOpen).
 """
 import os
 
@@ -29,14 +31,41 @@ def _gemm(a, x, out, Fr, K, M, P, a_is_mk):
     return out
 
 
+def _wgrad(dy, x, weight):
+    if os.environ.get("RK_PW_WGRAD", "1") == "0":       # aten / MIOpen d(weight)
+        return torch.ops.aten.convolution_backward(dy, x, weight, None, *_ATEN_ARGS, [False, True, False])[1]
+    Fr, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    dev = x.device
+    L = _native.lib()
+    dw = torch.empty_like(weight)
+    with torch.cuda.device(dev):
+        nbytes = int(L.rk_pw_wgrad_workspace_bytes(Fr, Cin, Cout, H * W))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        rc = L.rk_pw_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W, ws.data_ptr(), nbytes,
+                               torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "rk_pw_wgrad_f32")
+    return dw
+
+
+_ATEN_ARGS = ([1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+
+
 class _Conv1x1Func(torch.autograd.Function):
+    """1x1 convolution; `hip_gemm` selects the HIP GEMM for forward / d(input) (else aten = MIOpen);
+    d(weight) is the HIP kernel either way (it wins on every shape: MIOpen's needs two layout transposes)."""
+
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, hip_gemm):
         Fr, Cin, H, W = x.shape
         Cout = weight.shape[0]
-        y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
-        _gemm(weight, x, y, Fr, Cin, Cout, H * W, True)
+        if hip_gemm:
+            y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
+            _gemm(weight, x, y, Fr, Cin, Cout, H * W, True)
+        else:
+            y = torch.ops.aten.convolution(x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(x, weight)
+        ctx.hip_gemm = hip_gemm
         return y
 
     @staticmethod
@@ -45,34 +74,38 @@ class _Conv1x1Func(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            Fr, Cin, H, W = x.shape
-            dx = torch.empty_like(x)
-            _gemm(weight, dy, dx, Fr, weight.shape[0], Cin, H * W, False)     # W read as [K=Cout][M=Cin]
+            if ctx.hip_gemm:
+                Fr, Cin, H, W = x.shape
+                dx = torch.empty_like(x)
+                _gemm(weight, dy, dx, Fr, weight.shape[0], Cin, H * W, False)     # W read as [K=Cout][M=Cin]
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, *_ATEN_ARGS, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(
-                dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw
+            dw = _wgrad(dy, x, weight)
+        return dx, dw, None
 
 
 def _eligible(conv, x):
+    """None: stock path; else whether forward / d(input) should use the HIP GEMM too."""
     mode = pointwise_mode()
     if mode == "0" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
-        return False
+        return None
     if not (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None
             and conv.weight.dtype == torch.float32):
-        return False
+        return None
     P = x.shape[2] * x.shape[3]
     K, M = conv.in_channels, conv.out_channels
     if P % 4 or K % 2 or M % 2 or x.numel() == 0:      # kernel constraints (M even: it is K of the d(input) GEMM)
-        return False
+        return None
     if mode == "all":
         return True
-    return P >= 3136 and K <= 128 and M <= 128           # measured win region (tools/pointwise_probe.py)
+    return P >= 3136 and K <= 128 and M <= 128           # measured win region of the GEMM (tools/pointwise_probe.py)
 
 
 def conv1x1(conv, x):
     """`conv(x)` for a 1x1 nn.Conv2d module."""
-    if not _eligible(conv, x):
+    hip_gemm = _eligible(conv, x)
+    if hip_gemm is None:
         return conv(x)
-    return _Conv1x1Func.apply(x.contiguous(), conv.weight)
+    return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm)

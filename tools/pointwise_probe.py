@@ -50,7 +50,14 @@ for dt in ((torch.float32,) if os.environ.get("PW_ONLY") else (torch.float32, to
                 gr = torch.nn.grad.conv2d_input(x.shape, w, gy); gk = pw_dx(gy, w)
                 e1 = float((yk - yr).abs().max() / yr.abs().max()); e2 = float((gk - gr).abs().max() / gr.abs().max())
                 tk = timeit(lambda: pw_fwd(x, w)); tkx = timeit(lambda: pw_dx(gy, w))
-                print("   rk_pw fwd %7.1f us (rel err %.1e) | d(input) %7.1f us (rel err %.1e)" % (tk, e1, tkx, e2))
+                from rubiksnet_amd.pointwise import _wgrad
+                wr = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                wk = _wgrad(gy, x.detach(), w.detach())
+                e3 = float((wk - wr).abs().max() / wr.abs().max())
+                tw = timeit(lambda: _wgrad(gy, x.detach(), w.detach()))
+                twr = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+                tdr = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False]))
+                print("   rk_pw fwd %7.1f us (rel err %.1e) | d(input) %7.1f us (rel err %.1e; MIOpen %7.1f) | d(weight) %7.1f us (rel err %.1e; MIOpen %7.1f)" % (tk, e1, tkx, e2, tdr, tw, e3, twr))
         if os.environ.get("PW_ONLY"): continue
         tc = timeit(conv_fb); tm = 0.0
         es = x.element_size()
