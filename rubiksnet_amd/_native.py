@@ -34,7 +34,7 @@ SIGNATURES = {
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
     "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_bn_workspace_bytes": (_sz, [_i, _i, _i]),
-    "rk_pw_gemm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rk_pw_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_pw_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
 }

@@ -119,9 +119,7 @@ class RubiksShiftBlock(nn.Module):
         out = self.as3(out)
         if self.se:
             out = self.se(out)
-        out = conv1x1(self.conv3, out)
-        out += shortcut
-        return out
+        return conv1x1(self.conv3, out, residual=shortcut)      # conv3(out) + shortcut, the add in the GEMM's epilogue
 
 
 class RubiksNetBackbone(nn.Module):

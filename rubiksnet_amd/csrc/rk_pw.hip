@@ -56,7 +56,7 @@ struct AStage {
 // kKC: K chunk (12 or 16: the launcher picks the one that pads K less)
 template <int WM, int kKC>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const float* __restrict__ X,
-                                                    float* __restrict__ Y, PwDims d) {
+                                                    const float* __restrict__ R, float* __restrict__ Y, PwDims d) {
     constexpr int MT = 64 * WM, WN = 4 / WM;
     __shared__ float As[2][kKC * MT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -116,9 +116,14 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;   // C/D map of 32x32 MFMA
-                if (gm < d.M)
-                    *reinterpret_cast<float4*>(yp + (size_t)gm * d.P) =
-                        make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                if (gm < d.M) {
+                    float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                    if (R) {                                      // fused residual: Y = A X + R (the block's shortcut)
+                        const float4 t = *reinterpret_cast<const float4*>(R + (yp - Y) + (size_t)gm * d.P);
+                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+                    }
+                    *reinterpret_cast<float4*>(yp + (size_t)gm * d.P) = o;
+                }
             }
     }
 }
@@ -305,10 +310,12 @@ using namespace rk::pw;
 
 extern "C" {
 
-// Y[f] = A X[f].  a_is_mk != 0: A is [M][K] row-major; else [K][M].  X [F,K,P], Y [F,M,P] fp32, P % 4 == 0.
-int rk_pw_gemm_f32(const float* A, const float* X, float* Y, int F, int K, int M, int P, int a_is_mk,
-                   rk_stream_t stream_) {
+// Y[f] = A X[f] (+ R[f]).  a_is_mk != 0: A is [M][K] row-major; else [K][M].  X [F,K,P], Y / R [F,M,P] fp32,
+// P % 4 == 0.  R may be NULL (no residual) and may alias Y.
+int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                   int a_is_mk, rk_stream_t stream_) {
     if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
+    if (R && ((uintptr_t)R & 15)) return RK_ERR_BAD_DIMS;
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0 || K % 2 != 0) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
     PwDims d;
@@ -324,7 +331,7 @@ int rk_pw_gemm_f32(const float* A, const float* X, float* Y, int F, int K, int M
     // chunk of 12 or 16 (2 waves per SIMD; 18 needs too many registers): the one that pads K less
     int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;
     if (kc_env == 12 || kc_env == 16) kc = kc_env;
-#define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<WMV, KCV>), grid, block, 0, stream, A, X, Y, d)
+#define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<WMV, KCV>), grid, block, 0, stream, A, X, R, Y, d)
 #define RK_PW_KC(WMV) do { if (kc == 12) RK_PW_GO(WMV, 12); else RK_PW_GO(WMV, 16); } while (0)
     if (wm == 1) RK_PW_KC(1);
     else if (wm == 2) RK_PW_KC(2);

@@ -22,11 +22,12 @@ def pointwise_mode():
     return os.environ.get("RK_PW", "auto")
 
 
-def _gemm(a, x, out, Fr, K, M, P, a_is_mk):
+def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None):
     dev = x.device
     with torch.cuda.device(dev):
-        rc = _native.lib().rk_pw_gemm_f32(a.data_ptr(), x.data_ptr(), out.data_ptr(), Fr, K, M, P, int(a_is_mk),
-                                          torch.cuda.current_stream(dev).cuda_stream)
+        rc = _native.lib().rk_pw_gemm_f32(a.data_ptr(), x.data_ptr(),
+                                          residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                          Fr, K, M, P, int(a_is_mk), torch.cuda.current_stream(dev).cuda_stream)
     _native.check(rc, "rk_pw_gemm_f32")
     return out
 
@@ -56,16 +57,19 @@ class _Conv1x1Func(torch.autograd.Function):
     d(weight) is the HIP kernel either way (it wins on every shape: MIOpen's needs two layout transposes)."""
 
     @staticmethod
-    def forward(ctx, x, weight, hip_gemm):
+    def forward(ctx, x, weight, hip_gemm, residual):
         Fr, Cin, H, W = x.shape
         Cout = weight.shape[0]
         if hip_gemm:
             y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
-            _gemm(weight, x, y, Fr, Cin, Cout, H * W, True)
+            _gemm(weight, x, y, Fr, Cin, Cout, H * W, True, residual)      # `+ residual` in the GEMM's epilogue
         else:
             y = torch.ops.aten.convolution(x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+            if residual is not None:
+                y.add_(residual)
         ctx.save_for_backward(x, weight)
         ctx.hip_gemm = hip_gemm
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
@@ -82,7 +86,7 @@ class _Conv1x1Func(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, *_ATEN_ARGS, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dy, x, weight)
-        return dx, dw, None
+        return dx, dw, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None)
 
 
 def _eligible(conv, x):
@@ -103,9 +107,12 @@ def _eligible(conv, x):
     return P >= 3136 and K <= 128 and M <= 128           # measured win region of the GEMM (tools/pointwise_probe.py)
 
 
-def conv1x1(conv, x):
-    """`conv(x)` for a 1x1 nn.Conv2d module."""
+def conv1x1(conv, x, residual=None):
+    """`conv(x)` (`conv(x) + residual` when a residual is given) for a 1x1 nn.Conv2d module."""
     hip_gemm = _eligible(conv, x)
-    if hip_gemm is None:
-        return conv(x)
-    return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm)
+    if hip_gemm is None or (residual is not None and not (residual.is_contiguous() and residual.dtype == x.dtype)):
+        y = conv(x)
+        if residual is not None:
+            y += residual
+        return y
+    return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual)

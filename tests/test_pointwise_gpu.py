@@ -45,6 +45,28 @@ def test_forward_and_gradients(monkeypatch, case):
         np.testing.assert_allclose(got.detach().cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6 * max(1.0, float(ref.abs().max())) * Cin ** 0.5)
 
 
+@pytest.mark.parametrize("mode", ["all", "auto"])
+def test_fused_residual(monkeypatch, mode):
+    """conv3(out) + shortcut with the add in the GEMM epilogue (HIP GEMM) or after aten's convolution (auto mode on a
+    small plane): same values and gradients as the unfused pair."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    monkeypatch.setenv("RK_PW", mode)
+    torch.manual_seed(1)
+    conv = nn.Conv2d(12, 20, 1, bias=False).cuda()
+    x = torch.randn(3, 12, 8, 8, device="cuda", requires_grad=True)
+    r = torch.randn(3, 20, 8, 8, device="cuda", requires_grad=True)
+    dy = torch.randn(3, 20, 8, 8, device="cuda")
+    y = conv1x1(conv, x, residual=r)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), r.grad.clone(), conv.weight.grad.clone())
+    x.grad = r.grad = conv.weight.grad = None
+    y2 = conv(x) + r
+    y2.backward(dy)
+    for a, b in zip(got, (y2.detach(), x.grad, r.grad, conv.weight.grad)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
 def test_ineligible_layers_take_the_stock_path(monkeypatch):
     from rubiksnet_amd.pointwise import conv1x1
 

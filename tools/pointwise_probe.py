@@ -9,7 +9,7 @@ def pw_fwd(x, w, out=None):
     Fr, Cin, H, W = x.shape
     Cout = w.shape[0]
     y = torch.empty(Fr, Cout, H, W, device=x.device, dtype=x.dtype) if out is None else out
-    rc = _native.lib().rk_pw_gemm_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H * W, 1,
+    rc = _native.lib().rk_pw_gemm_f32(w.data_ptr(), x.data_ptr(), None, y.data_ptr(), Fr, Cin, Cout, H * W, 1,
                                       torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
     return y
@@ -17,7 +17,7 @@ def pw_dx(gy, w):
     Fr, Cout, H, W = gy.shape
     Cin = w.shape[1]
     gx = torch.empty(Fr, Cin, H, W, device=gy.device, dtype=gy.dtype)
-    rc = _native.lib().rk_pw_gemm_f32(w.data_ptr(), gy.data_ptr(), gx.data_ptr(), Fr, Cout, Cin, H * W, 0,
+    rc = _native.lib().rk_pw_gemm_f32(w.data_ptr(), gy.data_ptr(), None, gx.data_ptr(), Fr, Cout, Cin, H * W, 0,
                                       torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
     return gx
