@@ -90,3 +90,42 @@ def test_rubiks3d_variant_under_autocast():
         out = net(clips)
     out.float().sum().backward()
     assert torch.isfinite(out.float()).all()
+
+
+def test_fused_paths_match_the_stock_backbone(monkeypatch):
+    """RubiksNet-Tiny with the fused BN+ReLU and the HIP 1x1 convolutions against the same weights on the stock
+    nn.BatchNorm2d / ReLU / MIOpen convolution path: logits, loss, running statistics and a spread of
+    gradients agree to fp32 round-off (train mode), and so do the eval-mode logits."""
+    import copy
+
+    from rubiksnet_amd import RubiksNet
+
+    torch.manual_seed(3)
+    ref = RubiksNet("tiny", 9, verbose=False).to(DEV).train()
+    clips = torch.randn(2, 8, 3, 224, 224, device=DEV)
+    labels = torch.tensor([1, 7], device=DEV)
+    results = []
+    for fast in (True, False):
+        monkeypatch.setenv("RK_FUSED_BN", "1" if fast else "0")
+        monkeypatch.setenv("RK_PW", "auto" if fast else "0")
+        net = copy.deepcopy(ref)
+        logits = net(clips)
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters()
+                 if n.endswith(("conv1.weight", "layer1.0.conv2.weight", "layer1.1.bn2.weight", "layer3.0.conv3.weight",
+                                "layer0.0.bn1.bias", "fc.weight"))}
+        rv = net.backbone.layer2[0].bn2.running_var.clone()
+        net.eval()
+        with torch.no_grad():
+            ev = net(clips)
+        results.append((logits.detach(), loss.detach(), grads, rv, ev))
+    (la, lossa, ga, rva, eva), (lb, lossb, gb, rvb, evb) = results
+    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(float(lossa), float(lossb), rtol=1e-4)
+    np.testing.assert_allclose(rva.cpu().numpy(), rvb.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(eva.cpu().numpy(), evb.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    assert len(ga) == 6
+    for n in ga:
+        scale = float(gb[n].abs().max())
+        np.testing.assert_allclose(ga[n].cpu().numpy(), gb[n].cpu().numpy(), rtol=0, atol=2e-3 * scale, err_msg=n)
