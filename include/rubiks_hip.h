@@ -185,17 +185,22 @@ RK_DECL_BN(bf16, void)
 /* ---- 1x1 convolution on NCHW activations -- widening row f1 of SURVEY 8(f), unfused half -----------
  * Replaces torch.nn.functional.conv2d with a 1x1 kernel, stride 1, no bias (rubiksnet/backbone.py:44-45
  * Conv1x1; conv2 / conv3 / stride-1 shortcuts of every block, :87-104) and its two gradients.
- *   rk_pw_gemm_f32 : Y[f] = A X[f] (+ R[f]), X [F,K,P], Y / R [F,M,P] fp32, P % 4 == 0, 16-byte aligned.
- *                    forward: A = weight [M=Cout][K=Cin], a_is_mk = 1; R = the block's shortcut
- *                    (backbone.py:134 `out += shortcut`) or NULL;
- *                    d(input): A = weight read as [K=Cout][M=Cin], a_is_mk = 0, X = d(output), R = NULL.  */
+ *   rk_pw_gemm_*  : Y[f] = A X[f] (+ R[f]), X [F,K,P], Y / R [F,M,P] fp32 or bf16 storage (fp32 arithmetic),
+ *                   A always fp32 (under bf16 autocast the weight is used as it is, no cast), P % 4 == 0.
+ *                   forward: A = weight [M=Cout][K=Cin], a_is_mk = 1; R = the block's shortcut
+ *                   (backbone.py:134 `out += shortcut`) or NULL;
+ *                   d(input): A = weight read as [K=Cout][M=Cin], a_is_mk = 0, X = d(output), R = NULL.
+ *   rk_pw_wgrad_* : d(weight)[M][K] (fp32) = sum_f dY[f] X[f]^T, dY [F,M,P], X [F,K,P]; ws of
+ *                   rk_pw_wgrad_workspace_bytes() bytes holds per-chunk partials (summed in a fixed order).   */
 int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                    int a_is_mk, rk_stream_t stream);
-/*   rk_pw_wgrad_f32: d(weight)[M][K] = sum_f dY[f] X[f]^T, dY [F,M,P], X [F,K,P]; ws of
- *                    rk_pw_wgrad_workspace_bytes() bytes holds per-chunk partials (summed in a fixed order).   */
+int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F, int K, int M, int P,
+                    int a_is_mk, rk_stream_t stream);
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
                     size_t ws_bytes, rk_stream_t stream);
+int rk_pw_wgrad_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws,
+                     size_t ws_bytes, rk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,32 @@ namespace pw {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 4 consecutive pixels of the streamed tensors: fp32 or bf16 storage, fp32 arithmetic either way (activations
+// under bf16 autocast; the weights and d(weight) stay fp32, so the autocast casts of the weight disappear)
+template <typename T> struct Px4;
+template <> struct Px4<float> {
+    using Raw = float4;
+    __device__ static __forceinline__ Raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ static __forceinline__ Raw load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ float4 widen(const Raw& r) { return r; }
+    __device__ static __forceinline__ void store(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct Px4<__hip_bfloat16> {
+    using Raw = uint2;
+    __device__ static __forceinline__ Raw zero() { return make_uint2(0u, 0u); }
+    __device__ static __forceinline__ Raw load(const __hip_bfloat16* p) { return *reinterpret_cast<const uint2*>(p); }
+    __device__ static __forceinline__ float4 widen(const Raw& r) {
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                           __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    }
+    __device__ static __forceinline__ unsigned bits(float f) {
+        return (unsigned)__builtin_bit_cast(unsigned short, __float2bfloat16(f));
+    }
+    __device__ static __forceinline__ void store(__hip_bfloat16* p, const float4& v) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(bits(v.x) | (bits(v.y) << 16), bits(v.z) | (bits(v.w) << 16));
+    }
+};
+
 struct PwDims {
     int F, K, M, P;
     long long ntot;         // F * P columns
@@ -54,9 +80,10 @@ struct AStage {
 };
 
 // kKC: K chunk (12 or 16: the launcher picks the one that pads K less)
-template <int WM, int kKC>
-__global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const float* __restrict__ X,
-                                                    const float* __restrict__ R, float* __restrict__ Y, PwDims d) {
+template <typename T, int WM, int kKC>
+__global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
+                                                    const T* __restrict__ R, T* __restrict__ Y, PwDims d) {
+    using Raw = typename Px4<T>::Raw;
     constexpr int MT = 64 * WM, WN = 4 / WM;
     __shared__ float As[2][kKC * MT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -67,8 +94,8 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw
     const bool valid = cg < d.ntot;
     const long long cgc = valid ? cg : 0;
     const int f = (int)(cgc / d.P), p = (int)(cgc - (long long)f * d.P);
-    const float* xp = X + ((size_t)f * d.K) * d.P + p;
-    float* yp = Y + ((size_t)f * d.M) * d.P + p;
+    const T* xp = X + ((size_t)f * d.K) * d.P + p;
+    T* yp = Y + ((size_t)f * d.M) * d.P + p;
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -78,13 +105,12 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
 
-    auto load_b = [&](int k) -> float4 {
-        return (valid && k < d.K) ? *reinterpret_cast<const float4*>(xp + (size_t)k * d.P)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_b = [&](int k) -> Raw {
+        return (valid && k < d.K) ? Px4<T>::load(xp + (size_t)k * d.P) : Px4<T>::zero();
     };
 
     AStage<MT, kKC> ast;
-    float4 bq[kKC / 2];                                   // B fragments of the current chunk, refilled in place:
+    Raw bq[kKC / 2];                                      // B fragments of the current chunk, refilled in place:
     ast.fetch(A, d, m0, 0);                               // step s of chunk c+1 is requested right after step s of
 #pragma unroll                                            // chunk c has consumed its registers (one chunk of MFMAs ahead)
     for (int s = 0; s < kKC / 2; ++s) bq[s] = load_b(2 * s + kh);
@@ -99,7 +125,8 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw
 #pragma unroll
         for (int s = 0; s < kKC / 2; ++s) {
             const float a0 = as[(2 * s + kh) * MT], a1 = as[(2 * s + kh) * MT + 32];
-            const float bv[4] = {bq[s].x, bq[s].y, bq[s].z, bq[s].w};
+            const float4 bw = Px4<T>::widen(bq[s]);
+            const float bv[4] = {bw.x, bw.y, bw.z, bw.w};
             bq[s] = load_b((c + 1) * kKC + 2 * s + kh);    // (all zeros past K)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -119,10 +146,10 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16) ? 1 : 2)) void k_pw
                 if (gm < d.M) {
                     float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
                     if (R) {                                      // fused residual: Y = A X + R (the block's shortcut)
-                        const float4 t = *reinterpret_cast<const float4*>(R + (yp - Y) + (size_t)gm * d.P);
+                        const float4 t = Px4<T>::widen(Px4<T>::load(R + (yp - Y) + (size_t)gm * d.P));
                         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
                     }
-                    *reinterpret_cast<float4*>(yp + (size_t)gm * d.P) = o;
+                    Px4<T>::store(yp + (size_t)gm * d.P, o);
                 }
             }
     }
@@ -149,18 +176,19 @@ struct WgDims {
 };
 
 // one lane's share of a 64 x 32 tile: 8 float4 (row = 8 j + lane / 8, pixels 4 (lane % 8) ..+3)
-__device__ __forceinline__ void wg_fetch(const float* __restrict__ T, int rows, int r0, int P, long long n0,
+template <typename TT>
+__device__ __forceinline__ void wg_fetch(const TT* __restrict__ T, int rows, int r0, int P, long long n0,
                                          long long nend, int Ftot, float4 (&v)[8], int Cdim) {
     const int lane = threadIdx.x & 63;
     const long long n = n0 + 4 * (lane & 7);
     const bool nok = n < nend;
     const long long nc = nok ? n : 0;
     const int f = (int)(nc / P), p = (int)(nc - (long long)f * P);
-    const float* base = T + ((size_t)f * Cdim) * P + p;
+    const TT* base = T + ((size_t)f * Cdim) * P + p;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = r0 + 8 * j + (lane >> 3);
-        v[j] = (nok && r < rows) ? *reinterpret_cast<const float4*>(base + (size_t)r * P)
+        v[j] = (nok && r < rows) ? Px4<TT>::widen(Px4<TT>::load(base + (size_t)r * P))
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
@@ -174,7 +202,8 @@ __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_pw_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, const T* __restrict__ X,
                                                      float* __restrict__ ws, WgDims d) {
     __shared__ float tiles[4][2][64 * kNB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -308,16 +337,17 @@ inline int make_wg(WgDims& d, int F, int K, int M, int P) {
 using namespace rk;
 using namespace rk::pw;
 
-extern "C" {
+namespace {
 
-// Y[f] = A X[f] (+ R[f]).  a_is_mk != 0: A is [M][K] row-major; else [K][M].  X [F,K,P], Y / R [F,M,P] fp32,
-// P % 4 == 0.  R may be NULL (no residual) and may alias Y.
-int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
-                   int a_is_mk, rk_stream_t stream_) {
+template <typename T>
+int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int K, int M, int P, int a_is_mk,
+            rk_stream_t stream_) {
+    const T* X = (const T*)X_; const T* R = (const T*)R_; T* Y = (T*)Y_;
     if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
-    if (R && ((uintptr_t)R & 15)) return RK_ERR_BAD_DIMS;
+    const uintptr_t am = 4 * sizeof(T) - 1;
+    if (R && ((uintptr_t)R & am)) return RK_ERR_BAD_DIMS;
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0 || K % 2 != 0) return RK_ERR_BAD_DIMS;
-    if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
+    if (((uintptr_t)X & am) || ((uintptr_t)Y & am)) return RK_ERR_BAD_DIMS;
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
     static const int wm_env = [] { const char* e = getenv("RK_PW_WM"); return e ? atoi(e) : 0; }();
@@ -331,7 +361,7 @@ int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int
     // chunk of 12 or 16 (2 waves per SIMD; 18 needs too many registers): the one that pads K less
     int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;
     if (kc_env == 12 || kc_env == 16) kc = kc_env;
-#define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<WMV, KCV>), grid, block, 0, stream, A, X, R, Y, d)
+#define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV>), grid, block, 0, stream, A, X, R, Y, d)
 #define RK_PW_KC(WMV) do { if (kc == 12) RK_PW_GO(WMV, 12); else RK_PW_GO(WMV, 16); } while (0)
     if (wm == 1) RK_PW_KC(1);
     else if (wm == 2) RK_PW_KC(2);
@@ -341,18 +371,15 @@ int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int
     return launch_status();
 }
 
-size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P) {
-    WgDims d;
-    return make_wg(d, F, K, M, P) ? 0 : (size_t)(d.S + kRed) * M * K * sizeof(float);
-}
-
-// dW[M][K] = sum_f dY[f] X[f]^T.  dY [F,M,P], X [F,K,P] fp32, P % 4 == 0, 16-byte aligned.
-int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
-                    size_t ws_bytes, rk_stream_t stream_) {
+template <typename T>
+int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
+             rk_stream_t stream_) {
+    const T* dY = (const T*)dY_; const T* X = (const T*)X_;
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
     WgDims d;
     if (int rc = make_wg(d, F, K, M, P)) return rc;
-    if (((uintptr_t)X & 15) || ((uintptr_t)dY & 15)) return RK_ERR_BAD_DIMS;
+    const uintptr_t am = 4 * sizeof(T) - 1;
+    if (((uintptr_t)X & am) || ((uintptr_t)dY & am)) return RK_ERR_BAD_DIMS;
     if (!ws || ws_bytes < (size_t)(d.S + kRed) * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int nmk = d.MB * d.KB, bpw = nmk < 4 ? nmk : 4, groups = (nmk + bpw - 1) / bpw;
@@ -360,7 +387,7 @@ int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, in
     float* part2 = part + (size_t)d.S * M * K;
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_pw_wgrad, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     if (d.S > kRed) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
@@ -368,6 +395,35 @@ int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, in
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
     }
     return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P) {
+    WgDims d;
+    return make_wg(d, F, K, M, P) ? 0 : (size_t)(d.S + kRed) * M * K * sizeof(float);
+}
+
+// Y[f] = A X[f] (+ R[f]).  a_is_mk != 0: A is [M][K] row-major; else [K][M] (always fp32).  X [F,K,P], Y / R [F,M,P]
+// fp32 or bf16, P % 4 == 0.  R may be NULL (no residual) and may alias Y.
+int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                   int a_is_mk, rk_stream_t stream) {
+    return pw_gemm<float>(A, X, R, Y, F, K, M, P, a_is_mk, stream);
+}
+int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F, int K, int M, int P, int a_is_mk,
+                    rk_stream_t stream) {
+    return pw_gemm<__hip_bfloat16>(A, X, R, Y, F, K, M, P, a_is_mk, stream);
+}
+// dW[M][K] (fp32) = sum_f dY[f] X[f]^T.  dY [F,M,P], X [F,K,P] fp32 or bf16, P % 4 == 0.
+int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
+                    size_t ws_bytes, rk_stream_t stream) {
+    return pw_wgrad<float>(dY, X, dW, F, K, M, P, ws, ws_bytes, stream);
+}
+int rk_pw_wgrad_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws,
+                     size_t ws_bytes, rk_stream_t stream) {
+    return pw_wgrad<__hip_bfloat16>(dY, X, dW, F, K, M, P, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,7 +1,9 @@
 """1x1 convolutions of the backbone through librubiks_hip's NCHW MFMA GEMM (rk_pw_gemm_f32), SURVEY 8(f) f1.
 
 `conv1x1(conv, x)` evaluates an ordinary bias-free `nn.Conv2d(kernel_size=1, stride=1)` module -- the module,
-its weight, its state-dict key stay what they are.  For fp32 GPU tensors with H*W % 4 == 0 and even channel
+its weight, its state-dict key stay what they are.  Activations may be fp32 or bf16 (autocast: the fp32 weight is
+used as it is and d(weight) comes out in fp32 -- no casts; arithmetic is fp32 MFMA either way).  For GPU tensors
+with H*W % 4 == 0 and even channel
 counts, d(weight) always runs on the HIP kernel (2.6x / 2.3x / 2.0x / 1.25x MIOpen's at 56x56 / 54->108 / 28x28 /
 14x14: MIOpen's NHWC implicit GEMM needs two layout transposes), and forward / d(input) do where they win -- the
 memory-bound 112x112 / 56x56 stages; elsewhere they stay on aten (MIOpen).  Other dtypes, 7x7 planes, strided
@@ -22,30 +24,42 @@ def pointwise_mode():
     return os.environ.get("RK_PW", "auto")
 
 
+_SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}      # storage of the activations; weights are fp32
+
+
 def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None):
     dev = x.device
+    fn = getattr(_native.lib(), "rk_pw_gemm_" + _SFX[x.dtype])
     with torch.cuda.device(dev):
-        rc = _native.lib().rk_pw_gemm_f32(a.data_ptr(), x.data_ptr(),
-                                          residual.data_ptr() if residual is not None else None, out.data_ptr(),
-                                          Fr, K, M, P, int(a_is_mk), torch.cuda.current_stream(dev).cuda_stream)
-    _native.check(rc, "rk_pw_gemm_f32")
+        rc = fn(a.data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                Fr, K, M, P, int(a_is_mk), torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "rk_pw_gemm")
     return out
 
 
+def _as(weight, dtype):
+    return weight if weight.dtype == dtype else weight.to(dtype)
+
+
 def _wgrad(dy, x, weight):
-    if os.environ.get("RK_PW_WGRAD", "1") == "0":       # aten / MIOpen d(weight)
-        return torch.ops.aten.convolution_backward(dy, x, weight, None, *_ATEN_ARGS, [False, True, False])[1]
+    # bf16 activations: MIOpen's d(weight) is the faster one (133 vs 172 us at [256,54->54,56x56]); fp32: the HIP
+    # kernel (123 vs 319 us)
+    use_hip = os.environ.get("RK_PW_WGRAD", "auto")
+    if use_hip == "0" or (use_hip == "auto" and x.dtype != torch.float32):
+        return torch.ops.aten.convolution_backward(dy, x, _as(weight, x.dtype), None, *_ATEN_ARGS,
+                                                   [False, True, False])[1].to(weight.dtype)
     Fr, Cin, H, W = x.shape
     Cout = weight.shape[0]
     dev = x.device
     L = _native.lib()
-    dw = torch.empty_like(weight)
+    dw = torch.empty_like(weight)                       # fp32, whatever the activations' storage type
     with torch.cuda.device(dev):
         nbytes = int(L.rk_pw_wgrad_workspace_bytes(Fr, Cin, Cout, H * W))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        rc = L.rk_pw_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W, ws.data_ptr(), nbytes,
-                               torch.cuda.current_stream(dev).cuda_stream)
-    _native.check(rc, "rk_pw_wgrad_f32")
+        rc = getattr(L, "rk_pw_wgrad_" + _SFX[x.dtype])(
+            dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W, ws.data_ptr(), nbytes,
+            torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "rk_pw_wgrad")
     return dw
 
 
@@ -64,7 +78,7 @@ class _Conv1x1Func(torch.autograd.Function):
             y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
             _gemm(weight, x, y, Fr, Cin, Cout, H * W, True, residual)      # `+ residual` in the GEMM's epilogue
         else:
-            y = torch.ops.aten.convolution(x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+            y = torch.ops.aten.convolution(x, _as(weight, x.dtype), None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
             if residual is not None:
                 y.add_(residual)
         ctx.save_for_backward(x, weight)
@@ -76,6 +90,8 @@ class _Conv1x1Func(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.hip_gemm:
@@ -83,16 +99,17 @@ class _Conv1x1Func(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 _gemm(weight, dy, dx, Fr, weight.shape[0], Cin, H * W, False)     # W read as [K=Cout][M=Cin]
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, *_ATEN_ARGS, [True, False, False])[0]
+                dx = torch.ops.aten.convolution_backward(dy, x, _as(weight, x.dtype), None, *_ATEN_ARGS,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dy, x, weight)
         return dx, dw, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None)
 
 
-def _eligible(conv, x):
+def _eligible(conv, x, has_residual=False):
     """None: stock path; else whether forward / d(input) should use the HIP GEMM too."""
     mode = pointwise_mode()
-    if mode == "0" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+    if mode == "0" or not (x.is_cuda and x.dtype in _SFX and x.dim() == 4):
         return None
     if not (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None
@@ -104,12 +121,17 @@ def _eligible(conv, x):
         return None
     if mode == "all":
         return True
-    return P >= 3136 and K <= 128 and M <= 128           # measured win region of the GEMM (tools/pointwise_probe.py)
+    # measured win region of the GEMM (tools/pointwise_probe.py); with a residual to fuse, the 28x28 tie
+    # (77 vs 76 us) tips over: the epilogue add replaces a separate elementwise pass
+    if x.dtype == torch.bfloat16:                        # forward / d(input) win on the big planes only; the rest is stock
+        return True if (P >= 3136 and K <= 128 and M <= 128) else None
+    p_min = 784 if has_residual else 3136
+    return P >= p_min and K <= 128 and M <= 128
 
 
 def conv1x1(conv, x, residual=None):
     """`conv(x)` (`conv(x) + residual` when a residual is given) for a 1x1 nn.Conv2d module."""
-    hip_gemm = _eligible(conv, x)
+    hip_gemm = _eligible(conv, x, residual is not None)
     if hip_gemm is None or (residual is not None and not (residual.is_contiguous() and residual.dtype == x.dtype)):
         y = conv(x)
         if residual is not None:

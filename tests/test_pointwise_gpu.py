@@ -67,6 +67,37 @@ def test_fused_residual(monkeypatch, mode):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, float(b.abs().max())))
 
 
+@pytest.mark.parametrize("case", [(5, 54, 54, 8, 8), (2, 54, 108, 28, 28), (3, 216, 432, 6, 6)])
+def test_bf16_activations_fp32_weight(monkeypatch, case):
+    """bf16 storage (autocast): fp32 weight used as it is, fp32 MFMA arithmetic, outputs rounded once, d(weight)
+    in fp32 -- checked against conv2d in fp64 on the bf16-rounded activations."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    monkeypatch.setenv("RK_PW", "all")
+    monkeypatch.setenv("RK_PW_WGRAD", "1")          # the HIP d(weight) kernel (auto mode leaves bf16 to aten)
+    Fr, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(Fr, Cin, H, W, generator=g).bfloat16()
+    r = torch.randn(Fr, Cout, H, W, generator=g).bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    dy = torch.randn(Fr, Cout, H, W, generator=g).bfloat16()
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr) + r.double()
+    yr.backward(dy.double())
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xd = x.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv1x1(conv, xd, residual=r.cuda())
+    assert y.dtype == torch.bfloat16 and "Conv1x1Func" in type(y.grad_fn).__name__
+    y.backward(dy.cuda())
+    assert conv.weight.grad.dtype == torch.float32 and xd.grad.dtype == torch.bfloat16
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-2, atol=1e-2 * float(yr.abs().max()))
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=1e-2 * float(xr.grad.abs().max()))
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=2e-5 * float(wr.grad.abs().max()) * Cin ** 0.5)
+
+
 def test_ineligible_layers_take_the_stock_path(monkeypatch):
     from rubiksnet_amd.pointwise import conv1x1
 
