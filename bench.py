@@ -249,7 +249,7 @@ def main():
                 "algorithmic_bytes_per_step": bytes_step,
             },
             "clips_per_s": env.world_size * SHAPE[0] / t_step,
-            "frac_of_hbm_peak": both_gbs / HBM_PEAK_GBS,
+            "frac_of_hbm_peak": value / env.world_size / HBM_PEAK_GBS,   # per GPU, from the wall-clock value
             "roofline": {
                 "kernel": "rk3d backward (d(x) + d(shift) + finalize)", "bound": "hbm",
                 "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
