@@ -115,7 +115,11 @@ __global__ __launch_bounds__(kBlock) void k3d_forward_column(const T* __restrict
 }
 
 // ----------------------------------------------------------------------------------- backward
-template <typename T, bool WRITE_GX, int kM>
+// SINGLE: both spatial strides >= 2.  Then an input element has at most ONE gy tap -- (h+pH+fl'H+j) % sH == 0 holds
+// for one j of {0, 1} at most, likewise k -- and the reference's tree collapses, exactly (the other three taps
+// are zeros: 0*w and x+0 are exact), to Q = wj (v wk), QH = +-(v wk), QW = +-(wj v): one load per element and
+// plane instead of four predicated ones (the four stride-(1,2,2) layers of each network run here).
+template <typename T, bool WRITE_GX, int kM, bool SINGLE>
 __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restrict__ x, const T* __restrict__ shift,
                                                               const T* __restrict__ gy, T* __restrict__ gx,
                                                               T* __restrict__ part, CDims cd) {
@@ -142,8 +146,13 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
             const T* gc = gy + ((size_t)id.n * d.To * d.C + id.c) * HWo;
             T* oc = WRITE_GX ? gx + ((size_t)id.n * d.T * d.C + id.c) * HW : nullptr;
 
-            // per INPUT element: gy offsets of the 4 taps (row-major in the output plane), -1 = no such tap
-            int tap[kM][4], iidx[kM];
+            const T rT = fT.r, rH = fH.r, rW = fW.r;
+            T xa[kM], xb[kM], Qprev[kM];
+            T sT = 0, sH = 0, sW = 0;
+            int iidx[kM];
+            // per INPUT element: gy offsets of its taps (row-major in the output plane), -1 = no such tap
+            int tap[kM][SINGLE ? 1 : 4];
+            T wj[kM], wk[kM], sj[kM], sk[kM];                         // SINGLE: the tap's H / W weights and signs
 #pragma unroll
             for (int m = 0; m < kM; ++m) {
                 const int i = id.chunk * cd.E * kM + m * cd.E + e;
@@ -153,14 +162,18 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
                 const int r0 = unmap(h + d.pH + fH.fl, d.sH, d.Ho), r1 = unmap(h + d.pH + fH.fl + 1, d.sH, d.Ho);
                 const int c0 = unmap(w + d.pW + fW.fl, d.sW, d.Wo), c1 = unmap(w + d.pW + fW.fl + 1, d.sW, d.Wo);
                 const bool live = i < HW;
-                tap[m][0] = (live && r0 >= 0 && c0 >= 0) ? r0 * d.Wo + c0 : -1;
-                tap[m][1] = (live && r0 >= 0 && c1 >= 0) ? r0 * d.Wo + c1 : -1;
-                tap[m][2] = (live && r1 >= 0 && c0 >= 0) ? r1 * d.Wo + c0 : -1;
-                tap[m][3] = (live && r1 >= 0 && c1 >= 0) ? r1 * d.Wo + c1 : -1;
+                if (SINGLE) {
+                    const int r = r0 >= 0 ? r0 : r1, c = c0 >= 0 ? c0 : c1;       // at most one of each exists
+                    tap[m][0] = (live && r >= 0 && c >= 0) ? r * d.Wo + c : -1;
+                    wj[m] = r0 >= 0 ? 1 - rH : rH;  sj[m] = r0 >= 0 ? (T)1 : (T)-1;
+                    wk[m] = c0 >= 0 ? 1 - rW : rW;  sk[m] = c0 >= 0 ? (T)1 : (T)-1;
+                } else {
+                    tap[m][0] = (live && r0 >= 0 && c0 >= 0) ? r0 * d.Wo + c0 : -1;
+                    tap[m][SINGLE ? 0 : 1] = (live && r0 >= 0 && c1 >= 0) ? r0 * d.Wo + c1 : -1;
+                    tap[m][SINGLE ? 0 : 2] = (live && r1 >= 0 && c0 >= 0) ? r1 * d.Wo + c0 : -1;
+                    tap[m][SINGLE ? 0 : 3] = (live && r1 >= 0 && c1 >= 0) ? r1 * d.Wo + c1 : -1;
+                }
             }
-            const T rT = fT.r, rH = fH.r, rW = fW.r;
-            T xa[kM], xb[kM], Qprev[kM];
-            T sT = 0, sH = 0, sW = 0;
 #pragma unroll
             for (int m = 0; m < kM; ++m) {
                 xa[m] = 0; Qprev[m] = 0;
@@ -178,17 +191,27 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
                 const T* xn = xc + (has_next ? (size_t)(to + 2) * tsi : 0);
 #pragma unroll
                 for (int m = 0; m < kM; ++m) {
-                    T q00 = 0, q01 = 0, q10 = 0, q11 = 0;
-                    if (valid) {
-                        if (tap[m][0] >= 0) q00 = p[tap[m][0]];
-                        if (tap[m][1] >= 0) q01 = p[tap[m][1]];
-                        if (tap[m][2] >= 0) q10 = p[tap[m][2]];
-                        if (tap[m][3] >= 0) q11 = p[tap[m][3]];
+                    T Q, QH, QW;
+                    if (SINGLE) {
+                        T v = 0;
+                        if (valid && tap[m][0] >= 0) v = p[tap[m][0]];
+                        const T vk = v * wk[m];
+                        Q = wj[m] * vk;                                  // = the reference's tree with three zero taps
+                        QH = sj[m] * vk;
+                        QW = sk[m] * (wj[m] * v);
+                    } else {
+                        T q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+                        if (valid) {
+                            if (tap[m][0] >= 0) q00 = p[tap[m][0]];
+                            if (tap[m][SINGLE ? 0 : 1] >= 0) q01 = p[tap[m][SINGLE ? 0 : 1]];
+                            if (tap[m][SINGLE ? 0 : 2] >= 0) q10 = p[tap[m][SINGLE ? 0 : 2]];
+                            if (tap[m][SINGLE ? 0 : 3] >= 0) q11 = p[tap[m][SINGLE ? 0 : 3]];
+                        }
+                        const T la = q00 * (1 - rW) + q01 * rW, lb = q10 * (1 - rW) + q11 * rW;
+                        Q = (1 - rH) * la + rH * lb;                     // the reference's tree, contraction off
+                        QH = la - lb;
+                        QW = ((1 - rH) * q00 + rH * q10) - ((1 - rH) * q01 + rH * q11);
                     }
-                    const T la = q00 * (1 - rW) + q01 * rW, lb = q10 * (1 - rW) + q11 * rW;
-                    const T Q = (1 - rH) * la + rH * lb;                 // the reference's tree, contraction off
-                    const T QH = la - lb;
-                    const T QW = ((1 - rH) * q00 + rH * q10) - ((1 - rH) * q01 + rH * q11);
                     const T dx = xb[m] - xa[m];
                     const T mx = (1 - rT) * xb[m] + rT * xa[m];
                     sT += Q * dx;
@@ -258,10 +281,14 @@ template <typename T>
 inline int launch_backward(const T* x, const T* shift, const T* gy, T* gx, T* ws, const Dims3& d,
                            hipStream_t stream) {
     const CDims cd = make_cdims(d, d.H * d.W);
-#define RK_COL_BWD(GX, MM) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM>), dim3(grid_of(cd)), dim3(kBlock), 0, \
-                                              stream, x, shift, gy, gx, ws, cd)
-    if (gx) { if (cd.M == 1) RK_COL_BWD(true, 1); else RK_COL_BWD(true, 4); }
-    else { if (cd.M == 1) RK_COL_BWD(false, 1); else RK_COL_BWD(false, 4); }
+    static const bool single_off = [] { const char* e = getenv("RK_COL_SINGLE"); return e && e[0] == '0'; }();
+    const bool single = d.sH >= 2 && d.sW >= 2 && !single_off;
+#define RK_COL_BWD(GX, MM, SG) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG>), dim3(grid_of(cd)), dim3(kBlock), \
+                                                  0, stream, x, shift, gy, gx, ws, cd)
+#define RK_COL_SG(GX, MM) do { if (single) RK_COL_BWD(GX, MM, true); else RK_COL_BWD(GX, MM, false); } while (0)
+    if (gx) { if (cd.M == 1) RK_COL_SG(true, 1); else RK_COL_SG(true, 4); }
+    else { if (cd.M == 1) RK_COL_SG(false, 1); else RK_COL_SG(false, 4); }
+#undef RK_COL_SG
 #undef RK_COL_BWD
     return d.N * cd.nchunks;
 }
