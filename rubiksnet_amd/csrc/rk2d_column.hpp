@@ -1,0 +1,260 @@
+// rk2d_column.hpp -- RubiksShift2D "column" kernels: any stride / padding, any H x W, every storage type,
+// quantize off.  They take what the streaming kernels (rk2d_dma.hpp / rk2d_stage.hpp) do not: the stride-2
+// layers and the 14x14 / 7x7 planes (W % 4 != 0) of the -aq networks, which on the per-plane kernels of
+// rk2d_generic.hpp were 14 % of the Tiny-AQ bf16 train step (two passes for the backward, 4 predicated taps
+// with % and / per element, geometry recomputed for every plane).
+//
+// Same idea as rk3d_column.hpp without the T coupling: a group of E threads owns (channel, chunk of the plane)
+// and walks a group of frames, so the channel's shift, the per-element tap offsets and weights are computed
+// once; taps are per-element global loads served by L1/L2.
+//   forward : interp2d of the 4 taps (rubiks2d_kernels.cu:60-66, :94-146) -- bit-identical to the oracle.
+//   backward: d(x) + d(shift) in ONE pass, adjoint form on the input side with the negated shift (fl', r'):
+//             gx = interp2d of the gy taps that exist ((h+pH+fl'H+j) % sH == 0, rubiks2d_kernels.cu:298-300)
+//             -- the tree of K8, bit-identical -- and gH = sum x (la - lb), gW = sum x (colA - colB) from the same
+//             taps (la / lb: W-lerps of the two tap rows, colA / colB: H-lerps of the two tap columns).
+//             SINGLE (both strides >= 2): an input element has at most one tap and the tree collapses exactly
+//             to (v wj) wk.
+// Channels within 1e-7 of an integer shift (central-difference branch, :189-253) run the per-element reference
+// formulation of rk2d_generic.hpp for their frames.  Partials part[c][2][P], P = groups * chunks.
+#pragma once
+#include "rk2d_generic.hpp"
+
+namespace rk {
+namespace col2d {
+
+using namespace g2d;
+
+struct C2Dims {
+    Dims2 d;
+    int E, logE;          // threads per group (64 / 128 / 256)
+    int nchunks;          // chunks per plane (E * M elements each)
+    int M;                // elements per thread (1 or 4)
+    int FG, ngroups;      // frames per group, groups
+};
+
+struct Col2Id { int c, chunk, g; bool valid; };
+
+__device__ __forceinline__ Col2Id my_column2(const C2Dims& cd, int& e) {
+    const int sub = threadIdx.x >> cd.logE;
+    e = threadIdx.x & (cd.E - 1);
+    const long long id = (long long)blockIdx.x * (kBlock >> cd.logE) + sub;     // (g, c, chunk) flattened
+    Col2Id r;
+    r.valid = id < (long long)cd.ngroups * cd.d.C * cd.nchunks;
+    const long long q = r.valid ? id : 0;
+    r.chunk = (int)(q % cd.nchunks);
+    const long long col = q / cd.nchunks;
+    r.c = (int)(col % cd.d.C);
+    r.g = (int)(col / cd.d.C);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <typename T, int kM>
+__global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict__ x, const T* __restrict__ shift,
+                                                             T* __restrict__ y, C2Dims cd) {
+    using CT = typename Compute<T>::type;
+    const Dims2& d = cd.d;
+    int e;
+    const Col2Id id = my_column2(cd, e);
+    if (!id.valid) return;
+    const CT offH = ld(shift + id.c), offW = ld(shift + d.C + id.c);
+    const int iH = floor_fast(offH), iW = floor_fast(offW);
+    const CT rH = offH - (CT)iH, rW = offW - (CT)iW;
+    const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
+    const size_t fsi = (size_t)d.C * HW, fso = (size_t)d.C * HWo;
+    const int f0 = id.g * cd.FG, nf = min(cd.FG, d.N - f0);
+    const T* xc = x + ((size_t)f0 * d.C + id.c) * HW;
+    T* yc = y + ((size_t)f0 * d.C + id.c) * HWo;
+
+    int o00[kM], oidx[kM];
+    unsigned mask[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) {
+        const int i = id.chunk * cd.E * kM + m * cd.E + e;
+        oidx[m] = i < HWo ? i : -1;
+        const int ii = i < HWo ? i : 0;
+        const int ho = ii / d.Wo, wo = ii - ho * d.Wo;
+        const int h0 = ho * d.sH - d.pH + iH, w0 = wo * d.sW - d.pW + iW;
+        const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h0 + 1 >= 0 && h0 + 1 < d.H;
+        const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w0 + 1 >= 0 && w0 + 1 < d.W;
+        o00[m] = h0 * d.W + w0;
+        mask[m] = (i < HWo) ? ((mh0 && mw0 ? 1u : 0u) | (mh0 && mw1 ? 2u : 0u) | (mh1 && mw0 ? 4u : 0u) |
+                               (mh1 && mw1 ? 8u : 0u)) : 0u;
+    }
+    for (int k = 0; k < nf; ++k) {
+        const T* p = xc + (size_t)k * fsi;
+        T* out = yc + (size_t)k * fso;
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+            CT p00 = 0, p01 = 0, p10 = 0, p11 = 0;
+            const unsigned mk = mask[m];
+            if (mk & 1u) p00 = ld(p + o00[m]);
+            if (mk & 2u) p01 = ld(p + o00[m] + 1);
+            if (mk & 4u) p10 = ld(p + o00[m] + d.W);
+            if (mk & 8u) p11 = ld(p + o00[m] + d.W + 1);
+            if (oidx[m] >= 0) st(out + oidx[m], interp2d(p00, p01, p10, p11, rH, rW));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- backward
+template <typename T, int kM, bool SINGLE>
+__global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restrict__ gy, const T* __restrict__ x,
+                                                              const T* __restrict__ shift, T* __restrict__ gx,
+                                                              typename Compute<T>::type* __restrict__ part,
+                                                              C2Dims cd) {
+    using CT = typename Compute<T>::type;
+    __shared__ CT red[2][kBlock / kWave];
+    const Dims2& d = cd.d;
+    int e;
+    const Col2Id id = my_column2(cd, e);
+    CT accH = 0, accW = 0;
+    if (id.valid) {
+        const CT s0 = ld(shift + id.c), s1 = ld(shift + d.C + id.c);
+        const int f0 = id.g * cd.FG, nf = min(cd.FG, d.N - f0);
+        const CT u0 = s0 - (CT)floor_fast(s0), u1 = s1 - (CT)floor_fast(s1);
+        if (u0 < (CT)1e-7f || u1 < (CT)1e-7f) {
+            // central-difference branch: the reference's per-element formulation; chunk 0 does the whole planes
+            if (id.chunk == 0)
+                for (int k = 0; k < nf; ++k) {
+                    backward_input_plane2<T, false>(gy, shift, gx, d, f0 + k, id.c, e, cd.E);
+                    shift_grad_plane2<T>(gy, x, shift, d, f0 + k, id.c, e, cd.E, accH, accW);
+                }
+        } else {
+            const CT nH = -s0, nW = -s1;
+            const int flH = floor_fast(nH), flW = floor_fast(nW);
+            const CT rH = nH - (CT)flH, rW = nW - (CT)flW;                     // fl', r'
+            const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
+            const size_t fsi = (size_t)d.C * HW, fso = (size_t)d.C * HWo;
+            const T* xc = x + ((size_t)f0 * d.C + id.c) * HW;
+            const T* gc = gy + ((size_t)f0 * d.C + id.c) * HWo;
+            T* oc = gx + ((size_t)f0 * d.C + id.c) * HW;
+
+            int iidx[kM], tap[kM][SINGLE ? 1 : 4];
+            CT wj[kM], wk[kM], sj[kM], sk[kM];                                 // SINGLE: the tap's weights and signs
+#pragma unroll
+            for (int m = 0; m < kM; ++m) {
+                const int i = id.chunk * cd.E * kM + m * cd.E + e;
+                const bool live = i < HW;
+                iidx[m] = live ? i : -1;
+                const int ii = live ? i : 0;
+                const int h = ii / d.W, w = ii - h * d.W;
+                const int r0 = unmap2(h + d.pH + flH, d.sH, d.Ho), r1 = unmap2(h + d.pH + flH + 1, d.sH, d.Ho);
+                const int c0 = unmap2(w + d.pW + flW, d.sW, d.Wo), c1 = unmap2(w + d.pW + flW + 1, d.sW, d.Wo);
+                if (SINGLE) {
+                    const int r = r0 >= 0 ? r0 : r1, c = c0 >= 0 ? c0 : c1;   // at most one of each exists
+                    tap[m][0] = (live && r >= 0 && c >= 0) ? r * d.Wo + c : -1;
+                    wj[m] = r0 >= 0 ? 1 - rH : rH;  sj[m] = r0 >= 0 ? (CT)1 : (CT)-1;
+                    wk[m] = c0 >= 0 ? 1 - rW : rW;  sk[m] = c0 >= 0 ? (CT)1 : (CT)-1;
+                } else {
+                    tap[m][0] = (live && r0 >= 0 && c0 >= 0) ? r0 * d.Wo + c0 : -1;
+                    tap[m][SINGLE ? 0 : 1] = (live && r0 >= 0 && c1 >= 0) ? r0 * d.Wo + c1 : -1;
+                    tap[m][SINGLE ? 0 : 2] = (live && r1 >= 0 && c0 >= 0) ? r1 * d.Wo + c0 : -1;
+                    tap[m][SINGLE ? 0 : 3] = (live && r1 >= 0 && c1 >= 0) ? r1 * d.Wo + c1 : -1;
+                }
+            }
+            CT sH = 0, sW = 0;
+            for (int k = 0; k < nf; ++k) {
+                const T* p = gc + (size_t)k * fso;
+                const T* xp = xc + (size_t)k * fsi;
+                T* out = oc + (size_t)k * fsi;
+#pragma unroll
+                for (int m = 0; m < kM; ++m) {
+                    const CT xv = iidx[m] >= 0 ? ld(xp + iidx[m]) : (CT)0;
+                    CT Q, QH, QW;
+                    if (SINGLE) {
+                        CT v = 0;
+                        if (tap[m][0] >= 0) v = ld(p + tap[m][0]);
+                        const CT vj = v * wj[m];
+                        Q = vj * wk[m];                                      // = K8's interp2d with three zero taps
+                        QH = sj[m] * (v * wk[m]);
+                        QW = sk[m] * vj;
+                    } else {
+                        CT q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+                        if (tap[m][0] >= 0) q00 = ld(p + tap[m][0]);
+                        if (tap[m][SINGLE ? 0 : 1] >= 0) q01 = ld(p + tap[m][SINGLE ? 0 : 1]);
+                        if (tap[m][SINGLE ? 0 : 2] >= 0) q10 = ld(p + tap[m][SINGLE ? 0 : 2]);
+                        if (tap[m][SINGLE ? 0 : 3] >= 0) q11 = ld(p + tap[m][SINGLE ? 0 : 3]);
+                        Q = interp2d(q00, q01, q10, q11, rH, rW);            // K8's tree, contraction off
+                        QH = (q00 * (1 - rW) + q01 * rW) - (q10 * (1 - rW) + q11 * rW);
+                        QW = ((1 - rH) * q00 + rH * q10) - ((1 - rH) * q01 + rH * q11);
+                    }
+                    sH += QH * xv;
+                    sW += QW * xv;
+                    if (iidx[m] >= 0) st(out + iidx[m], Q);
+                }
+            }
+            accH = sH; accW = sW;
+        }
+    }
+    accH = group_sum(accH, cd.E, red[0]);
+    accW = group_sum(accW, cd.E, red[1]);
+    if (id.valid && e == 0) {
+        const int P = cd.ngroups * cd.nchunks;
+        CT* o = part + (size_t)id.c * 2 * P + (size_t)id.g * cd.nchunks + id.chunk;
+        o[0] = accH;
+        o[P] = accW;
+    }
+}
+
+// ----------------------------------------------------------------------------------- host side
+inline bool supported(int quantize) {
+    static const bool off = [] { const char* e = getenv("RK_COLUMN2D"); return e && e[0] == '0'; }();
+    static const bool force_generic = [] { const char* e = getenv("RK_FORCE_GENERIC"); return e && e[0] == '1'; }();
+    return !off && !force_generic && !quantize;
+}
+
+// plane_elems: the plane the threads index (output plane for forward, input plane for backward)
+inline C2Dims make_c2dims(const Dims2& d, int plane_elems) {
+    C2Dims cd;
+    cd.d = d;
+    if (plane_elems <= kWave) { cd.E = kWave; cd.M = 1; }
+    else if (plane_elems <= kBlock) { cd.E = kBlock; cd.M = 1; }
+    else { cd.E = kBlock; cd.M = 4; }
+    cd.logE = (cd.E == 64) ? 6 : (cd.E == 128 ? 7 : 8);
+    cd.nchunks = (plane_elems + cd.E * cd.M - 1) / (cd.E * cd.M);
+    // frames per group: enough groups to fill the chip (>= ~4096 thread groups), at least 4 frames each
+    static const int fg_env = [] { const char* e = getenv("RK_COL2D_FG"); return e ? atoi(e) : 0; }();
+    int fg = 16;
+    while (fg > 4 && (long long)((d.N + fg - 1) / fg) * d.C * cd.nchunks * cd.E < 4096LL * kBlock) fg /= 2;
+    if (fg_env > 0) fg = fg_env;
+    cd.FG = fg < d.N ? fg : d.N;
+    cd.ngroups = (d.N + cd.FG - 1) / cd.FG;
+    return cd;
+}
+inline unsigned grid_of(const C2Dims& cd) {
+    const long long groups = (long long)cd.ngroups * cd.d.C * cd.nchunks;
+    const int per_block = kBlock / cd.E;
+    return (unsigned)((groups + per_block - 1) / per_block);
+}
+
+template <typename T>
+inline void launch_forward(const T* x, const T* shift, T* y, const Dims2& d, hipStream_t stream) {
+    const C2Dims cd = make_c2dims(d, d.Ho * d.Wo);
+    if (cd.M == 1)
+        hipLaunchKernelGGL((k2d_forward_column<T, 1>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+    else
+        hipLaunchKernelGGL((k2d_forward_column<T, 4>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+}
+
+inline int backward_partials(const Dims2& d) {
+    const C2Dims cd = make_c2dims(d, d.H * d.W);
+    return cd.ngroups * cd.nchunks;
+}
+
+// d(x) + d(shift) partials into ws[C][2][P]; returns P
+template <typename T>
+inline int launch_backward(const T* gy, const T* x, const T* shift, T* gx, typename Compute<T>::type* ws,
+                           const Dims2& d, hipStream_t stream) {
+    const C2Dims cd = make_c2dims(d, d.H * d.W);
+    const bool single = d.sH >= 2 && d.sW >= 2;
+#define RK_C2_BWD(MM, SG) hipLaunchKernelGGL((k2d_backward_column<T, MM, SG>), dim3(grid_of(cd)), dim3(kBlock), 0, \
+                                             stream, gy, x, shift, gx, ws, cd)
+    if (cd.M == 1) { if (single) RK_C2_BWD(1, true); else RK_C2_BWD(1, false); }
+    else { if (single) RK_C2_BWD(4, true); else RK_C2_BWD(4, false); }
+#undef RK_C2_BWD
+    return cd.ngroups * cd.nchunks;
+}
+
+}  // namespace col2d
+}  // namespace rk

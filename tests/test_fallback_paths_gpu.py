@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("env", [
     {"RK_DMA": "0", "RK_DMA_BWD": "0"},            # register-staged streaming kernels (rk3d_stream.hpp)
-    {"RK_DMA": "0", "RK_DMA_BWD": "0", "RK_COLUMN": "0", "RK_DMA2D": "0"},   # + no column / 2-D streaming kernels
+    {"RK_DMA": "0", "RK_DMA_BWD": "0", "RK_COLUMN": "0", "RK_DMA2D": "0", "RK_COLUMN2D": "0"},   # + no column / 2-D streaming kernels
     {"RK_FORCE_GENERIC": "1"},                     # per-plane generic kernels only
 ], ids=["register-staged", "no-column-no-2d-streaming", "generic-only"])
 def test_parity_suite_on_fallback_kernels(env):
