@@ -15,6 +15,7 @@
 // is staged through LDS in [k][m] order (conflict-free fragment reads), K in chunks of 16, double buffered, one
 // barrier per chunk.  fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain
 // (cdna_hip_programming.md, "FP32-input MFMA") -- same arithmetic class as the MIOpen / rocBLAS fp32 kernels.
+#include <type_traits>
 #include "rk_common.hpp"
 
 namespace rk {
@@ -299,6 +300,134 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// d(weight) for bf16 activations on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  The reduction
+// index (pixels) is the contiguous one in NCHW, which is exactly what the bf16 fragments want: lane (i, g) holds
+// 8 consecutive k = pixels of row i, a 16-byte read.  Same decomposition, staging and reductions as k_pw_wgrad;
+// tiles stay bf16 in LDS (64 rows x 32 pixels, row stride 80 B: the ds_read_b128 fragment reads are
+// conflict-free), 8 MFMAs per 32-pixel tile instead of 64.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kRowB = 80;                 // bytes per tile row (64 data + 16 pad)
+
+__device__ __forceinline__ void wgb_fetch(const __hip_bfloat16* __restrict__ T, int rows, int r0, int P, long long n0,
+                                          long long nend, uint2 (&v)[8], int Cdim) {
+    const int lane = threadIdx.x & 63;
+    const long long n = n0 + 4 * (lane & 7);
+    const bool nok = n < nend;
+    const long long nc = nok ? n : 0;
+    const int f = (int)(nc / P), p = (int)(nc - (long long)f * P);
+    const __hip_bfloat16* base = T + ((size_t)f * Cdim) * P + p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 8 * j + (lane >> 3);
+        v[j] = (nok && r < rows) ? *reinterpret_cast<const uint2*>(base + (size_t)r * P) : make_uint2(0u, 0u);
+    }
+}
+__device__ __forceinline__ void wgb_deposit(char* tile, const uint2 (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<uint2*>(tile + (8 * j + (lane >> 3)) * kRowB + 8 * (lane & 7)) = v[j];
+}
+
+__global__ __launch_bounds__(kBlock) void k_pw_wgrad_bf16(const __hip_bfloat16* __restrict__ dY,
+                                                          const __hip_bfloat16* __restrict__ X,
+                                                          float* __restrict__ ws, WgDims d) {
+    __shared__ __attribute__((aligned(16))) char tiles[4][2][64 * kRowB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int nmk = d.MB * d.KB;
+    const int bpw = nmk < 4 ? nmk : 4;
+    const int sub = 4 / bpw;
+    const int groups = (nmk + bpw - 1) / bpw;
+    const int chunk = blockIdx.x / groups, grp = blockIdx.x - chunk * groups;
+    const int blk = wave % bpw, subc = wave / bpw;
+    const int mk = grp * bpw + blk;
+    const bool live = mk < nmk && subc < sub;
+    const int mkc = live ? mk : 0;
+    const int mb = mkc / d.KB, kb = mkc - mb * d.KB;
+    const int per = d.chunk / sub;
+    const long long n0 = (long long)chunk * d.chunk + (long long)subc * per;
+    long long nend = n0 + per;
+    nend = nend < d.ntot ? nend : d.ntot;
+    if (!live) nend = n0;
+    char* ta = tiles[wave][0];
+    char* tb = tiles[wave][1];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    uint2 va[8], vb[8];
+    wgb_fetch(dY, d.M, 64 * mb, d.P, n0, nend, va, d.M);
+    wgb_fetch(X, d.K, 64 * kb, d.P, n0, nend, vb, d.K);
+    const int steps = per / kNB;
+#pragma nounroll
+    for (int it = 0; it < steps; ++it) {
+        __syncthreads();
+        wgb_deposit(ta, va);
+        wgb_deposit(tb, vb);
+        __syncthreads();
+        const long long nn = n0 + (long long)(it + 1) * kNB;
+        wgb_fetch(dY, d.M, 64 * mb, d.P, nn, nend, va, d.M);
+        wgb_fetch(X, d.K, 64 * kb, d.P, nn, nend, vb, d.K);
+#pragma unroll
+        for (int s = 0; s < kNB / 16; ++s) {                        // 16 pixels per MFMA
+            const int off = 32 * s + 16 * kh;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ta + l31 * kRowB + off);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ta + (32 + l31) * kRowB + off);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(tb + l31 * kRowB + off);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(tb + (32 + l31) * kRowB + off);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // sum the sub-chunk waves of each block into its subc == 0 wave, one sub-chunk at a time through the tile
+    // memory (bpw blocks x 16 KB fit the 40 KB of tiles only for one sub-chunk index at once)
+    __syncthreads();
+    for (int o = 1; o < sub; ++o) {
+        float* buf = reinterpret_cast<float*>(&tiles[0][0][0]) + blk * (64 * 64);
+        if (subc == o) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (subc == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += buf[((a * 2 + b) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (live && subc == 0) {
+        float* out = ws + (size_t)chunk * d.M * d.K;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = 64 * mb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int gk = 64 * kb + 32 * b + l31;
+                    if (gm < d.M && gk < d.K) out[(size_t)gm * d.K + gk] = acc[a][b][r];
+                }
+    }
+}
+
 // out[part][i] = sum of in[c][i] over the chunks c of this part (c = part, part + parts, ...): coalesced in i,
 // fixed order.  Launched twice: S chunks -> kRed parts -> 1.
 constexpr int kRed = 32;
@@ -387,7 +516,13 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
     float* part2 = part + (size_t)d.S * M * K;
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
+    if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+        if (bf16_mfma) hipLaunchKernelGGL(k_pw_wgrad_bf16, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+        else hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    } else {
+        hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    }
     if (d.S > kRed) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
