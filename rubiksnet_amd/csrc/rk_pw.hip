@@ -176,16 +176,29 @@ struct WgDims {
     int chunk;                           // pixels per chunk (multiple of kNB)
 };
 
+// this lane's position in the pixel stream: n = (f, p); advanced 32 pixels per tile without dividing
+struct PixCursor {
+    long long n;
+    int f, p;
+    __device__ __forceinline__ void init(long long n0, int P) {
+        n = n0 + 4 * (int)(threadIdx.x & 7);
+        f = (int)(n / P);
+        p = (int)(n - (long long)f * P);
+    }
+    __device__ __forceinline__ void advance(int P) {
+        n += kNB;
+        p += kNB;
+        while (p >= P) { p -= P; ++f; }
+    }
+};
+
 // one lane's share of a 64 x 32 tile: 8 float4 (row = 8 j + lane / 8, pixels 4 (lane % 8) ..+3)
 template <typename TT>
-__device__ __forceinline__ void wg_fetch(const TT* __restrict__ T, int rows, int r0, int P, long long n0,
-                                         long long nend, int Ftot, float4 (&v)[8], int Cdim) {
+__device__ __forceinline__ void wg_fetch(const TT* __restrict__ T, int rows, int r0, int P, const PixCursor& c,
+                                         long long nend, float4 (&v)[8], int Cdim) {
     const int lane = threadIdx.x & 63;
-    const long long n = n0 + 4 * (lane & 7);
-    const bool nok = n < nend;
-    const long long nc = nok ? n : 0;
-    const int f = (int)(nc / P), p = (int)(nc - (long long)f * P);
-    const TT* base = T + ((size_t)f * Cdim) * P + p;
+    const bool nok = c.n < nend;
+    const TT* base = T + (nok ? ((size_t)c.f * Cdim) * P + c.p : 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = r0 + 8 * j + (lane >> 3);
@@ -238,8 +251,10 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 va[8], vb[8];
-    wg_fetch(dY, d.M, 64 * mb, d.P, n0, nend, d.F, va, d.M);
-    wg_fetch(X, d.K, 64 * kb, d.P, n0, nend, d.F, vb, d.K);
+    PixCursor cur;
+    cur.init(n0, d.P);
+    wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);
+    wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
     const int steps = per / kNB;                                // same for every wave: barriers stay uniform
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
@@ -247,9 +262,9 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
         wg_deposit(ta, va);
         wg_deposit(tb, vb);
         __syncthreads();
-        const long long nn = n0 + (long long)(it + 1) * kNB;
-        wg_fetch(dY, d.M, 64 * mb, d.P, nn, nend, d.F, va, d.M);       // next tile, in flight during the MFMAs
-        wg_fetch(X, d.K, 64 * kb, d.P, nn, nend, d.F, vb, d.K);
+        cur.advance(d.P);
+        wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);           // next tile, in flight during the MFMAs
+        wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
 #pragma unroll
         for (int s = 0; s < kNB / 2; ++s) {
             const float a0 = ta[tile_at(l31, 2 * s + kh)], a1 = ta[tile_at(32 + l31, 2 * s + kh)];
@@ -310,14 +325,11 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kRowB = 80;                 // bytes per tile row (64 data + 16 pad)
 
-__device__ __forceinline__ void wgb_fetch(const __hip_bfloat16* __restrict__ T, int rows, int r0, int P, long long n0,
-                                          long long nend, uint2 (&v)[8], int Cdim) {
+__device__ __forceinline__ void wgb_fetch(const __hip_bfloat16* __restrict__ T, int rows, int r0, int P,
+                                          const PixCursor& c, long long nend, uint2 (&v)[8], int Cdim) {
     const int lane = threadIdx.x & 63;
-    const long long n = n0 + 4 * (lane & 7);
-    const bool nok = n < nend;
-    const long long nc = nok ? n : 0;
-    const int f = (int)(nc / P), p = (int)(nc - (long long)f * P);
-    const __hip_bfloat16* base = T + ((size_t)f * Cdim) * P + p;
+    const bool nok = c.n < nend;
+    const __hip_bfloat16* base = T + (nok ? ((size_t)c.f * Cdim) * P + c.p : 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = r0 + 8 * j + (lane >> 3);
@@ -363,19 +375,18 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_bf16(const __hip_bfloat16* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    uint2 va[8], vb[8];
-    wgb_fetch(dY, d.M, 64 * mb, d.P, n0, nend, va, d.M);
-    wgb_fetch(X, d.K, 64 * kb, d.P, n0, nend, vb, d.K);
+    // two tiles in flight (registers): with 8 MFMAs per tile the compute phase is far too short to cover a
+    // global-load round trip, so the loop is unrolled by two over two register sets
+    uint2 va0[8], vb0[8], va1[8], vb1[8];
+    PixCursor cur;
+    cur.init(n0, d.P);
+    wgb_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va0, d.M);
+    wgb_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb0, d.K);
+    cur.advance(d.P);
+    wgb_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va1, d.M);
+    wgb_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb1, d.K);
     const int steps = per / kNB;
-#pragma nounroll
-    for (int it = 0; it < steps; ++it) {
-        __syncthreads();
-        wgb_deposit(ta, va);
-        wgb_deposit(tb, vb);
-        __syncthreads();
-        const long long nn = n0 + (long long)(it + 1) * kNB;
-        wgb_fetch(dY, d.M, 64 * mb, d.P, nn, nend, va, d.M);
-        wgb_fetch(X, d.K, 64 * kb, d.P, nn, nend, vb, d.K);
+    auto consume = [&]() {
 #pragma unroll
         for (int s = 0; s < kNB / 16; ++s) {                        // 16 pixels per MFMA
             const int off = 32 * s + 16 * kh;
@@ -388,6 +399,25 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_bf16(const __hip_bfloat16* 
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
+    };
+#pragma nounroll
+    for (int it = 0; it < steps; it += 2) {                        // (tiles past the range are zeros)
+        __syncthreads();
+        wgb_deposit(ta, va0);
+        wgb_deposit(tb, vb0);
+        __syncthreads();
+        cur.advance(d.P);
+        wgb_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va0, d.M);      // tile it + 2
+        wgb_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb0, d.K);
+        consume();
+        __syncthreads();
+        wgb_deposit(ta, va1);
+        wgb_deposit(tb, vb1);
+        __syncthreads();
+        cur.advance(d.P);
+        wgb_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va1, d.M);      // tile it + 3
+        wgb_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb1, d.K);
+        consume();
     }
     // sum the sub-chunk waves of each block into its subc == 0 wave, one sub-chunk at a time through the tile
     // memory (bpw blocks x 16 KB fit the 40 KB of tiles only for one sub-chunk index at once)

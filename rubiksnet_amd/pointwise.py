@@ -4,8 +4,9 @@
 its weight, its state-dict key stay what they are.  Activations may be fp32 or bf16 (autocast: the fp32 weight is
 used as it is and d(weight) comes out in fp32 -- no casts; arithmetic is fp32 MFMA either way).  For GPU tensors
 with H*W % 4 == 0 and even channel
-counts, d(weight) always runs on the HIP kernel (2.6x / 2.3x / 2.0x / 1.25x MIOpen's at 56x56 / 54->108 / 28x28 /
-14x14: MIOpen's NHWC implicit GEMM needs two layout transposes), and forward / d(input) do where they win -- the
+counts, d(weight) always runs on the HIP kernels (fp32: 2.6x / 2.3x / 2.0x / 1.25x MIOpen's at 56x56 / 54->108 /
+28x28 / 14x14; bf16, on the bf16 MFMA: 2.4x / 3.2x / 3.9x / 1.7x: MIOpen's NHWC implicit GEMM needs two layout
+transposes), and forward / d(input) do where they win -- the
 memory-bound 112x112 / 56x56 stages; elsewhere they stay on aten (MIOpen).  Other dtypes, 7x7 planes, strided
 shortcuts, CPU tensors: `conv(x)`.  `RK_PW=0` disables the HIP path, `RK_PW=all` forces the HIP GEMM wherever
 the kernel's constraints allow.
@@ -42,10 +43,9 @@ def _as(weight, dtype):
 
 
 def _wgrad(dy, x, weight):
-    # bf16 activations: MIOpen's d(weight) is the faster one (133 vs 172 us at [256,54->54,56x56]); fp32: the HIP
-    # kernel (123 vs 319 us)
-    use_hip = os.environ.get("RK_PW_WGRAD", "auto")
-    if use_hip == "0" or (use_hip == "auto" and x.dtype != torch.float32):
+    # the HIP kernels win on every probed shape: fp32 113 vs 295 us, bf16 (bf16 MFMA) 55 vs 133 us at
+    # [256,54->54,56x56] -- MIOpen's d(weight) needs two layout transposes
+    if os.environ.get("RK_PW_WGRAD", "1") == "0":
         return torch.ops.aten.convolution_backward(dy, x, _as(weight, x.dtype), None, *_ATEN_ARGS,
                                                    [False, True, False])[1].to(weight.dtype)
     Fr, Cin, H, W = x.shape
@@ -123,8 +123,8 @@ def _eligible(conv, x, has_residual=False):
         return True
     # measured win region of the GEMM (tools/pointwise_probe.py); with a residual to fuse, the 28x28 tie
     # (77 vs 76 us) tips over: the epilogue add replaces a separate elementwise pass
-    if x.dtype == torch.bfloat16:                        # forward / d(input) win on the big planes only; the rest is stock
-        return True if (P >= 3136 and K <= 128 and M <= 128) else None
+    if x.dtype == torch.bfloat16:                        # forward / d(input) win on the big planes only
+        return P >= 3136 and K <= 128 and M <= 128
     p_min = 784 if has_residual else 3136
     return P >= p_min and K <= 128 and M <= 128
 

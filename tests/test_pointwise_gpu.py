@@ -74,7 +74,6 @@ def test_bf16_activations_fp32_weight(monkeypatch, case):
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", "all")
-    monkeypatch.setenv("RK_PW_WGRAD", "1")          # the HIP d(weight) kernel (auto mode leaves bf16 to aten)
     Fr, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(Fr, Cin, H, W, generator=g).bfloat16()
