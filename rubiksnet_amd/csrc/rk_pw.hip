@@ -22,6 +22,7 @@ namespace rk {
 namespace pw {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // 4 consecutive pixels of the streamed tensors: fp32 or bf16 storage, fp32 arithmetic either way (activations
 // under bf16 autocast; the weights and d(weight) stay fp32, so the autocast casts of the weight disappear)
@@ -156,6 +157,144 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Forward / d(input) for bf16 activations on the bf16 MFMA.  Here the reduction index (channels) is the
+// STRIDED one, and a bf16 fragment wants 8 consecutive k per lane, so the streamed operand is transposed on
+// its way through LDS: each wave loads its 16-channel x 128-pixel chunk as 8-byte cells along the pixels
+// (coalesced) and writes it pixel-major -- row rho(4 j + e) = 32 e + j, 16 channels = 32 B + 16 B pad -- so that
+// the fragment of column block q, lane (j, g) is ONE aligned 16-byte read of row 32 q + j (conflict-free at
+// the 48-byte row stride), while the lane's 4 results of a row are still 4 consecutive pixels (8-byte
+// store).  The small operand is rounded to bf16 as it is staged ([m][16 k], same row format): under autocast
+// that is the cast torch would have made.  8 MFMAs per 16-channel chunk per wave instead of 64 at fp32.
+constexpr int kBC = 16;                   // channels per chunk = K of one bf16 MFMA
+constexpr int kRowT = 48;                 // bytes per pixel row / per A row (32 data + 16 pad)
+
+template <int WM, bool A_MK>
+__global__ __launch_bounds__(kBlock, (WM == 4 ? 1 : 2)) void k_pw_gemm_bf16(const float* __restrict__ A,
+                                                            const __hip_bfloat16* __restrict__ X,
+                                                            const __hip_bfloat16* __restrict__ R,
+                                                            __hip_bfloat16* __restrict__ Y, PwDims d) {
+    constexpr int MT = 64 * WM, WN = 4 / WM;
+    __shared__ __attribute__((aligned(16))) char As[2][MT * kRowT];
+    __shared__ __attribute__((aligned(16))) char Xs[WN][2][128 * kRowT];   // one tile per column group, shared by its WM waves
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * MT;
+    const long long cg = ((long long)blockIdx.x * WN + wn) * 128 + 4 * l31;
+    const bool valid = cg < d.ntot;
+    const long long cgc = valid ? cg : 0;
+    const int f = (int)(cgc / d.P), p = (int)(cgc - (long long)f * d.P);
+    const __hip_bfloat16* xp = X + ((size_t)f * d.K) * d.P + p;
+    __hip_bfloat16* yp = Y + ((size_t)f * d.M) * d.P + p;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
+
+    // this lane's share of a chunk of X: channels k0 + 2 s + kh for the s = wm, wm + WM, ... of this wave (the WM
+    // waves of a column group split the 8 channel pairs), pixels 4 l31 .. + 3
+    constexpr int kXS = kBC / 2 / WM;
+    auto fetch_x = [&](int k0, uint2 (&v)[kXS]) {
+#pragma unroll
+        for (int t = 0; t < kXS; ++t) {
+            const int k = k0 + 2 * (wm + WM * t) + kh;
+            v[t] = (valid && k < d.K) ? *reinterpret_cast<const uint2*>(xp + (size_t)k * d.P) : make_uint2(0u, 0u);
+        }
+    };
+    auto deposit_x = [&](char* tile, const uint2 (&v)[kXS]) {
+#pragma unroll
+        for (int t = 0; t < kXS; ++t) {
+            const int s = wm + WM * t;
+            char* q = tile + l31 * kRowT + 2 * (2 * s + kh);                     // row 32 e + j, channel 2 s + kh
+            *reinterpret_cast<unsigned short*>(q) = (unsigned short)(v[t].x & 0xffffu);
+            *reinterpret_cast<unsigned short*>(q + 32 * kRowT) = (unsigned short)(v[t].x >> 16);
+            *reinterpret_cast<unsigned short*>(q + 64 * kRowT) = (unsigned short)(v[t].y & 0xffffu);
+            *reinterpret_cast<unsigned short*>(q + 96 * kRowT) = (unsigned short)(v[t].y >> 16);
+        }
+    };
+    // the A chunk: MT x 16, one element per (thread, i)
+    constexpr int kPerA = MT * kBC / kBlock;
+    // element e of a chunk <-> (m, kk): along the operand's contiguous index, so that the (L2-resident) reads coalesce
+    auto a_elem = [&](int e, int& m, int& kk) {
+        if (A_MK) { m = e / kBC; kk = e - m * kBC; }
+        else { kk = e / MT; m = e - kk * MT; }
+    };
+    auto fetch_a = [&](int k0, float (&v)[kPerA]) {
+#pragma unroll
+        for (int i = 0; i < kPerA; ++i) {
+            int m, kk;
+            a_elem(threadIdx.x + kBlock * i, m, kk);
+            const int gk = k0 + kk, gm = m0 + m;
+            const bool ok = gk < d.K && gm < d.M;
+            const size_t idx = A_MK ? (size_t)gm * d.K + gk : (size_t)gk * d.M + gm;
+            v[i] = ok ? A[ok ? idx : 0] : 0.f;
+        }
+    };
+    auto deposit_a = [&](char* as, const float (&v)[kPerA]) {
+#pragma unroll
+        for (int i = 0; i < kPerA; ++i) {
+            int m, kk;
+            a_elem(threadIdx.x + kBlock * i, m, kk);
+            *reinterpret_cast<unsigned short*>(as + m * kRowT + 2 * kk) =
+                __builtin_bit_cast(unsigned short, __float2bfloat16(v[i]));
+        }
+    };
+
+    uint2 xv[kXS];
+    float av[kPerA];
+    fetch_x(0, xv);
+    fetch_a(0, av);
+    deposit_x(Xs[wn][0], xv);
+    deposit_a(As[0], av);
+    const int nchunks = (d.K + kBC - 1) / kBC;
+#pragma nounroll
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                                   // chunk c is in buffers c & 1; the others are free
+        const bool more = c + 1 < nchunks;
+        if (more) {
+            fetch_x((c + 1) * kBC, xv);
+            fetch_a((c + 1) * kBC, av);
+        }
+        const char* xt = Xs[wn][c & 1] + l31 * kRowT + 16 * kh;
+        const char* at = As[c & 1] + (wm * 64 + l31) * kRowT + 16 * kh;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(at);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(at + 32 * kRowT);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x8 bq = *reinterpret_cast<const bf16x8*>(xt + 32 * q * kRowT);
+            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq, acc[0][q], 0, 0, 0);
+            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[1][q], 0, 0, 0);
+        }
+        if (more) {
+            deposit_x(Xs[wn][(c + 1) & 1], xv);
+            deposit_a(As[(c + 1) & 1], av);
+        }
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (gm < d.M) {
+                    float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                    if (R) {
+                        const float4 t = Px4<__hip_bfloat16>::widen(
+                            Px4<__hip_bfloat16>::load(R + (yp - Y) + (size_t)gm * d.P));
+                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+                    }
+                    Px4<__hip_bfloat16>::store(yp + (size_t)gm * d.P, o);
+                }
+            }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // d(weight):  dW[m][k] = sum over pixels n = (f, p) of dY[f][m][p] * X[f][k][p].
@@ -322,7 +461,6 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
 // 8 consecutive k = pixels of row i, a 16-byte read.  Same decomposition, staging and reductions as k_pw_wgrad;
 // tiles stay bf16 in LDS (64 rows x 32 pixels, row stride 80 B: the ds_read_b128 fragment reads are
 // conflict-free), 8 MFMAs per 32-pixel tile instead of 64.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kRowB = 80;                 // bytes per tile row (64 data + 16 pad)
 
 __device__ __forceinline__ void wgb_fetch(const __hip_bfloat16* __restrict__ T, int rows, int r0, int P,
@@ -520,6 +658,18 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     // chunk of 12 or 16 (2 waves per SIMD; 18 needs too many registers): the one that pads K less
     int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;
     if (kc_env == 12 || kc_env == 16) kc = kc_env;
+    if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+        static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
+        if (bf16_mfma) {
+#define RK_PW_B(WMV) do { if (a_is_mk) hipLaunchKernelGGL((k_pw_gemm_bf16<WMV, true>), grid, block, 0, stream, A, X, R, Y, d); \
+                          else hipLaunchKernelGGL((k_pw_gemm_bf16<WMV, false>), grid, block, 0, stream, A, X, R, Y, d); } while (0)
+            if (wm == 1) RK_PW_B(1);
+            else if (wm == 2) RK_PW_B(2);
+            else RK_PW_B(4);
+#undef RK_PW_B
+            return launch_status();
+        }
+    }
 #define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV>), grid, block, 0, stream, A, X, R, Y, d)
 #define RK_PW_KC(WMV) do { if (kc == 12) RK_PW_GO(WMV, 12); else RK_PW_GO(WMV, 16); } while (0)
     if (wm == 1) RK_PW_KC(1);

@@ -123,8 +123,9 @@ def _eligible(conv, x, has_residual=False):
         return True
     # measured win region of the GEMM (tools/pointwise_probe.py); with a residual to fuse, the 28x28 tie
     # (77 vs 76 us) tips over: the epilogue add replaces a separate elementwise pass
-    if x.dtype == torch.bfloat16:                        # forward / d(input) win on the big planes only
-        return P >= 3136 and K <= 128 and M <= 128
+    if x.dtype == torch.bfloat16:                        # bf16-MFMA GEMM: 43 vs 137 us at 56x56, 32 vs 80 us at 28x28
+        cmax = int(os.environ.get("RK_PW_BF16_CMAX", "128"))
+        return P >= 784 and K <= cmax and M <= cmax
     p_min = 784 if has_residual else 3136
     return P >= p_min and K <= 128 and M <= 128
 
