@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
         return (valid && k < d.K) ? Px4<T>::load(xp + (size_t)k * d.P) : Px4<T>::zero();
     };
 
+    const bool blk1 = m0 + wm * 64 + 32 < d.M;            // wave-uniform: does the second 32-row block hold any row?
     AStage<MT, kKC> ast;
     Raw bq[kKC / 2];                                      // B fragments of the current chunk, refilled in place:
     ast.fetch(A, d, m0, 0);                               // step s of chunk c+1 is requested right after step s of
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             const float bv[4] = {bw.x, bw.y, bw.z, bw.w};
             bq[s] = load_b((c + 1) * kKC + 2 * s + kh);    // (all zeros past K)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[0][q], 0, 0, 0);
-                acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[1][q], 0, 0, 0);
-            }
+            for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[0][q], 0, 0, 0);
+            if (blk1)                                       // (72 or 144 channels: the last 32-row block is all padding)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[1][q], 0, 0, 0);
         }
         if (more) ast.deposit(As[(c + 1) & 1]);
     }
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(kBlock, (WM == 4 ? 1 : 2)) void k_pw_gemm_bf16(cons
         for (int q = 0; q < 4; ++q) {
             const bf16x8 bq = *reinterpret_cast<const bf16x8*>(xt + 32 * q * kRowT);
             acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq, acc[0][q], 0, 0, 0);
-            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[1][q], 0, 0, 0);
+            if (m0 + wm * 64 + 32 < d.M) acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[1][q], 0, 0, 0);
         }
         if (more) {
             deposit_x(Xs[wn][(c + 1) & 1], xv);
@@ -389,6 +390,8 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // 32-row blocks that are all padding (72, 144, 288 channels) are skipped; wave-uniform
+    const bool a1_on = 64 * mb + 32 < d.M, b1_on = 64 * kb + 32 < d.K;
     float4 va[8], vb[8];
     PixCursor cur;
     cur.init(n0, d.P);
@@ -409,9 +412,9 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
             const float a0 = ta[tile_at(l31, 2 * s + kh)], a1 = ta[tile_at(32 + l31, 2 * s + kh)];
             const float b0 = tb[tile_at(l31, 2 * s + kh)], b1 = tb[tile_at(32 + l31, 2 * s + kh)];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (b1_on) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            if (a1_on) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (a1_on && b1_on) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
     // sum the sub-chunk waves of each block into its subc == 0 wave (fixed order), through the tile memory
@@ -515,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_bf16(const __hip_bfloat16* 
 
     // two tiles in flight (registers): with 8 MFMAs per tile the compute phase is far too short to cover a
     // global-load round trip, so the loop is unrolled by two over two register sets
+    const bool a1_on = 64 * mb + 32 < d.M, b1_on = 64 * kb + 32 < d.K;   // skip all-padding 32-row blocks
     uint2 va0[8], vb0[8], va1[8], vb1[8];
     PixCursor cur;
     cur.init(n0, d.P);
@@ -533,9 +537,9 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_bf16(const __hip_bfloat16* 
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(tb + l31 * kRowB + off);
             const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(tb + (32 + l31) * kRowB + off);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (b1_on) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            if (a1_on) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            if (a1_on && b1_on) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
     };
 #pragma nounroll

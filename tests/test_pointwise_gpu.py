@@ -17,6 +17,8 @@ CASES = [   # frames, Cin, Cout, H, W
     (3, 216, 432, 6, 6),       # M > 256: two row tiles; K = 12 x 18
     (7, 64, 40, 10, 14),       # K = 4 x 16, ragged columns
     (2, 50, 22, 6, 6),         # K = 50: padded last chunk
+    (3, 72, 144, 8, 8),        # Large's widths: the last 32-row block of a 64-row tile is all padding (skipped)
+    (2, 144, 72, 8, 8),
 ]
 
 
@@ -67,7 +69,7 @@ def test_fused_residual(monkeypatch, mode):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, float(b.abs().max())))
 
 
-@pytest.mark.parametrize("case", [(5, 54, 54, 8, 8), (2, 54, 108, 28, 28), (3, 216, 432, 6, 6)])
+@pytest.mark.parametrize("case", [(5, 54, 54, 8, 8), (2, 54, 108, 28, 28), (3, 216, 432, 6, 6), (3, 72, 144, 8, 8)])
 def test_bf16_activations_fp32_weight(monkeypatch, case):
     """bf16 storage (autocast): fp32 weight used as it is, fp32 MFMA arithmetic, outputs rounded once, d(weight)
     in fp32 -- checked against conv2d in fp64 on the bf16-rounded activations."""
