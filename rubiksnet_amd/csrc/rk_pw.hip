@@ -459,6 +459,126 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
 
 
 // ---------------------------------------------------------------------------------------------
+// d(weight) for wide layers (more than 64 channels on either side): one workgroup = a 128 x 128 block of dW,
+// its 4 waves = the four 64 x 64 quadrants, sharing ONE pair of staged tiles (128 channels x 32 pixels each).
+// Against four independent wave tasks this halves the loads and LDS writes per MFMA and -- what matters for
+// 144 / 288 / 576 channels -- halves how many times each operand row is re-read across the grid (a 64-row
+// block of dY is needed by every 64-column block of X: [256,288,14,14] re-read 2 x 5 x 58 MB through L2).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ dY, const T* __restrict__ X,
+                                                          float* __restrict__ ws, WgDims d) {
+    __shared__ float tiles[2][128 * kNB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave & 1, wk = wave >> 1;
+    const int MT2 = (d.M + 127) / 128, KT2 = (d.K + 127) / 128;
+    const int pair = blockIdx.x % (MT2 * KT2), chunk = blockIdx.x / (MT2 * KT2);
+    const int mt = pair / KT2, kt = pair - mt * KT2;
+    const long long n0 = (long long)chunk * d.chunk;
+    long long nend = n0 + d.chunk;
+    nend = nend < d.ntot ? nend : d.ntot;
+    float* ta = tiles[0];
+    float* tb = tiles[1];
+    const int rowA = 128 * mt + 64 * wm, rowB = 128 * kt + 64 * wk;       // this wave's quadrant
+    const bool a0_on = rowA < d.M, a1_on = rowA + 32 < d.M, b0_on = rowB < d.K, b1_on = rowB + 32 < d.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // a thread's share of a 128-row tile: rows (tid >> 3) + 32 j, pixels 4 (tid & 7) ..+3
+    PixCursor cur;
+    cur.init(n0, d.P);
+    auto fetch = [&](const T* __restrict__ src, int rows, int r0, int Cdim, float4 (&v)[4]) {
+        const bool nok = cur.n < nend;
+        const T* base = src + (nok ? ((size_t)cur.f * Cdim) * d.P + cur.p : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + (int)(threadIdx.x >> 3) + 32 * j;
+            v[j] = (nok && r < rows) ? Px4<T>::widen(Px4<T>::load(base + (size_t)r * d.P)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto deposit = [&](float* tile, const float4 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (int)(threadIdx.x >> 3) + 32 * j, col = 4 * (int)(threadIdx.x & 7);
+            tile[tile_at(row, col)] = v[j].x; tile[tile_at(row, col + 1)] = v[j].y;
+            tile[tile_at(row, col + 2)] = v[j].z; tile[tile_at(row, col + 3)] = v[j].w;
+        }
+    };
+    float4 va[4], vb[4];
+    fetch(dY, d.M, 128 * mt, d.M, va);
+    fetch(X, d.K, 128 * kt, d.K, vb);
+    const int steps = d.chunk / kNB;
+#pragma nounroll
+    for (int it = 0; it < steps; ++it) {
+        __syncthreads();
+        deposit(ta, va);
+        deposit(tb, vb);
+        __syncthreads();
+        cur.advance(d.P);
+        fetch(dY, d.M, 128 * mt, d.M, va);
+        fetch(X, d.K, 128 * kt, d.K, vb);
+        if (a0_on && b0_on) {
+#pragma unroll
+            for (int s = 0; s < kNB / 2; ++s) {
+                const float a0 = ta[tile_at(64 * wm + l31, 2 * s + kh)], a1 = ta[tile_at(64 * wm + 32 + l31, 2 * s + kh)];
+                const float b0 = tb[tile_at(64 * wk + l31, 2 * s + kh)], b1 = tb[tile_at(64 * wk + 32 + l31, 2 * s + kh)];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                if (b1_on) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                if (a1_on) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                if (a1_on && b1_on) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    if (a0_on && b0_on) {
+        float* out = ws + (size_t)chunk * d.M * d.K;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = rowA + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int gk = rowB + 32 * b + l31;
+                    if (gm < d.M && gk < d.K) out[(size_t)gm * d.K + gk] = acc[a][b][r];
+                }
+    }
+}
+
+// planner of the wide kernel: S pixel chunks so that ~768 workgroups run, partials under a quarter of the operands
+// Worth it when the 128 x 128 tiles are mostly full: quadrants in use / quadrants launched >= 3/4 (72, 108, 216, 432,
+// 576 channels yes; 144 and 288 -- 2.25 tiles per side -- and 54 -> 108 no: measured 216 -> 261 us, 176 -> 177 us,
+// 216 -> 270 us against 292 -> 226 us at 72, 135 -> 100 us at 108, 131 -> 98 us at 216)
+inline bool use_wide(int M, int K) {
+    static const int mode = [] { const char* e = getenv("RK_PW_WG_WIDE"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || (M <= 64 && K <= 64)) return false;
+    if (mode == 2) return true;
+    const int q = ((M + 63) / 64) * ((K + 63) / 64), slots = 4 * ((M + 127) / 128) * ((K + 127) / 128);
+    return 4 * q >= 3 * slots;
+}
+inline int make_wg_wide(WgDims& d, int F, int K, int M, int P) {
+    if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0) return RK_ERR_BAD_DIMS;
+    d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
+    d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
+    const int pairs = ((M + 127) / 128) * ((K + 127) / 128);
+    static const int want = [] { const char* e = getenv("RK_PW_WG_WIDE_WGS"); return e ? atoi(e) : 768; }();
+    long long S = want / pairs;
+    const long long cap = ((long long)(M + K) * d.ntot) / (4LL * M * K);
+    if (S > cap) S = cap;
+    if (S < 1) S = 1;
+    long long chunk = (d.ntot + S - 1) / S;
+    chunk = (chunk + kNB - 1) / kNB * kNB;
+    d.chunk = (int)chunk;
+    d.S = (int)((d.ntot + chunk - 1) / chunk);
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // d(weight) for bf16 activations on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  The reduction
 // index (pixels) is the contiguous one in NCHW, which is exactly what the bf16 fragments want: lane (i, g) holds
 // 8 consecutive k = pixels of row i, a 16-byte read.  Same decomposition, staging and reductions as k_pw_wgrad;
@@ -690,7 +810,10 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
     const T* dY = (const T*)dY_; const T* X = (const T*)X_;
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
     WgDims d;
-    if (int rc = make_wg(d, F, K, M, P)) return rc;
+    static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
+    // the wide (shared-tile) kernel for > 64 channels; bf16 activations keep the bf16-MFMA kernel
+    const bool wide = use_wide(M, K) && !(std::is_same<T, __hip_bfloat16>::value && bf16_mfma);
+    if (int rc = wide ? make_wg_wide(d, F, K, M, P) : make_wg(d, F, K, M, P)) return rc;
     const uintptr_t am = 4 * sizeof(T) - 1;
     if (((uintptr_t)X & am) || ((uintptr_t)dY & am)) return RK_ERR_BAD_DIMS;
     if (!ws || ws_bytes < (size_t)(d.S + kRed) * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
@@ -700,8 +823,10 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
     float* part2 = part + (size_t)d.S * M * K;
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
-    static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
-    if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+    if (wide) {
+        const int pairs = ((M + 127) / 128) * ((K + 127) / 128);
+        hipLaunchKernelGGL((k_pw_wgrad_wide<T>), dim3((unsigned)(d.S * pairs)), dim3(kBlock), 0, stream, dY, X, part, d);
+    } else if constexpr (std::is_same<T, __hip_bfloat16>::value) {
         if (bf16_mfma) hipLaunchKernelGGL(k_pw_wgrad_bf16, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
         else hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     } else {
@@ -721,8 +846,9 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
 extern "C" {
 
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P) {
-    WgDims d;
-    return make_wg(d, F, K, M, P) ? 0 : (size_t)(d.S + kRed) * M * K * sizeof(float);
+    WgDims d, w;
+    if (make_wg(d, F, K, M, P) || make_wg_wide(w, F, K, M, P)) return 0;
+    return (size_t)((d.S > w.S ? d.S : w.S) + kRed) * M * K * sizeof(float);      // whichever kernel is chosen
 }
 
 // Y[f] = A X[f] (+ R[f]).  a_is_mk != 0: A is [M][K] row-major; else [K][M] (always fp32).  X [F,K,P], Y / R [F,M,P]
