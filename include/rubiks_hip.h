@@ -196,6 +196,13 @@ int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int
                    int a_is_mk, rk_stream_t stream);
 int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F, int K, int M, int P,
                     int a_is_mk, rk_stream_t stream);
+/*   rk_pw_gemm_fused_f32: inference form, Y[f] = epi(A pro(X[f])) (+ R[f]) with
+ *                   pro: x' = relu?(ka[k] x + kb[k]) per input channel  (relu(bn1(x)) feeding conv2, backbone.py:129-131)
+ *                   epi: y  = relu?(ma[m] y + mb[m]) per output channel (relu(bn2(conv2(.))), BatchNorm in eval mode:
+ *                   a = gamma / sqrt(running_var + eps), b = beta - running_mean * a).  NULL pairs switch a stage off. */
+int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                         int a_is_mk, const float* ka, const float* kb, int relu_in, const float* ma,
+                         const float* mb, int relu_out, rk_stream_t stream);
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
                     size_t ws_bytes, rk_stream_t stream);

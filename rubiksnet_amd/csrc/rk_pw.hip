@@ -58,6 +58,15 @@ struct PwDims {
 };
 
 
+// Inference-time fusion of the block's BatchNorms into the GEMM (eval mode: running statistics are constants):
+//   prologue on the streamed operand, per input channel k:   x' = relu?(ka[k] x + kb[k])   (relu(bn1(x)) -> conv2)
+//   epilogue on the result, per output channel m:             y  = relu?(ma[m] y + mb[m])   (relu(bn2(conv2(.))))
+// NULL pointers switch a stage off.
+struct PwFuse {
+    const float* ka; const float* kb; const float* ma; const float* mb;
+    int relu_in, relu_out;
+};
+
 // A chunk -> registers (global, L2-resident) -> LDS image As[kk][m], m < MT, zero padded
 template <int MT, int kKC>
 struct AStage {
@@ -82,9 +91,9 @@ struct AStage {
 };
 
 // kKC: K chunk (12 or 16: the launcher picks the one that pads K less)
-template <typename T, int WM, int kKC>
+template <typename T, int WM, int kKC, bool FUSE>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
-                                                    const T* __restrict__ R, T* __restrict__ Y, PwDims d) {
+                                                    const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz) {
     using Raw = typename Px4<T>::Raw;
     constexpr int MT = 64 * WM, WN = 4 / WM;
     __shared__ float As[2][kKC * MT];
@@ -129,7 +138,17 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
         for (int s = 0; s < kKC / 2; ++s) {
             const float a0 = as[(2 * s + kh) * MT], a1 = as[(2 * s + kh) * MT + 32];
             const float4 bw = Px4<T>::widen(bq[s]);
-            const float bv[4] = {bw.x, bw.y, bw.z, bw.w};
+            float bv[4] = {bw.x, bw.y, bw.z, bw.w};
+            if (FUSE && fz.ka) {                            // BN (+ReLU) of the input channel, applied on the fly
+                const int k = c * kKC + 2 * s + kh;
+                const bool kin = k < d.K;                   // (padded k: A is zero there, any finite value will do)
+                const float pa = kin ? fz.ka[k] : 0.f, pb = kin ? fz.kb[k] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = fmaf(pa, bv[q], pb);
+                    bv[q] = fz.relu_in ? fmaxf(t, 0.f) : t;
+                }
+            }
             bq[s] = load_b((c + 1) * kKC + 2 * s + kh);    // (all zeros past K)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[0][q], 0, 0, 0);
@@ -148,6 +167,11 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
                 const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;   // C/D map of 32x32 MFMA
                 if (gm < d.M) {
                     float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                    if (FUSE && fz.ma) {                          // BN (+ReLU) of the output channel
+                        const float ea = fz.ma[gm], eb = fz.mb[gm];
+                        o.x = fmaf(ea, o.x, eb); o.y = fmaf(ea, o.y, eb); o.z = fmaf(ea, o.z, eb); o.w = fmaf(ea, o.w, eb);
+                        if (fz.relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    }
                     if (R) {                                      // fused residual: Y = A X + R (the block's shortcut)
                         const float4 t = Px4<T>::widen(Px4<T>::load(R + (yp - Y) + (size_t)gm * d.P));
                         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
@@ -762,7 +786,7 @@ namespace {
 
 template <typename T>
 int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int K, int M, int P, int a_is_mk,
-            rk_stream_t stream_) {
+            rk_stream_t stream_, const PwFuse* fuse = nullptr) {
     const T* X = (const T*)X_; const T* R = (const T*)R_; T* Y = (T*)Y_;
     if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
     const uintptr_t am = 4 * sizeof(T) - 1;
@@ -784,7 +808,7 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if (kc_env == 12 || kc_env == 16) kc = kc_env;
     if constexpr (std::is_same<T, __hip_bfloat16>::value) {
         static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
-        if (bf16_mfma) {
+        if (bf16_mfma && !(fuse && (fuse->ka || fuse->ma))) {
 #define RK_PW_B(WMV) do { if (a_is_mk) hipLaunchKernelGGL((k_pw_gemm_bf16<WMV, true>), grid, block, 0, stream, A, X, R, Y, d); \
                           else hipLaunchKernelGGL((k_pw_gemm_bf16<WMV, false>), grid, block, 0, stream, A, X, R, Y, d); } while (0)
             if (wm == 1) RK_PW_B(1);
@@ -794,7 +818,10 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
             return launch_status();
         }
     }
-#define RK_PW_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV>), grid, block, 0, stream, A, X, R, Y, d)
+    const bool fused = fuse && (fuse->ka || fuse->ma);
+    PwFuse fz = fused ? *fuse : PwFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
+#define RK_PW_GO(WMV, KCV) do { if (fused) hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV, true>), grid, block, 0, stream, A, X, R, Y, d, fz); \
+                                else hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV, false>), grid, block, 0, stream, A, X, R, Y, d, fz); } while (0)
 #define RK_PW_KC(WMV) do { if (kc == 12) RK_PW_GO(WMV, 12); else RK_PW_GO(WMV, 16); } while (0)
     if (wm == 1) RK_PW_KC(1);
     else if (wm == 2) RK_PW_KC(2);
@@ -860,6 +887,15 @@ int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int
 int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F, int K, int M, int P, int a_is_mk,
                     rk_stream_t stream) {
     return pw_gemm<__hip_bfloat16>(A, X, R, Y, F, K, M, P, a_is_mk, stream);
+}
+// Inference: Y[f] = epi(A pro(X[f])) (+ R[f]) with the per-channel affine (+ReLU) stages of PwFuse above; ka / kb
+// have K entries, ma / mb have M; a NULL pair switches its stage off.
+int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                         int a_is_mk, const float* ka, const float* kb, int relu_in, const float* ma,
+                         const float* mb, int relu_out, rk_stream_t stream) {
+    if ((ka == nullptr) != (kb == nullptr) || (ma == nullptr) != (mb == nullptr)) return RK_ERR_NULL_POINTER;
+    const PwFuse fz{ka, kb, ma, mb, relu_in, relu_out};
+    return pw_gemm<float>(A, X, R, Y, F, K, M, P, a_is_mk, stream, &fz);
 }
 // dW[M][K] (fp32) = sum_f dY[f] X[f]^T.  dY [F,M,P], X [F,K,P] fp32 or bf16, P % 4 == 0.
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,

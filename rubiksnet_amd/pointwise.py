@@ -18,7 +18,7 @@ import torch
 
 from . import _native
 
-__all__ = ["conv1x1", "pointwise_mode"]
+__all__ = ["conv1x1", "pointwise_mode", "fused_eval_block"]
 
 
 def pointwise_mode():
@@ -139,3 +139,84 @@ def conv1x1(conv, x, residual=None):
             y += residual
         return y
     return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Inference: BatchNorm in eval mode is a per-channel affine map with constant coefficients, so the block's two
+# BN+ReLU pairs ride on the conv2 GEMM -- relu(bn1(x)) on its operand load, relu(bn2(.)) on its epilogue -- and the
+# residual add on the conv3 GEMM: per block two GEMMs and the shift touch memory, nothing else.
+
+def _bn_affine(bn):
+    """(a, b) with bn(x) = a x + b in eval mode, cached on the module until a parameter / statistic changes."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+    cached = getattr(bn, "_rk_affine", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            a = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+            b = (bn.bias.float() - bn.running_mean.float() * a).contiguous()
+        cached = (key, a, b)
+        bn._rk_affine = cached
+    return cached[1], cached[2]
+
+
+def _gemm_fused(conv, x, pro=None, epi=None, residual=None):
+    Fr, Cin, H, W = x.shape
+    Cout = conv.out_channels
+    y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
+    dev = x.device
+    ka, kb = pro if pro is not None else (None, None)
+    ma, mb = epi if epi is not None else (None, None)
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    with torch.cuda.device(dev):
+        rc = _native.lib().rk_pw_gemm_fused_f32(
+            conv.weight.data_ptr(), x.data_ptr(), ptr(residual), y.data_ptr(), Fr, Cin, Cout, H * W, 1,
+            ptr(ka), ptr(kb), 1, ptr(ma), ptr(mb), 1, torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "rk_pw_gemm_fused_f32")
+    return y
+
+
+def _plain_1x1(conv, x):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
+            and conv.in_channels <= 128 and conv.out_channels <= 128)
+
+
+def _eval_bn(bn):
+    return (isinstance(bn, torch.nn.BatchNorm2d) and not bn.training and bn.affine and bn.track_running_stats
+            and bn.running_mean is not None and bn.weight.dtype == torch.float32)
+
+
+def _stride_one(as3):
+    """True when no shift inside `as3` (RubiksShift2D, the 3-D wrapper, the attention + 2-D pair) subsamples."""
+    for m in as3.modules():
+        st = getattr(m, "stride", None)
+        if st is None:
+            continue
+        st = (st,) if isinstance(st, int) else tuple(st)
+        if any(int(v) != 1 for v in st):
+            return False
+    return True
+
+
+def fused_eval_block(block, x):
+    """Inference forward of a RubiksShiftBlock with bn1 / bn2 / the residual add fused into the two 1x1 GEMMs, or None
+    when the block does not qualify (training mode, gradients, bf16, SE layer, strided or wide layers, small planes,
+    `RK_FUSED_EVAL=0`) -- the caller then runs the layer-by-layer path."""
+    if (os.environ.get("RK_FUSED_EVAL", "1") == "0" or pointwise_mode() == "0" or block.training
+            or torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4)
+            or block.se is not None or x.numel() == 0):
+        return None
+    P = x.shape[2] * x.shape[3]
+    identity = isinstance(block.shortcut, torch.nn.Identity)
+    if (P % 4 or P < 784 or not (_plain_1x1(block.conv2, x) and _plain_1x1(block.conv3, x))
+            or not (_eval_bn(block.bn1) and _eval_bn(block.bn2)) or not (identity or _plain_1x1(block.shortcut, x))
+            or not _stride_one(block.as3)):
+        return None
+    x = x.contiguous()
+    pro = _bn_affine(block.bn1)
+    shortcut = x if identity else _gemm_fused(block.shortcut, x, pro=pro)
+    mid = _gemm_fused(block.conv2, x, pro=pro, epi=_bn_affine(block.bn2))
+    mid = block.as3(mid)
+    return _gemm_fused(block.conv3, mid.contiguous(), residual=shortcut)

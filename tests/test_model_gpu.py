@@ -128,4 +128,35 @@ def test_fused_paths_match_the_stock_backbone(monkeypatch):
     assert len(ga) == 6
     for n in ga:
         scale = float(gb[n].abs().max())
-        np.testing.assert_allclose(ga[n].cpu().numpy(), gb[n].cpu().numpy(), rtol=0, atol=2e-3 * scale, err_msg=n)
+        # gradients of the first layers sit behind ~35 layers of differently-ordered fp32 sums (and MIOpen's own
+        # d(weight) kernels are not run-to-run deterministic): a few 1e-3 of the largest element
+        np.testing.assert_allclose(ga[n].cpu().numpy(), gb[n].cpu().numpy(), rtol=0, atol=6e-3 * scale, err_msg=n)
+
+
+@pytest.mark.parametrize("variant", ["rubiks3d", "rubiks3d-aq"])
+def test_fused_inference_blocks_match_layer_by_layer(monkeypatch, variant):
+    """Eval mode: blocks whose BatchNorms / residual add ride on the 1x1 GEMMs (pointwise.fused_eval_block) against
+    the layer-by-layer path, on random running statistics so that the BN coefficients are not trivial."""
+    from rubiksnet_amd import RubiksNet
+    from rubiksnet_amd import pointwise
+
+    torch.manual_seed(5)
+    net = RubiksNet("tiny", 9, variant=variant, verbose=False).to(DEV)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    net.eval()
+    clips = torch.randn(2, 8, 3, 224, 224, device=DEV)
+    calls = []
+    real = pointwise._gemm_fused
+    monkeypatch.setattr(pointwise, "_gemm_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    outs = []
+    with torch.no_grad():
+        for fused in ("1", "0"):
+            monkeypatch.setenv("RK_FUSED_EVAL", fused)
+            outs.append(net(clips))
+    assert len(calls) >= 6                                   # the fused path really ran (>= 3 blocks x 2 GEMMs)
+    scale = float(outs[1].abs().max())
+    np.testing.assert_allclose(outs[0].cpu().numpy(), outs[1].cpu().numpy(), rtol=0, atol=2e-4 * scale)
