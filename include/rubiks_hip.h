@@ -203,6 +203,11 @@ int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F
 int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, const float* ma,
                          const float* mb, int relu_out, rk_stream_t stream);
+/*   rk_stem_conv3x3s2_f32: the backbone's first layer (backbone.py:154, Conv3x3(3, width, stride=2), no bias) on the
+ *                   same GEMM with the im2col gathered on the fly: W [Cout][Cin][3][3], X [F,Cin,Hin,Win],
+ *                   Y [F,Cout,Hin/2,Win/2]; Hin even, Win % 8 == 0, 9 Cin <= 64.                              */
+int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                          rk_stream_t stream);
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
                     size_t ws_bytes, rk_stream_t stream);

@@ -11,7 +11,7 @@ import math
 import torch.nn as nn
 
 from .fused_bn import bn_relu
-from .pointwise import conv1x1, fused_eval_block
+from .pointwise import conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 
 __all__ = ["RubiksNetBackbone", "RubiksShiftBlock", "SELayer"]
@@ -161,7 +161,7 @@ class RubiksNetBackbone(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
-        x = self.conv1(x)
+        x = stem_conv(self.conv1, x)
         for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)
         x = bn_relu(self.bn_last, x)

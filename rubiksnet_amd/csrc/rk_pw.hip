@@ -54,6 +54,7 @@ struct PwDims {
     int F, K, M, P;
     long long ntot;         // F * P columns
     int a_is_mk;            // A given as [M][K] row-major (the weight itself), else [K][M]
+    int Cin, Hin, Win, Wo;  // STEM mode only: 3x3 / stride 2 / pad 1 convolution, K = 9 Cin, P = Ho * Wo
     int WM, WN;             // waves along M / along N (WM * WN = 4); workgroup tile = 64 WM rows x 128 WN columns
 };
 
@@ -91,7 +92,11 @@ struct AStage {
 };
 
 // kKC: K chunk (12 or 16: the launcher picks the one that pads K less)
-template <typename T, int WM, int kKC, bool FUSE>
+// STEM: the streamed operand is gathered as the im2col of a 3x3 / stride-2 / pad-1 convolution instead of read as
+// a [K, P] matrix (the backbone's first layer, backbone.py:154 Conv3x3(3, width, stride=2)): column = output
+// pixel, k = (ci, kh, kw); a lane's 4 output pixels read 4 input pixels 2 apart (the only out-of-range ones
+// are row -1 / Hin and column -1).
+template <typename T, int WM, int kKC, bool FUSE, bool STEM = false>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
                                                     const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz) {
     using Raw = typename Px4<T>::Raw;
@@ -116,8 +121,22 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
 
+    const int s_ho = STEM ? p / d.Wo : 0, s_wo = STEM ? p - s_ho * d.Wo : 0;      // this lane's first output pixel
     auto load_b = [&](int k) -> Raw {
-        return (valid && k < d.K) ? Px4<T>::load(xp + (size_t)k * d.P) : Px4<T>::zero();
+        if constexpr (STEM && std::is_same<T, float>::value) {
+            const int ci = k / 9, r9 = k - 9 * ci, kh3 = r9 / 3, kw3 = r9 - 3 * kh3;
+            const int hi = 2 * s_ho - 1 + kh3, wi = 2 * s_wo - 1 + kw3;
+            const bool ok = valid && k < d.K && hi >= 0 && hi < d.Hin;
+            const float* row = X + (((size_t)f * d.Cin + (ok ? ci : 0)) * d.Hin + (ok ? hi : 0)) * d.Win;
+            float4 v;
+            v.x = (ok && wi >= 0) ? row[wi >= 0 ? wi : 0] : 0.f;
+            v.y = ok ? row[wi + 2] : 0.f;
+            v.z = ok ? row[wi + 4] : 0.f;
+            v.w = ok ? row[wi + 6] : 0.f;
+            return v;
+        } else {
+            return (valid && k < d.K) ? Px4<T>::load(xp + (size_t)k * d.P) : Px4<T>::zero();
+        }
     };
 
     const bool blk1 = m0 + wm * 64 + 32 < d.M;            // wave-uniform: does the second 32-row block hold any row?
@@ -795,6 +814,7 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if (((uintptr_t)X & am) || ((uintptr_t)Y & am)) return RK_ERR_BAD_DIMS;
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
+    d.Cin = d.Hin = d.Win = d.Wo = 0;
     static const int wm_env = [] { const char* e = getenv("RK_PW_WM"); return e ? atoi(e) : 0; }();
     int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
     if (wm_env == 1 || wm_env == 2 || wm_env == 4) wm = wm_env;
@@ -887,6 +907,28 @@ int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int
 int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F, int K, int M, int P, int a_is_mk,
                     rk_stream_t stream) {
     return pw_gemm<__hip_bfloat16>(A, X, R, Y, F, K, M, P, a_is_mk, stream);
+}
+// 3x3 / stride 2 / pad 1 convolution, no bias (the stem): W [Cout][Cin][3][3], X [F, Cin, Hin, Win], Y [F, Cout, Ho, Wo],
+// Ho = Hin / 2, Wo = Win / 2 (Hin even, Win % 8 == 0, 9 Cin <= 64).  Same GEMM, im2col gathered on the fly.
+int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                          rk_stream_t stream_) {
+    if (!W || !X || !Y) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || 9 * Cin > 64) return RK_ERR_BAD_DIMS;
+    if ((uintptr_t)Y & 15) return RK_ERR_BAD_DIMS;
+    PwDims d;
+    d.F = F; d.K = 9 * Cin; d.M = Cout; d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    d.P = (Hin / 2) * d.Wo; d.ntot = (long long)F * d.P; d.a_is_mk = 1;
+    const int wm = Cout <= 64 ? 1 : (Cout <= 128 ? 2 : 4);
+    d.WM = wm; d.WN = 4 / wm;
+    const int mt = 64 * wm;
+    const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((Cout + mt - 1) / mt)), block(kBlock);
+    hipStream_t stream = (hipStream_t)stream_;
+    const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const float* R = nullptr;
+    if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
+    else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
+    else hipLaunchKernelGGL((k_pw_gemm<float, 4, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
+    return launch_status();
 }
 // Inference: Y[f] = epi(A pro(X[f])) (+ R[f]) with the per-channel affine (+ReLU) stages of PwFuse above; ka / kb
 // have K entries, ma / mb have M; a NULL pair switches its stage off.

@@ -18,7 +18,7 @@ import torch
 
 from . import _native
 
-__all__ = ["conv1x1", "pointwise_mode", "fused_eval_block"]
+__all__ = ["conv1x1", "stem_conv", "pointwise_mode", "fused_eval_block"]
 
 
 def pointwise_mode():
@@ -220,3 +220,42 @@ def fused_eval_block(block, x):
     mid = _gemm_fused(block.conv2, x, pro=pro, epi=_bn_affine(block.bn2))
     mid = block.as3(mid)
     return _gemm_fused(block.conv3, mid.contiguous(), residual=shortcut)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The stem: Conv3x3(3, width, stride=2) (backbone.py:154) on the same MFMA GEMM, im2col gathered on the fly.
+
+class _StemFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_stem_conv3x3s2_f32(weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W,
+                                                     torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_stem_conv3x3s2_f32")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            dy.contiguous(), x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        return gx, gw
+
+
+def stem_conv(conv, x):
+    """`conv(x)` for the backbone's 3x3 / stride-2 / pad-1 first layer (forward on the HIP GEMM; backward on aten)."""
+    ok = (pointwise_mode() != "0" and os.environ.get("RK_STEM", "1") != "0"
+          and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
+          and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+          and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+          and conv.weight.dtype == torch.float32 and 9 * conv.in_channels <= 64
+          and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+    if not ok:
+        return conv(x)
+    return _StemFunc.apply(x.contiguous(), conv.weight)

@@ -113,3 +113,25 @@ def test_ineligible_layers_take_the_stock_path(monkeypatch):
     monkeypatch.setenv("RK_PW", "0")
     x4 = torch.randn(2, 6, 8, 8, device="cuda", requires_grad=True)
     assert "Conv1x1Func" not in type(conv1x1(conv, x4).grad_fn).__name__
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 32, 40, 54), (2, 3, 224, 224, 72), (5, 2, 18, 16, 20), (2, 7, 8, 8, 150)])
+def test_stem_conv(shape):
+    """The 3x3 / stride-2 / pad-1 first layer on the MFMA GEMM (im2col gathered on the fly) against F.conv2d in fp64;
+    d(weight) goes through aten."""
+    from rubiksnet_amd.pointwise import stem_conv
+
+    Fr, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(Fr, Cin, H, W, generator=g)
+    conv = nn.Conv2d(Cin, Cout, 3, stride=2, padding=1, bias=False)
+    dy = torch.randn(Fr, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.double(), conv.weight.detach().double(), stride=2, padding=1)
+    conv = conv.cuda()
+    y = stem_conv(conv, x.cuda())
+    assert "StemFunc" in type(y.grad_fn).__name__
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()) * (9 * Cin) ** 0.5)
+    y.backward(dy.cuda())
+    wr = conv.weight.detach().double().cpu().requires_grad_(True)
+    F.conv2d(x.double(), wr, stride=2, padding=1).backward(dy.double())
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=1e-4 * float(wr.grad.abs().max()))
