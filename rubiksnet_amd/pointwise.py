@@ -111,6 +111,8 @@ def _eligible(conv, x, has_residual=False):
     mode = pointwise_mode()
     if mode == "0" or not (x.is_cuda and x.dtype in _SFX and x.dim() == 4):
         return None
+    if x.dtype == torch.float32 and torch.is_autocast_enabled():
+        return None                                       # autocast would run this layer in bf16: let it
     if not (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None
             and conv.weight.dtype == torch.float32):
@@ -250,7 +252,9 @@ class _StemFunc(torch.autograd.Function):
 
 def stem_conv(conv, x):
     """`conv(x)` for the backbone's 3x3 / stride-2 / pad-1 first layer (forward on the HIP GEMM; backward on aten)."""
-    ok = (pointwise_mode() != "0" and os.environ.get("RK_STEM", "1") != "0"
+    # under autocast the stock layer would produce a bf16 activation: leave it to autocast (an fp32 output here would
+    # keep the next BatchNorm / shift in fp32 storage)
+    ok = (pointwise_mode() != "0" and os.environ.get("RK_STEM", "1") != "0" and not torch.is_autocast_enabled()
           and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
           and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
           and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
