@@ -166,7 +166,9 @@ size_t rk_tshift3_backward_workspace_bytes(int NT, int n_segment, int C, int HW)
  *                  r = (1 - momentum) r + momentum * stat, with the UNBIASED variance, as torch does.
  *                  Needs ws of rk_bn_workspace_bytes(F, C, P) bytes.
  *   training == 0: y = relu?(gamma (x - running_mean) / sqrt(running_var + eps) + beta); save_*, ws unused.
- *   backward     : gradients of the training-mode forward; the ReLU mask is recomputed from x.
+ *   backward     : gradients of the training-mode forward; the ReLU mask is recomputed from x.  dskip (or NULL): a
+ *                  gradient of the same shape added into dx -- the branch of the block's identity shortcut
+ *                  (backbone.py:130), which autograd would otherwise sum with a separate elementwise pass.
  *   relu != 0 fuses the ReLU (and its backward).                                                         */
 size_t rk_bn_workspace_bytes(int F, int C, int P);
 #define RK_DECL_BN(SFX, CTYPE)                                                                                   \
@@ -175,9 +177,9 @@ size_t rk_bn_workspace_bytes(int F, int C, int P);
                                  int C, int P, float eps, float momentum, int relu, int training, void* ws,     \
                                  size_t ws_bytes, rk_stream_t stream);                                           \
     int rk_bn_relu_backward_##SFX(const CTYPE* dy, const CTYPE* x, const float* gamma, const float* beta,        \
-                                  const float* save_mean, const float* save_invstd, CTYPE* dx, float* dgamma,    \
-                                  float* dbeta, int F, int C, int P, int relu, void* ws, size_t ws_bytes,        \
-                                  rk_stream_t stream);
+                                  const float* save_mean, const float* save_invstd, const CTYPE* dskip,          \
+                                  CTYPE* dx, float* dgamma, float* dbeta, int F, int C, int P, int relu,         \
+                                  void* ws, size_t ws_bytes, rk_stream_t stream);
 RK_DECL_BN(f32, float)
 RK_DECL_BN(bf16, void)
 #undef RK_DECL_BN

@@ -10,7 +10,7 @@ import math
 
 import torch.nn as nn
 
-from .fused_bn import bn_relu
+from .fused_bn import bn_relu, bn_relu_skip
 from .pointwise import conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 
@@ -117,8 +117,12 @@ class RubiksShiftBlock(nn.Module):
             y = fused_eval_block(self, x)
             if y is not None:
                 return y
-        out = bn_relu(self.bn1, x)          # relu(bn(.)) as one operator on GPU tensors (fused_bn.py)
-        shortcut = x if isinstance(self.shortcut, nn.Identity) else conv1x1(self.shortcut, out)
+        if isinstance(self.shortcut, nn.Identity):
+            # relu(bn(.)) as one operator on GPU tensors (fused_bn.py); the shortcut's gradient joins inside its backward
+            out, shortcut = bn_relu_skip(self.bn1, x)
+        else:
+            out = bn_relu(self.bn1, x)
+            shortcut = conv1x1(self.shortcut, out)
         out = bn_relu(self.bn2, conv1x1(self.conv2, out))
         out = self.as3(out)
         if self.se:

@@ -200,8 +200,9 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_invstd,
-                                                      const float* __restrict__ part, T* __restrict__ dx,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, BnDims d) {
+                                                      const float* __restrict__ part, const T* __restrict__ skip,
+                                                      T* __restrict__ dx, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, BnDims d) {
     __shared__ double sm[1][2];
     const Where w = where_am_i(d);
     double S[2];
@@ -224,6 +225,12 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
             const float dz = (RELU && fmaf(a, xv[e], b) <= 0.f) ? 0.f : gv[e];
             const float xh = (xv[e] - mean) * invstd;
             gv[e] = a * (dz - k1 - xh * k2);
+        }
+        if (skip) {                        // x also feeds the block's identity shortcut: add that branch's gradient here
+            float sv[VEC];
+            Pack<T, VEC>::load(skip + o, sv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gv[e] += sv[e];
         }
         Pack<T, VEC>::store(dx + o, gv);
     });
@@ -281,9 +288,9 @@ int bn_forward(const void* x_, const float* gamma, const float* beta, float* run
 
 template <typename T>
 int bn_backward(const void* dy_, const void* x_, const float* gamma, const float* beta, const float* save_mean,
-                const float* save_invstd, void* dx_, float* dgamma, float* dbeta, int F, int C, int P, int relu,
-                void* ws, size_t ws_bytes, rk_stream_t stream_) {
-    const T* dy = (const T*)dy_; const T* x = (const T*)x_; T* dx = (T*)dx_;
+                const float* save_invstd, const void* skip_, void* dx_, float* dgamma, float* dbeta, int F, int C, int P,
+                int relu, void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    const T* dy = (const T*)dy_; const T* x = (const T*)x_; T* dx = (T*)dx_; const T* skip = (const T*)skip_;
     if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta)
         return RK_ERR_NULL_POINTER;
     BnDims d;
@@ -292,13 +299,13 @@ int bn_backward(const void* dy_, const void* x_, const float* gamma, const float
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid(grid_bn(d)), block(kBlock);
     float* part = (float*)ws;
-    const bool v4 = vec4_ok<T>(d, x, dy, dx);
+    const bool v4 = vec4_ok<T>(d, x, dy, dx) && !((uintptr_t)skip & (4 * sizeof(T) - 1));
 #define RK_BN_BWD(VEC, RELU)                                                                                       \
     do {                                                                                                           \
         hipLaunchKernelGGL((k_bn_bwd_reduce<T, VEC, RELU>), grid, block, 0, stream, dy, x, gamma, beta, save_mean,  \
                            save_invstd, part, d);                                                                  \
         hipLaunchKernelGGL((k_bn_bwd_dx<T, VEC, RELU>), grid, block, 0, stream, dy, x, gamma, beta, save_mean,      \
-                           save_invstd, (const float*)part, dx, dgamma, dbeta, d);                                 \
+                           save_invstd, (const float*)part, skip, dx, dgamma, dbeta, d);                           \
     } while (0)
     if (v4) { if (relu) RK_BN_BWD(4, true); else RK_BN_BWD(4, false); }
     else { if (relu) RK_BN_BWD(1, true); else RK_BN_BWD(1, false); }
@@ -328,11 +335,11 @@ size_t rk_bn_workspace_bytes(int F, int C, int P) {
                                 eps, momentum, relu, training, ws, ws_bytes, stream);                             \
     }                                                                                                             \
     int rk_bn_relu_backward_##SFX(const CTYPE* dy, const CTYPE* x, const float* gamma, const float* beta,         \
-                                  const float* save_mean, const float* save_invstd, CTYPE* dx, float* dgamma,     \
-                                  float* dbeta, int F, int C, int P, int relu, void* ws, size_t ws_bytes,         \
-                                  rk_stream_t stream) {                                                           \
-        return bn_backward<TYPE>(dy, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, F, C, P, relu,    \
-                                 ws, ws_bytes, stream);                                                           \
+                                  const float* save_mean, const float* save_invstd, const CTYPE* dskip,           \
+                                  CTYPE* dx, float* dgamma, float* dbeta, int F, int C, int P, int relu,          \
+                                  void* ws, size_t ws_bytes, rk_stream_t stream) {                                \
+        return bn_backward<TYPE>(dy, x, gamma, beta, save_mean, save_invstd, dskip, dx, dgamma, dbeta, F, C, P,   \
+                                 relu, ws, ws_bytes, stream);                                                     \
     }
 RK_DEF_BN(f32, float, float)
 RK_DEF_BN(bf16, __hip_bfloat16, void)

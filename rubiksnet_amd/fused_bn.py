@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import _native
 
-__all__ = ["bn_relu", "fused_bn_enabled"]
+__all__ = ["bn_relu", "bn_relu_skip", "fused_bn_enabled"]
 
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
 
@@ -38,7 +38,7 @@ class _BNReLUTrain(torch.autograd.Function):
     """y = relu?(batch_norm(x)) with batch statistics; updates running_mean / running_var in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, with_skip=False):
         L = _native.lib()
         Fr, C, H, W = x.shape
         P = H * W
@@ -55,10 +55,16 @@ class _BNReLUTrain(torch.autograd.Function):
         _native.check(rc, "rk_bn_relu_forward")
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.relu = relu
-        return y            # (running_mean / running_var are buffers updated in place by the kernel, as F.batch_norm does)
+        ctx.with_skip = with_skip
+        # (running_mean / running_var are buffers updated in place by the kernel, as F.batch_norm does)
+        if with_skip:
+            # second output: x itself, for the block's identity shortcut -- its gradient then arrives HERE and is
+            # added inside the d(x) kernel instead of by a separate autograd accumulation pass
+            return y, x.view_as(x)
+        return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         L = _native.lib()
         Fr, C, H, W = x.shape
@@ -67,6 +73,10 @@ class _BNReLUTrain(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            if dskip.dtype != x.dtype:
+                dskip = dskip.to(x.dtype)
         dx = torch.empty_like(x)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
@@ -74,10 +84,10 @@ class _BNReLUTrain(torch.autograd.Function):
             ws, nbytes = _ws(L, Fr, C, P, dev)
             rc = getattr(L, "rk_bn_relu_backward_" + _SFX[x.dtype])(
                 dy.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), save_mean.data_ptr(),
-                save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, P,
+                save_invstd.data_ptr(), _ptr(dskip), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, P,
                 int(ctx.relu), ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "rk_bn_relu_backward")
-        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None, None
 
 
 def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):
@@ -102,6 +112,24 @@ def _fusable(bn, x):
         and bn.affine and bn.weight.dtype == torch.float32
         and (bn.running_mean is None or bn.running_mean.dtype == torch.float32)
     )
+
+
+def bn_relu_skip(bn, x):
+    """(`relu(bn(x))`, x) for a block whose input also feeds an identity shortcut.  On the fused training path the
+    second element is an autograd alias of x whose gradient is added inside the BN d(x) kernel (one elementwise pass
+    less per block); elsewhere it is x itself."""
+    if (_fusable(bn, x) and (bn.training or (bn.running_mean is None and bn.running_var is None))
+            and torch.is_grad_enabled() and x.requires_grad and os.environ.get("RK_BN_SKIP", "1") != "0"):
+        x = x.contiguous()
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
+        rv = bn.running_var if (bn.training and bn.track_running_stats) else None
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, True, True)
+    return bn_relu(bn, x), x
 
 
 def bn_relu(bn, x, relu=True):

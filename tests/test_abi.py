@@ -56,7 +56,7 @@ def test_argument_validation_without_a_device():
     assert L.rk3d_forward_f32(None, one, one, *dims, 1, 1, 1, 0, 0, 0, 0, None) == -1
     assert L.rk_bn_relu_forward_f32(one, one, one, one, one, None, None, one, 4, 3, 16, 1e-5, 0.1, 1, 1, one, 1 << 20, None) == -1
     assert L.rk_bn_relu_forward_f32(one, one, one, one, one, one, one, one, 4, 3, 16, 1e-5, 0.1, 1, 1, None, 0, None) == -4
-    assert L.rk_bn_relu_backward_bf16(one, one, one, one, one, one, one, one, one, 4, 0, 16, 1, one, 1 << 20, None) == -2
+    assert L.rk_bn_relu_backward_bf16(one, one, one, one, one, one, None, one, one, one, 4, 0, 16, 1, one, 1 << 20, None) == -2
     assert L.rk_pw_gemm_f32(one, one, None, None, 4, 8, 8, 16, 1, None) == -1
     assert L.rk_pw_gemm_f32(one, one, None, one, 4, 8, 8, 49, 1, None) == -2    # P % 4 != 0
     assert L.rk_pw_gemm_f32(one, one, None, one, 4, 7, 8, 16, 1, None) == -2    # odd K

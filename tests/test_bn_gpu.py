@@ -143,3 +143,25 @@ def test_block_matches_stock_batchnorm(monkeypatch):
         outs.append((y.detach(), xi.grad, blk.bn2.weight.grad, blk.bn1.running_var.clone()))
     for a, b in zip(*outs):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_skip_gradient_is_added_inside_the_bn_backward():
+    """bn_relu_skip: (relu(bn(x)), alias of x); the alias' gradient joins d(x) inside the BN backward kernel."""
+    from rubiksnet_amd.fused_bn import bn_relu_skip
+
+    x, dy, bn = _make((6, 10, 12, 12), seed=11)
+    g = torch.Generator().manual_seed(12)
+    dskip = torch.randn(x.shape, generator=g)
+    ref = copy.deepcopy(bn).double().train()
+    xr = x.double().requires_grad_(True)
+    yr = F.relu(ref(xr))
+    (yr * dy.double()).sum().backward(retain_graph=True)
+    (xr * dskip.double()).sum().backward()
+    dev = copy.deepcopy(bn).cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    y, skip = bn_relu_skip(dev, xd)
+    assert "BNReLUTrain" in type(skip.grad_fn).__name__
+    ((y * dy.cuda()).sum() + (skip * dskip.cuda()).sum()).backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=0, atol=2e-5 * float(xr.grad.abs().max()))
+    np.testing.assert_allclose(dev.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
