@@ -71,7 +71,7 @@ class _Conv1x1Func(torch.autograd.Function):
     d(weight) is the HIP kernel either way (it wins on every shape: MIOpen's needs two layout transposes)."""
 
     @staticmethod
-    def forward(ctx, x, weight, hip_gemm, residual):
+    def forward(ctx, x, weight, hip_gemm, residual, hip_dx=None):
         Fr, Cin, H, W = x.shape
         Cout = weight.shape[0]
         if hip_gemm:
@@ -82,7 +82,7 @@ class _Conv1x1Func(torch.autograd.Function):
             if residual is not None:
                 y.add_(residual)
         ctx.save_for_backward(x, weight)
-        ctx.hip_gemm = hip_gemm
+        ctx.hip_dx = hip_gemm if hip_dx is None else hip_dx
         ctx.has_residual = residual is not None
         return y
 
@@ -94,7 +94,7 @@ class _Conv1x1Func(torch.autograd.Function):
             dy = dy.to(x.dtype)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            if ctx.hip_gemm:
+            if ctx.hip_dx:
                 Fr, Cin, H, W = x.shape
                 dx = torch.empty_like(x)
                 _gemm(weight, dy, dx, Fr, weight.shape[0], Cin, H * W, False)     # W read as [K=Cout][M=Cin]
@@ -103,7 +103,7 @@ class _Conv1x1Func(torch.autograd.Function):
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dy, x, weight)
-        return dx, dw, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None)
+        return dx, dw, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None), None
 
 
 def _eligible(conv, x, has_residual=False):
@@ -128,8 +128,10 @@ def _eligible(conv, x, has_residual=False):
     if x.dtype == torch.bfloat16:                        # bf16-MFMA GEMM: 43 vs 137 us at 56x56, 32 vs 80 us at 28x28
         cmax = int(os.environ.get("RK_PW_BF16_CMAX", "128"))
         return P >= 784 and K <= cmax and M <= cmax
-    p_min = 784 if has_residual else 3136
-    return P >= p_min and K <= 128 and M <= 128
+    cmax = int(os.environ.get("RK_PW_F32_CMAX28", "160"))
+    if P >= 3136:
+        return K <= 128 and M <= 128
+    return P >= 784 and K <= cmax and M <= cmax       # 28x28: 108 ch ties MIOpen (77 vs 76 us), 144 ch wins (191 vs 215)
 
 
 def conv1x1(conv, x, residual=None):
@@ -140,7 +142,11 @@ def conv1x1(conv, x, residual=None):
         if residual is not None:
             y += residual
         return y
-    return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual)
+    # d(input) alone also wins one step wider: 144 channels at 28x28 (Large): 194 vs MIOpen's 363 us
+    P = x.shape[2] * x.shape[3]
+    hip_dx = hip_gemm or (x.dtype == torch.float32 and pointwise_mode() == "auto" and P >= 784
+                          and max(conv.in_channels, conv.out_channels) <= 160)
+    return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual, hip_dx)
 
 
 # ---------------------------------------------------------------------------------------------------------------
