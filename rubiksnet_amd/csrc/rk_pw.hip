@@ -816,7 +816,10 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
     d.Cin = d.Hin = d.Win = d.Wo = 0;
     static const int wm_env = [] { const char* e = getenv("RK_PW_WM"); return e ? atoi(e) : 0; }();
-    int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
+    // rows per workgroup tile = 64 wm.  Above 128 rows 64-row tiles win although the streamed operand is then
+    // re-read once per tile (L2 / Infinity Cache absorb it; 288 rows: 101 us against 141 / 179 us with 128 / 256-row
+    // tiles, which also pad 288 to 384 / 512)
+    int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
     if (wm_env == 1 || wm_env == 2 || wm_env == 4) wm = wm_env;
     d.WM = wm; d.WN = 4 / wm;
     const int mt = 64 * wm;
