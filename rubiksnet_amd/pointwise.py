@@ -191,7 +191,7 @@ def _plain_1x1(conv, x):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
             and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
-            and conv.in_channels <= 128 and conv.out_channels <= 128)
+            and max(conv.in_channels, conv.out_channels) <= int(os.environ.get("RK_FUSED_EVAL_CMAX", "320")))
 
 
 def _eval_bn(bn):
@@ -221,7 +221,8 @@ def fused_eval_block(block, x):
         return None
     P = x.shape[2] * x.shape[3]
     identity = isinstance(block.shortcut, torch.nn.Identity)
-    if (P % 4 or P < 784 or not (_plain_1x1(block.conv2, x) and _plain_1x1(block.conv3, x))
+    if (P % 4 or P < int(os.environ.get("RK_FUSED_EVAL_PMIN", "196"))
+            or not (_plain_1x1(block.conv2, x) and _plain_1x1(block.conv3, x))
             or not (_eval_bn(block.bn1) and _eval_bn(block.bn2)) or not (identity or _plain_1x1(block.shortcut, x))
             or not _stride_one(block.as3)):
         return None
