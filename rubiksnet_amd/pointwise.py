@@ -133,8 +133,9 @@ def _eligible(conv, x, has_residual=False):
         return K <= 128 and M <= 128
     if P >= 784:
         return K <= cmax and M <= cmax                   # 28x28: 108 ch ties MIOpen (77 vs 76 us), 144 ch wins (123 vs 215)
-    # 14x14: a tie on its own (288 ch: 101 vs 106 us), a win when the residual add rides on the epilogue
-    return has_residual and P >= 196 and K <= int(os.environ.get("RK_PW_F32_CMAX14", "320")) and M <= 320
+    # 14x14: about a tie on its own (288 ch: 101 vs 106 us), a win when the residual add rides on the epilogue
+    c14 = int(os.environ.get("RK_PW_F32_CMAX14", "320"))
+    return P >= 196 and K <= c14 and M <= c14
 
 
 def conv1x1(conv, x, residual=None):
