@@ -139,7 +139,12 @@ def _eligible(conv, x, has_residual=False):
 
 
 def conv1x1(conv, x, residual=None):
-    """`conv(x)` (`conv(x) + residual` when a residual is given) for a 1x1 nn.Conv2d module."""
+    """`conv(x)` (`conv(x) + residual` when a residual is given) for a 1x1 nn.Conv2d module -- or an nn.Sequential
+    ending in one (the -aq variant prepends its AttentionShift to conv2, models.py:_prepare_backbone)."""
+    if isinstance(conv, torch.nn.Sequential) and len(conv) > 0 and isinstance(conv[-1], torch.nn.Conv2d):
+        for m in list(conv)[:-1]:
+            x = m(x)
+        conv = conv[-1]
     hip_gemm = _eligible(conv, x, residual is not None)
     if hip_gemm is None or (residual is not None and not (residual.is_contiguous() and residual.dtype == x.dtype)):
         y = conv(x)
