@@ -27,7 +27,7 @@ def _get_output_dim(orig, stride, padding):
 
 def compute_output_shape(x, stride, padding, shift_dim=_DIM):
     batch, C_in, H_in, W_in = x.size()
-    assert shift_dim == 2, "TODO"
+    assert shift_dim == 2, "only the 2-D shift is defined here (rubiks2d/primitive.py:15-27)"
     strides = make_tuple(stride, shift_dim)
     paddings = make_tuple(padding, shift_dim)
     return (batch, C_in, int(_get_output_dim(H_in, strides[0], paddings[0])),
