@@ -6,10 +6,16 @@
 
 A "step" is one forward + one backward of the operator over one batch of synthetic input,
 x [32, 8, 64, 56, 56] fp32 (layout [N,T,C,H,W]), stride 1, pad 0, normalize_grad on.
-Inputs are resident in HBM before the timed region.  For N > 1 (launched by torchrun, one rank
-per GPU) every rank runs the same per-GPU batch -- the path shards along clips with no
-data-path collective (weak scaling); `value` is the whole-job aggregate.  Rank 0 prints ONE
-JSON line.
+Inputs are resident in HBM before the timed region.  For N > 1 there is one rank per GPU (RCCL):
+either launched by `python -m torch.distributed.run ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or -- when WORLD_SIZE is not set -- bench.py re-executes
+itself under torch.distributed.run on 127.0.0.1.  Every rank runs the same per-GPU batch: the path
+shards along clips with no data-path collective (weak scaling); `value` is the whole-job aggregate.
+Rank 0 prints ONE JSON line.  `models` holds the model-level legs of BASELINE.json configs[2..4]
+(per-GPU share of the global batch; DDP all-reduce over RCCL for N > 1).
+
+Without a GPU (`--dry-run`, implied when torch.cuda is unavailable) only the launcher, the rendezvous,
+the barrier / max-over-ranks timing and the all-reduce probe run, on gloo: the product has no CPU path.
 """
 import argparse
 import json
@@ -175,26 +181,100 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
-def model_bench(env, tier, per_gpu_batch, steps, warmup):
+# (name, tier, variant, autocast dtype, what) -- BASELINE.json configs[2], [3], [4] + the metric's Tiny train step
+MODEL_LEGS = {
+    "tiny-train": ("tiny", "rubiks3d", None, "train"),
+    "tiny-fwd-b64": ("tiny", "rubiks3d", None, "forward"),          # configs[2]
+    "large-train": ("large", "rubiks3d", None, "train"),            # configs[3], per-GPU share of 256 / 8
+    "large-aq-bf16-train": ("large", "rubiks3d-aq", torch.bfloat16, "train"),   # configs[4]
+}
+
+
+def model_bench(env, leg, per_gpu_batch, steps, warmup):
     from rubiksnet_amd import RubiksNet
 
+    tier, variant, amp, what = MODEL_LEGS[leg]
     dev = env.device
     torch.manual_seed(0)
-    net = RubiksNet(tier, num_classes=174, num_frames=8, verbose=False).to(dev)
-    model = dp.wrap_ddp(net, env)
-    opt = dp.make_optimizer(model, lr=1e-3, kind="adam")
-    clips = torch.randn(per_gpu_batch, 8, 3, 224, 224, device=dev)
-    labels = torch.randint(0, 174, (per_gpu_batch,), device=dev)
-    model.train()
+    net = RubiksNet(tier, num_classes=174, num_frames=8, variant=variant, verbose=False).to(dev)
+    if what == "forward":
+        per_gpu_batch = 64
+        net.eval()
+        clips = torch.randn(per_gpu_batch, 8, 3, 224, 224, device=dev)
+
+        def step():
+            with torch.no_grad():
+                net(clips)
+        desc = "full forward (eval, no grad), fp32"
+    else:
+        model = dp.wrap_ddp(net, env)
+        opt = dp.make_optimizer(model, lr=1e-3, kind="adam")
+        clips = torch.randn(per_gpu_batch, 8, 3, 224, 224, device=dev)
+        labels = torch.randint(0, 174, (per_gpu_batch,), device=dev)
+        model.train()
+
+        def step():
+            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                dp.train_step(model, opt, clips, labels)
+        desc = "train step (fwd+bwd+Adam%s), %s" % (", DDP all-reduce" if env.distributed else "",
+                                                     "bf16 autocast" if amp is not None else "fp32")
     for _ in range(warmup):
-        dp.train_step(model, opt, clips, labels)
-    dt = dp.timed_region(env, lambda: dp.train_step(model, opt, clips, labels), steps)
+        step()
+    dt = dp.timed_region(env, step, steps)
     return {
-        "name": "rubiksnet-%s" % tier, "what": "train step (fwd+bwd+Adam), fp32, synthetic clips",
+        "name": "rubiksnet-%s%s" % (tier, "-aq" if variant.endswith("aq") else ""), "what": desc + ", synthetic clips",
         "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * env.world_size, "steps": steps,
         "ms_per_step": 1e3 * dt / steps, "clips_per_s": per_gpu_batch * env.world_size * steps / dt,
         "parallelism": "dp%d" % env.world_size,
     }
+
+
+def allreduce_probe(env, mbytes=34, iters=10):
+    """One gradient-sized all-reduce (RubiksNet-Large: 34 MB fp32) over the job's process group."""
+    import torch.distributed as dist
+
+    if not env.distributed:
+        return None
+    buf = torch.ones(mbytes * (1 << 20) // 4, dtype=torch.float32, device=env.device)
+    for _ in range(2):
+        dist.all_reduce(buf)
+    dt = dp.timed_region(env, lambda: dist.all_reduce(buf), iters) / iters
+    n = env.world_size
+    return {"bytes": buf.numel() * 4, "ms": 1e3 * dt, "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+            "bus_GBps": 2 * (n - 1) / n * buf.numel() * 4 / dt / 1e9}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no torchrun environment: re-execute under torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(env, args):
+    """No GPU: everything of the N-rank path that is not the product kernel."""
+    probe = allreduce_probe(env, mbytes=4, iters=3)
+    dt = dp.timed_region(env, lambda: None, args.steps)
+    if env.is_main:
+        print(json.dumps({
+            "metric": "RubiksShift3D fwd+bwd GB/s vs HBM roofline", "value": None, "unit": "GB/s",
+            "n_gpus": env.world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dry_run": True, "backend": env.backend, "rccl_ranks": env.world_size, "allreduce_probe": probe,
+            "empty_timed_region_s": dt,
+            "config": {"workload": "dry run on %s: launcher + rendezvous + barrier/max timing + all-reduce only "
+                                   "(the operator has no CPU path)" % env.backend},
+        }), flush=True)
 
 
 def main():
@@ -202,15 +282,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--model", default="tiny", help="tier for the model leg, or 'none'")
-    ap.add_argument("--model-batch", type=int, default=32, help="clips per GPU for the model leg")
-    ap.add_argument("--model-steps", type=int, default=8)
+    ap.add_argument("--models", default="tiny-train,tiny-fwd-b64,large-train,large-aq-bf16-train",
+                    help="comma list of model legs (%s) or 'none'" % ", ".join(MODEL_LEGS))
+    ap.add_argument("--model-batch", type=int, default=32, help="clips per GPU for the train-step legs")
+    ap.add_argument("--model-steps", type=int, default=6)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dry-run", action="store_true", help="no kernels: launcher / rendezvous / timing only (gloo)")
     args = ap.parse_args()
 
-    env = dp.init_distributed()
-    assert env.device.type == "cuda", "bench.py needs a GPU (no CPU fallback for the product path)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    dry = args.dry_run or not torch.cuda.is_available()
+    env = dp.init_distributed(prefer_gpu=not dry)
     assert env.world_size == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world_size)
+    if dry:
+        dry_run(env, args)
+        if env.distributed:
+            torch.distributed.destroy_process_group()
+        return
+    assert env.device.type == "cuda", "bench.py needs a GPU (no CPU fallback for the product path)"
 
     r = op_bench(env, args.steps, args.warmup)
     t_step = r["elapsed_s"] / args.steps
@@ -220,18 +311,22 @@ def main():
     fwd_gbs = r["bytes_fwd"] / (r["fwd_ms"] * 1e-3) / 1e9
     both_gbs = bytes_step / ((r["fwd_ms"] + r["bwd_ms"]) * 1e-3) / 1e9
 
-    model = None
-    if args.model != "none":
-        try:
-            model = model_bench(env, args.model, args.model_batch, args.model_steps, 3)
-        except Exception as exc:  # the op number must still be reported
-            model = {"error": repr(exc)}
+    models = {}
+    if args.models != "none":
+        for leg in args.models.split(","):
+            try:
+                models[leg] = model_bench(env, leg, args.model_batch, args.model_steps, 3)
+            except Exception as exc:  # the op number must still be reported
+                models[leg] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
+    probe = allreduce_probe(env)
 
     cpu = None
-    if env.is_main and env.world_size == 1 and not args.no_cpu:
+    if env.is_main and not args.no_cpu:      # after every timed GPU leg; the other ranks wait at the final barrier
         cpu = cpu_baseline()
+    dp.barrier(env)
 
-    traffic, traffic_src = pmc_traffic("k3d_dma_backward")
+    traffic, traffic_src = pmc_traffic("backward")
     rk2d = op2d_bench(env) if env.is_main else None
 
     if env.is_main:
@@ -264,7 +359,10 @@ def main():
             },
             "cpu_baseline": cpu,
             "rk2d": rk2d,
-            "model": model,
+            "model": models.get("tiny-train"),
+            "models": models,
+            "rccl_ranks": torch.distributed.get_world_size() if env.distributed else 1,
+            "allreduce_probe": probe,
         }
         print(json.dumps(out), flush=True)
     if env.distributed:

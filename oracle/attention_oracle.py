@@ -34,16 +34,20 @@ def taps_forward(x, soft, n_segment):
     return y.reshape(nt, c, h, w)
 
 
-def taps_backward(gy, x, soft, n_segment):
-    """Adjoint of taps_forward: returns (gx, gsoft[C,3])."""
+def taps_backward(gy, x, soft, n_segment, compute=np.float64):
+    """Adjoint of taps_forward: returns (gx, gsoft[C,3]).  `compute` is the arithmetic type of gx
+    (float32 reproduces the kernel's per-element expression (s1*g[t] + s0*g[t+1]) + s2*g[t-1] exactly;
+    fp addition is commutative, so this is the kernel's (s0*g[t+1] + s1*g[t]) + s2*g[t-1]);
+    the tap sums are always float64."""
     nt, c, h, w = x.shape
     n = nt // n_segment
     xv = x.reshape(n, n_segment, c, h, w).astype(np.float64)
     gv = gy.reshape(n, n_segment, c, h, w).astype(np.float64)
-    s = soft.astype(np.float64).reshape(1, 1, c, 3, 1, 1)
-    gx = s[:, :, :, 1] * gv
-    gx[:, :-1] += s[:, :, :, 0] * gv[:, 1:]
-    gx[:, 1:] += s[:, :, :, 2] * gv[:, :-1]
+    gc = gy.reshape(n, n_segment, c, h, w).astype(compute)
+    s = soft.astype(compute).reshape(1, 1, c, 3, 1, 1)
+    gx = s[:, :, :, 1] * gc
+    gx[:, :-1] += s[:, :, :, 0] * gc[:, 1:]
+    gx[:, 1:] += s[:, :, :, 2] * gc[:, :-1]
     gs = np.zeros((c, 3), dtype=np.float64)
     gs[:, 1] = (gv * xv).sum(axis=(0, 1, 3, 4))
     gs[:, 0] = (gv[:, 1:] * xv[:, :-1]).sum(axis=(0, 1, 3, 4))

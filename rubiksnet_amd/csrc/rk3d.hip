@@ -4,6 +4,7 @@
 #include "rk3d_generic.hpp"
 #include "rk3d_stream.hpp"
 #include "rk3d_dma.hpp"
+#include "rk3d_plane.hpp"
 #include "rk3d_column.hpp"
 
 #include <type_traits>
@@ -47,6 +48,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     if (int rc = make_dims(d, N, Tn, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if constexpr (std::is_same<T, float>::value) {
+        if (!quantize && plane3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
     }
     if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
@@ -81,6 +83,7 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
                 return launch_status();
             }
         } else if (!quantize && gx) {
+            if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
         }
     }

@@ -27,17 +27,29 @@ __device__ __forceinline__ void stream_store(float4* p, const float4& v) {
 // One wave-instruction of LDS-DMA, saddr form: lane l copies 16 B from (sbase + voff_l) to LDS byte
 // address lds_dst + 16*l.  The s_waitcnt lgkmcnt(0) orders it behind this wave's earlier LDS reads of
 // the slot being refilled (and covers the M0 write -> use hazard).
+template <bool NT = true>
 __device__ __forceinline__ void dma16s(const void* sbase_uniform, int voff, unsigned lds_dst_uniform) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "global_load_lds_dwordx4 %1, %2 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
-        : "memory");
+    if (NT)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
+            : "memory");
+    else   // default cache policy: the line stays in this XCD's L2 for a second reader (rk3d_plane.hpp)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
+            : "memory");
 }
 
 #define RK_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -126,12 +138,12 @@ __device__ __forceinline__ void make_bcells(BCells<ROUNDS>& cs, const BDims& d, 
 }
 
 // DMA the band of a tap plane (uniform pointer to slot cell 0's source, may lie before the plane) into a slot
-template <int ROUNDS>
+template <int ROUNDS, bool NT = true>
 __device__ __forceinline__ void dma_taps(const float* src0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
     const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i)
-        if (cs.in_act[i]) dma16s(src0, cs.off0 + 4096 * i, dst + 4096u * i);
+        if (cs.in_act[i]) dma16s<NT>(src0, cs.off0 + 4096 * i, dst + 4096u * i);
 }
 // zero the same cells instead (the plane lies outside [0, T))
 template <int ROUNDS>

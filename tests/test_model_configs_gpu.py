@@ -1,0 +1,247 @@
+"""GPU tests of the BASELINE.json model-level configs, with the shift operators checked against the
+oracle on the activations and gradients they actually see inside the network:
+
+  configs[2]  RubiksNet-Tiny (rubiks3d) full forward, batch 64                (2 clips of the batch checked)
+  configs[3]  RubiksNet-Large (rubiks3d) train step: forward + backward + Adam (per-GPU share of the DP batch)
+  configs[4]  RubiksNet-Large-AQ (rubiks3d-aq) under bf16 autocast, train step
+
+The taps sit on the drop-in boundary itself -- the six callables of rubiksnet_amd.rubiksnet_cuda
+(cuda_src/rubiks.cpp:384-396) and the temporal 3-tap autograd Function of AttentionShift -- so what is
+compared is exactly what librubiks_hip.so was handed and what it wrote.  Bars: y and d(x) bit-exact
+(fp32), or equal to the fp32 oracle on the widened inputs rounded once (bf16 storage); d(shift) / d(taps)
+against the oracle evaluated in fp64.  Reference call sites: rubiksnet/models.py:67-110,
+scripts/test_installation.py:6-10, scripts/example_finetune.py:85-97.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (C, H, stride_hw) of the 9 distinct RubiksShift3D call shapes per tier width
+def _expected_shapes(width):
+    w = width
+    return {(w, 112, 1), (w, 112, 2), (w, 56, 1), (2 * w, 56, 2), (2 * w, 28, 1), (4 * w, 28, 2), (4 * w, 14, 1),
+            (8 * w, 14, 2), (8 * w, 7, 1)}
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy() if t.dtype in (torch.bfloat16, torch.float16) else t.detach().cpu().numpy()
+
+
+class _Taps:
+    """Records the first call per distinct (shape, stride, dtype) at the binding level."""
+
+    def __init__(self, monkeypatch, keep_clips=None):
+        from rubiksnet_amd import rubiksnet_cuda as rc
+        from rubiksnet_amd.attention_shift import _TemporalShift3Func as TS
+
+        self.f3, self.b3, self.f2, self.b2, self.fa, self.ba = {}, {}, {}, {}, {}, {}
+        self.calls = dict(f3=0, b3=0, f2=0, b2=0, fa=0, ba=0)
+        k = keep_clips
+        f3, b3, f2, b2 = (rc.rubiks_shift_3d_forward_float, rc.rubiks_shift_3d_backward_float, rc.rubiks2d_forward,
+                          rc.rubiks2d_backward)
+        tsf, tsb = TS.forward, TS.backward
+        taps = self
+
+        def fwd3(input, shift, strides, paddings, quantize, output):
+            ret = f3(input, shift, strides, paddings, quantize, output)
+            taps.calls["f3"] += 1
+            key = (tuple(input.shape), tuple(strides))
+            if key not in taps.f3:
+                taps.f3[key] = dict(x=_np(input[:k]), shift=_np(shift), s=list(strides), p=list(paddings), q=bool(quantize),
+                                    y=_np(output[:k]))
+            return ret
+
+        def bwd3(input, shift, output_grad, strides, paddings, input_grad, shift_grad, normalize_grad,
+                 normalize_t_factor, quantize):
+            ret = b3(input, shift, output_grad, strides, paddings, input_grad, shift_grad, normalize_grad,
+                     normalize_t_factor, quantize)
+            taps.calls["b3"] += 1
+            key = (tuple(input.shape), tuple(strides))
+            if key not in taps.b3:
+                taps.b3[key] = dict(x=_np(input), shift=_np(shift), gy=_np(output_grad), s=list(strides), p=list(paddings),
+                                    q=bool(quantize), norm=bool(normalize_grad), tf=float(normalize_t_factor),
+                                    gx=None if input_grad is None else _np(input_grad),
+                                    gs=None if shift_grad is None else _np(shift_grad))
+            return ret
+
+        def fwd2(input, shift, strides, paddings, quantize, output):
+            ret = f2(input=input, shift=shift, strides=strides, paddings=paddings, quantize=quantize, output=output)
+            taps.calls["f2"] += 1
+            key = (tuple(input.shape), tuple(strides), input.dtype)
+            if key not in taps.f2:
+                taps.f2[key] = dict(x=input.detach().cpu(), shift=shift.detach().cpu(), s=list(strides), p=list(paddings),
+                                    q=bool(quantize), y=output.detach().cpu())
+            return ret
+
+        def bwd2(upstream_grad, input, shift, strides, paddings, normalize_grad, enable_shift_grad, quantize,
+                 input_grad, shift_grad):
+            ret = b2(upstream_grad=upstream_grad, input=input, shift=shift, strides=strides, paddings=paddings,
+                     normalize_grad=normalize_grad, enable_shift_grad=enable_shift_grad, quantize=quantize,
+                     input_grad=input_grad, shift_grad=shift_grad)
+            taps.calls["b2"] += 1
+            key = (tuple(input.shape), tuple(strides), input.dtype)
+            if key not in taps.b2:
+                taps.b2[key] = dict(x=input.detach().cpu(), shift=shift.detach().cpu(), gy=upstream_grad.detach().cpu(),
+                                    s=list(strides), p=list(paddings), q=bool(quantize), norm=bool(normalize_grad),
+                                    enable=bool(enable_shift_grad), gx=input_grad.detach().cpu(),
+                                    gs=shift_grad.detach().cpu())
+            return ret
+
+        def tfwd(ctx, x, soft, n_segment):
+            y = tsf(ctx, x, soft, n_segment)
+            taps.calls["fa"] += 1
+            key = (tuple(x.shape), x.dtype)
+            if key not in taps.fa:
+                taps.fa[key] = dict(x=x.detach().cpu(), soft=soft.detach().cpu(), S=int(n_segment), y=y.detach().cpu())
+            return y
+
+        def tbwd(ctx, gy):
+            out = tsb(ctx, gy)
+            taps.calls["ba"] += 1
+            x, soft = ctx.saved_tensors
+            key = (tuple(x.shape), x.dtype)
+            if key not in taps.ba:
+                taps.ba[key] = dict(x=x.detach().cpu(), soft=soft.detach().cpu(), S=int(ctx.n_segment), gy=gy.detach().cpu(),
+                                    gx=out[0].detach().cpu(), gsoft=out[1].detach().cpu())
+            return out
+
+        monkeypatch.setattr(rc, "rubiks_shift_3d_forward_float", fwd3)
+        monkeypatch.setattr(rc, "rubiks_shift_3d_backward_float", bwd3)
+        monkeypatch.setattr(rc, "rubiks2d_forward", fwd2)
+        monkeypatch.setattr(rc, "rubiks2d_backward", bwd2)
+        monkeypatch.setattr(TS, "forward", staticmethod(tfwd))
+        monkeypatch.setattr(TS, "backward", staticmethod(tbwd))
+
+
+def _check_3d_forward(oracle, rec, what):
+    for key, r in rec.items():
+        y_ref = oracle.rk3d_forward(r["x"], r["shift"], r["s"], r["p"], r["q"])
+        np.testing.assert_array_equal(r["y"], y_ref, err_msg="%s forward %s" % (what, key))
+
+
+def _check_3d_backward(oracle, rec, what):
+    for key, r in rec.items():
+        gx_ref, _ = oracle.rk3d_backward(r["gy"], r["x"], r["shift"], r["s"], r["p"], quantize=r["q"])
+        np.testing.assert_array_equal(r["gx"], gx_ref, err_msg="%s d(x) %s" % (what, key))
+        _, gs_ref = oracle.rk3d_backward(r["gy"].astype(np.float64), r["x"].astype(np.float64),
+                                         r["shift"].astype(np.float64), r["s"], r["p"], normalize_grad=r["norm"],
+                                         normalize_t_factor=r["tf"], quantize=r["q"])
+        assert r["norm"], "the model's shift layers normalise their gradient (K5)"
+        # per-channel unit vectors after K5: same absolute bar as tests/test_parity_3d.py
+        np.testing.assert_allclose(r["gs"], gs_ref, rtol=0, atol=2e-5, err_msg="%s d(shift) %s" % (what, key))
+
+
+def _snapshot(net, names):
+    return {n: p.detach().clone() for n, p in net.named_parameters() if n in names}
+
+
+def test_large_train_step_shift_layers_match_oracle(oracle, monkeypatch):
+    """configs[3], one replica's share: RubiksNet-Large forward + backward + Adam; every distinct RubiksShift3D
+    call shape (9 of them over 51 layers) is compared with the oracle, forward AND backward."""
+    from rubiksnet_amd import RubiksNet, dp
+
+    torch.manual_seed(0)
+    B = 4
+    net = RubiksNet("large", 174, verbose=False).to(DEV)
+    opt = dp.make_optimizer(net, lr=1e-3, lr_shift_mult=0.1, kind="adam")
+    watched = {"backbone.conv1.weight", "backbone.layer3.17.as3.rubiks3d.shift", "backbone.layer4.2.conv3.weight",
+               "new_fc.weight"}
+    before = _snapshot(net, watched)
+    assert set(before) == watched
+    taps = _Taps(monkeypatch)
+    clips = torch.randn(B, 8, 3, 224, 224, device=DEV)
+    labels = torch.randint(0, 174, (B,), device=DEV)
+    loss = dp.train_step(net, opt, clips, labels)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert taps.calls["f3"] == 51 and taps.calls["b3"] == 51 and taps.calls["f2"] == 0
+    want = {((B, 8, c, h, h), (1, s, s)) for c, h, s in _expected_shapes(72)}
+    assert set(taps.f3) == want and set(taps.b3) == want
+    _check_3d_forward(oracle, taps.f3, "large")
+    _check_3d_backward(oracle, taps.b3, "large")
+    after = _snapshot(net, watched)
+    for n in watched:                                   # the optimizer really stepped every kind of parameter
+        assert torch.isfinite(after[n]).all() and not torch.equal(after[n], before[n]), n
+    shifts = [p for n, p in net.named_parameters() if n.endswith("shift")]
+    assert len(shifts) == 51 and all(p.grad is not None and torch.isfinite(p.grad).all() for p in shifts)
+
+
+def test_tiny_forward_batch64_shift_layers_match_oracle(oracle, monkeypatch):
+    """configs[2]: RubiksNet-Tiny full forward at batch 64 (eval, no grad -> the fused inference blocks);
+    the first two clips of every distinct shift call are compared with the oracle (the operator is per clip)."""
+    from rubiksnet_amd import RubiksNet
+
+    torch.manual_seed(2)
+    net = RubiksNet("tiny", 174, verbose=False).to(DEV).eval()
+    taps = _Taps(monkeypatch, keep_clips=2)
+    with torch.no_grad():
+        out = net(torch.randn(64, 8, 3, 224, 224, device=DEV))
+    assert out.shape == (64, 174) and torch.isfinite(out).all()
+    assert taps.calls["f3"] == 17
+    assert {(k[0][2], k[0][3], k[1][1]) for k in taps.f3} == _expected_shapes(54)
+    assert all(k[0][0] == 64 for k in taps.f3)
+    _check_3d_forward(oracle, taps.f3, "tiny b64")
+
+
+def _rounded(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+@pytest.mark.parametrize("tier,amp", [("large", torch.bfloat16), ("tiny", None)])
+def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp):
+    """configs[4]: the attention-quantized variant (RubiksShift2D + AttentionShift per block), Large under bf16
+    autocast (and Tiny in fp32): train step with every distinct 2-D shift / temporal-tap call checked."""
+    from oracle import attention_oracle as ao
+    from rubiksnet_amd import RubiksNet, dp
+
+    torch.manual_seed(4)
+    B = 4
+    width = 72 if tier == "large" else 54
+    nblocks = 51 if tier == "large" else 17
+    net = RubiksNet(tier, 174, variant="rubiks3d-aq", verbose=False).to(DEV)
+    opt = dp.make_optimizer(net, lr=1e-3, kind="adam")
+    taps = _Taps(monkeypatch)
+    clips = torch.randn(B, 8, 3, 224, 224, device=DEV)
+    labels = torch.randint(0, 174, (B,), device=DEV)
+    with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+        loss = dp.train_step(net, opt, clips, labels)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert taps.calls == dict(f3=0, b3=0, f2=nblocks, b2=nblocks, fa=nblocks, ba=nblocks)
+    st = torch.bfloat16 if amp is not None else torch.float32
+    assert {(k[0][1], k[0][2], k[1][0]) for k in taps.f2} == _expected_shapes(width)
+    assert all(k[2] == st and k[0][0] == B * 8 for k in taps.f2) and set(taps.b2) == set(taps.f2)
+
+    for key, r in taps.f2.items():                     # ---- RubiksShift2D forward
+        xf, sf = r["x"].float().numpy(), r["shift"].float().numpy()
+        y_ref = oracle.rk2d_forward(xf, sf, r["s"], r["p"], r["q"])
+        assert torch.equal(r["y"], _rounded(y_ref, st)), "2-D forward %s" % (key,)
+    for key, r in taps.b2.items():                     # ---- RubiksShift2D backward
+        xf, sf, gf = r["x"].float().numpy(), r["shift"].float().numpy(), r["gy"].float().numpy()
+        gx_ref, _ = oracle.rk2d_backward(gf, xf, sf, r["s"], r["p"], quantize=r["q"])
+        assert torch.equal(r["gx"], _rounded(gx_ref, st)), "2-D d(x) %s" % (key,)
+        assert r["norm"] and r["enable"]
+        _, gs_ref = oracle.rk2d_backward(gf.astype(np.float64), xf.astype(np.float64), sf.astype(np.float64), r["s"],
+                                         r["p"], normalize_grad=True)
+        # unit vectors after K9; bf16 storage rounds them to 2^-9 relative
+        np.testing.assert_allclose(r["gs"].float().numpy(), gs_ref, rtol=0, atol=2e-5 if amp is None else 4e-3,
+                                   err_msg="2-D d(shift) %s" % (key,))
+
+    assert len(taps.fa) >= 8 and set(taps.fa) == set(taps.ba)
+    for key, r in taps.fa.items():                     # ---- AttentionShift taps, forward
+        assert r["x"].dtype == st and r["soft"].dtype == torch.float32
+        y_ref = ao.taps_forward(r["x"].float().numpy(), r["soft"].numpy(), r["S"])
+        assert torch.equal(r["y"], _rounded(y_ref, st)), "temporal taps forward %s" % (key,)
+    for key, r in taps.ba.items():                     # ---- AttentionShift taps, backward
+        xf, gf, soft = r["x"].float().numpy(), r["gy"].float().numpy(), r["soft"].numpy()
+        gx_ref, _ = ao.taps_backward(gf, xf, soft, r["S"], compute=np.float32)
+        assert torch.equal(r["gx"], _rounded(gx_ref, st)), "temporal taps d(x) %s" % (key,)
+        _, gs_ref = ao.taps_backward(gf, xf, soft, r["S"])
+        scale = float(np.abs(gs_ref).max())
+        np.testing.assert_allclose(r["gsoft"].double().numpy(), gs_ref, rtol=0, atol=1e-3 * scale,
+                                   err_msg="temporal taps d(taps) %s" % (key,))
+    att = [p for n, p in net.named_parameters() if n.endswith("conv2.0.weight")]
+    assert len(att) == nblocks and all(p.grad is not None and torch.isfinite(p.grad).all() for p in att)
