@@ -40,7 +40,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def op_bench(env, steps, warmup, nsets=3):
+def op_bench(env, steps, warmup, nsets=3, settle_s=0.4):
     dev = env.device
     N, T, C, H, W = SHAPE
     numel = N * T * C * H * W
@@ -74,6 +74,16 @@ def op_bench(env, steps, warmup, nsets=3):
             e[2].record()
             events.append(e)
 
+    # The chip enters from a low-power state (sclk 95 MHz idle) and its power management needs a few hundred
+    # milliseconds of continuous load to settle: the first ~10 ms run FASTER-then-SLOWER than steady state
+    # (profiles/r02_sustained.txt: 183 -> 201 us/step inside the first 60 steps, 179.0 +- 0.3 us/step from 20 ms
+    # on, for seconds).  K = 20..50 timed steps are only 4..10 ms, so without this they would measure the
+    # transient.  Untimed, before the W warm-up steps.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < settle_s:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     # The K timed steps run bare: three event records per step inside the bracket cost ~15 us/step (7%) of
@@ -287,6 +297,8 @@ def main():
     ap.add_argument("--model-batch", type=int, default=32, help="clips per GPU for the train-step legs")
     ap.add_argument("--model-steps", type=int, default=6)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--settle", type=float, default=0.4,
+                    help="seconds of untimed continuous load before the warm-up steps (clock / power settle)")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: launcher / rendezvous / timing only (gloo)")
     args = ap.parse_args()
 
@@ -303,7 +315,7 @@ def main():
         return
     assert env.device.type == "cuda", "bench.py needs a GPU (no CPU fallback for the product path)"
 
-    r = op_bench(env, args.steps, args.warmup)
+    r = op_bench(env, args.steps, args.warmup, settle_s=args.settle)
     t_step = r["elapsed_s"] / args.steps
     bytes_step = r["bytes_fwd"] + r["bytes_bwd"]
     value = env.world_size * bytes_step / t_step / 1e9
@@ -342,6 +354,7 @@ def main():
                 "per_gpu_batch": SHAPE[0], "global_batch": SHAPE[0] * env.world_size,
                 "parallelism": "dp%d (clips sharded, no data-path collective)" % env.world_size,
                 "algorithmic_bytes_per_step": bytes_step,
+                "settle_s": args.settle,
             },
             "clips_per_s": env.world_size * SHAPE[0] / t_step,
             "frac_of_hbm_peak": value / env.world_size / HBM_PEAK_GBS,   # per GPU, from the wall-clock value

@@ -17,47 +17,25 @@ from .shiftlib import RubiksShift2D, RubiksShiftBase
 __all__ = ["RubiksNetBackbone", "RubiksShiftBlock", "SELayer"]
 
 
-def _skip_global_init(m):
-    return getattr(m, "skip_global_init", False)
+def _pointwise(c_in, c_out, stride=1):
+    return nn.Conv2d(c_in, c_out, kernel_size=1, stride=stride, bias=False)
 
 
-def conv2d_init(m):
-    """He-normal on fan-out (backbone.py:14-19)."""
-    assert isinstance(m, nn.Conv2d)
-    if _skip_global_init(m):
-        return
-    fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-    nn.init.normal_(m.weight, 0, math.sqrt(2.0 / fan_out))
+def _unit_bn(channels):
+    return nn.BatchNorm2d(channels)          # weight 1 / bias 0 is nn.BatchNorm2d's own initial state
 
 
-def norm_layer_init(m, weight_init=1.0):
-    assert isinstance(weight_init, (int, float))
-    assert isinstance(m, (nn.BatchNorm2d, nn.GroupNorm))
-    nn.init.constant_(m.weight, weight_init)
-    nn.init.constant_(m.bias, 0)
+def _he_fan_out_(conv):
+    """N(0, sqrt(2 / (k*k*C_out))) -- the reference's conv init (backbone.py:14-19)."""
+    kh, kw = conv.kernel_size
+    nn.init.normal_(conv.weight, mean=0.0, std=math.sqrt(2.0 / (kh * kw * conv.out_channels)))
 
 
-def conv_bn_init_module(net):
-    assert isinstance(net, nn.Module)
-    for m in net.modules():
-        if isinstance(m, nn.Conv2d):
-            conv2d_init(m)
-        elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
-            norm_layer_init(m, weight_init=1.0)
-
-
-def Conv3x3(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
-
-
-def Conv1x1(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
-
-
-def BN2d(planes, weight_init=1.0):
-    bn = nn.BatchNorm2d(planes)
-    norm_layer_init(bn, weight_init)
-    return bn
+# what `RubiksNetBackbone._reset_parameters` does per module type; a module opts out with `skip_global_init = True`
+_INITIALISERS = (
+    (nn.Conv2d, _he_fan_out_),
+    ((nn.BatchNorm2d, nn.GroupNorm), lambda m: (nn.init.ones_(m.weight), nn.init.zeros_(m.bias))),
+)
 
 
 class SELayer(nn.Module):
@@ -86,31 +64,24 @@ class RubiksShiftBlock(nn.Module):
         super().__init__()
         mid_planes = int(out_planes * parent.expansion)
         self.relu = nn.ReLU(inplace=True)
-        self.bn1 = BN2d(in_planes)
-        self.conv2 = Conv1x1(in_planes, mid_planes)
-        self.bn2 = BN2d(mid_planes)
-        self.as3 = RubiksShift2D(
-            mid_planes,
-            stride=stride,
-            normalize_grad=parent.normalize_grad,
-            quantize=parent.quantize,
-            init_shift=parent.init_shift,
-        )
-        use_se = parent.use_se
-        if use_se:
-            if isinstance(use_se, bool):
-                reduction = 12
-            else:
-                assert use_se > 2, ("SE reduction must > 2", use_se)
-                reduction = use_se
-            self.se = SELayer(mid_planes, reduction=reduction)
-        else:
-            self.se = None
-        self.conv3 = Conv1x1(mid_planes, out_planes)
-        if stride != 1 or in_planes != out_planes:
-            self.shortcut = Conv1x1(in_planes, out_planes, stride=stride)
-        else:
-            self.shortcut = nn.Identity()
+        self.bn1 = _unit_bn(in_planes)
+        self.conv2 = _pointwise(in_planes, mid_planes)
+        self.bn2 = _unit_bn(mid_planes)
+        self.as3 = RubiksShift2D(mid_planes, stride=stride, normalize_grad=parent.normalize_grad,
+                                 quantize=parent.quantize, init_shift=parent.init_shift)
+        self.se = self._make_se(mid_planes, parent.use_se)
+        self.conv3 = _pointwise(mid_planes, out_planes)
+        projects = stride != 1 or in_planes != out_planes
+        self.shortcut = _pointwise(in_planes, out_planes, stride=stride) if projects else nn.Identity()
+
+    @staticmethod
+    def _make_se(channels, use_se):
+        """`use_se`: falsy -> no gate; True -> the default reduction 12; an int -> that reduction (must exceed 2)."""
+        if not use_se:
+            return None
+        reduction = 12 if use_se is True else int(use_se)
+        assert reduction > 2, ("SE reduction must > 2", use_se)
+        return SELayer(channels, reduction=reduction)
 
     def forward(self, x):
         if not self.training:               # inference: BNs and the residual add ride on the two 1x1 GEMMs
@@ -141,7 +112,7 @@ class RubiksNetBackbone(nn.Module):
         self.use_se = use_se
         self.quantize = quantize
         self.normalize_grad = normalize_grad
-        self.conv1 = Conv3x3(3, self.inplanes, stride=2)
+        self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=3, stride=2, padding=1, bias=False)
 
         # (planes multiplier, #blocks, stride of the first block) per stage -- backbone.py:158-165
         self.layer0 = self._make_layer(RubiksShiftBlock, width, 1, stride=1)
@@ -151,12 +122,19 @@ class RubiksNetBackbone(nn.Module):
         self.layer4 = self._make_layer(RubiksShiftBlock, 8 * width, repeats[3], stride=2)
 
         self.relu = nn.ReLU(inplace=True)
-        self.bn_last = BN2d(8 * width)
+        self.bn_last = _unit_bn(8 * width)
         self.avgpool = nn.AvgPool2d(7, stride=1)
         self.fc = nn.Linear(8 * width, num_classes)
+        self._reset_parameters()
 
-        conv_bn_init_module(self)
-        self.fc.weight.data.normal_(0, 0.01)
+    def _reset_parameters(self):
+        for module in self.modules():
+            if getattr(module, "skip_global_init", False):
+                continue
+            for types, init in _INITIALISERS:
+                if isinstance(module, types):
+                    init(module)
+        nn.init.normal_(self.fc.weight, 0.0, 0.01)
 
     def _make_layer(self, block, planes, repeat, stride):
         blocks = [block(self.inplanes, planes, stride=stride, parent=self)]
@@ -172,24 +150,28 @@ class RubiksNetBackbone(nn.Module):
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))
 
+    # parameter-group rules: (group name, module types, which of the module's parameters, lr_mult key, decay_mult)
+    _POLICY = (
+        ("weight", (nn.Conv2d, nn.Conv3d, nn.Linear), "weight", 1),
+        ("bias", (nn.Conv2d, nn.Conv3d, nn.Linear), "bias", 0),
+        ("bn", (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d), None, 0),
+        ("shift", (RubiksShift2D, RubiksShiftBase), None, 0),
+    )
+
     def get_optim_policy(self, shift_lr_mult=0.01):
-        """Parameter groups with per-group lr / weight-decay multipliers (backbone.py:202-235)."""
-        weight, bias, bn, shift = [], [], [], []
-        for m in self.modules():
-            if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.Linear)):
-                ps = list(m.parameters())
-                weight.append(ps[0])
-                if len(ps) == 2:
-                    bias.append(ps[1])
-            elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
-                bn.extend(m.parameters())
-            elif isinstance(m, (RubiksShift2D, RubiksShiftBase)):
-                shift.extend(m.parameters())
-            elif len(m._modules) == 0 and len(list(m.parameters())) > 0:
-                raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(m)))
-        return [
-            {"params": weight, "lr_mult": 1, "decay_mult": 1, "name": "weight"},
-            {"params": bias, "lr_mult": 1, "decay_mult": 0, "name": "bias"},
-            {"params": bn, "lr_mult": 1, "decay_mult": 0, "name": "bn"},
-            {"params": shift, "lr_mult": shift_lr_mult, "decay_mult": 0, "name": "shift"},
-        ]
+        """Optimizer parameter groups `weight` / `bias` / `bn` / `shift` with `lr_mult` and `decay_mult` entries
+        (same groups, order and multipliers as the reference, backbone.py:202-235): only weights decay, shifts
+        train at `shift_lr_mult` of the base rate.  A parameter-owning leaf module of an unknown type is an error."""
+        groups = {name: [] for name, *_ in self._POLICY}
+        for module in self.modules():
+            own = dict(module.named_parameters(recurse=False))
+            if not own:
+                continue
+            rules = [r for r in self._POLICY if isinstance(module, r[1])]
+            if not rules:
+                raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(module)))
+            for name, _, attr, _ in rules:
+                groups[name] += [p for k, p in own.items() if attr is None or k == attr]
+        lr_mult = {"shift": shift_lr_mult}
+        return [{"params": groups[name], "lr_mult": lr_mult.get(name, 1), "decay_mult": decay, "name": name}
+                for name, _, _, decay in self._POLICY]

@@ -230,7 +230,10 @@ def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp)
         np.testing.assert_allclose(r["gs"].float().numpy(), gs_ref, rtol=0, atol=2e-5 if amp is None else 4e-3,
                                    err_msg="2-D d(shift) %s" % (key,))
 
-    assert len(taps.fa) >= 8 and set(taps.fa) == set(taps.ba)
+    # AttentionShift sits in front of conv2: block inputs (C, H) = (w,112), (w,56), (2w,28), (4w,14), (8w,7)
+    assert {(k[0][1], k[0][2]) for k in taps.fa} == {(width, 112), (width, 56), (2 * width, 28), (4 * width, 14),
+                                                     (8 * width, 7)}
+    assert set(taps.fa) == set(taps.ba)
     for key, r in taps.fa.items():                     # ---- AttentionShift taps, forward
         assert r["x"].dtype == st and r["soft"].dtype == torch.float32
         y_ref = ao.taps_forward(r["x"].float().numpy(), r["soft"].numpy(), r["S"])
