@@ -5,6 +5,7 @@
 #include "rk3d_stream.hpp"
 #include "rk3d_dma.hpp"
 #include "rk3d_plane.hpp"
+#include "rk3d_tile.hpp"
 #include "rk3d_column.hpp"
 
 #include <type_traits>
@@ -50,6 +51,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && plane3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
+        if (!quantize && tile3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
     }
     if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
     if (col3d::supported(d, quantize)) return col3d::launch_forward<T>(x, shift, y, d, stream);
@@ -82,9 +84,15 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
                                    d.C, P, normalize_grad, t_factor);
                 return launch_status();
             }
+            if (const int P = tile3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) {
+                hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const float*)ws, gshift,
+                                   d.C, P, normalize_grad, t_factor);
+                return launch_status();
+            }
         } else if (!quantize && gx) {
             if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
+            if (tile3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
         }
     }
     if (stream3d::backward_supported<T>(d, quantize, x, gy, gx))

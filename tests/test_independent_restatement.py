@@ -28,6 +28,8 @@ SHAPES3 = [
     (1, 4, 3, 112, 112, (1, 1, 1), (0, 0, 0)),
     (1, 3, 2, 96, 64, (1, 1, 1), (0, 0, 0)),
     (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)),
+    (2, 4, 24, 7, 7, (1, 1, 1), (0, 0, 0)),
+    (3, 5, 6, 14, 14, (1, 1, 1), (0, 0, 0)),
 ]
 KINDS3 = ["generic", "wide", "integer", "half", "oob"]
 SHAPES2 = [

@@ -26,6 +26,8 @@ SHAPES = [
     (1, 4, 3, 112, 112, (1, 1, 1), (0, 0, 0)),     # 112x112 stride 1: 4 row bands on the streaming path
     (1, 3, 2, 96, 64, (1, 1, 1), (0, 0, 0)),       # 4 bands of 24 rows, 16 float4 columns
     (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)),       # one band, ragged last round
+    (2, 4, 24, 7, 7, (1, 1, 1), (0, 0, 0)),        # tile kernels: 7x7, channel groups of 16 + 8
+    (3, 5, 6, 14, 14, (1, 1, 1), (0, 0, 0)),       # tile kernels: 14x14, channel groups of 4 + 2, odd T
 ]
 KINDS = ["generic", "wide", "integer", "half", "oob"]
 
