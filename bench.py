@@ -54,7 +54,6 @@ def op_bench(env, steps, warmup, nsets=3, settle_s=0.4):
     gshift = torch.empty(3, C, device=dev)
     s1, p0 = [1, 1, 1], [0, 0, 0]
     it = [0]
-    events = []
 
     def step(record=False):
         # forward on set i, backward on set i+1: the backward's x was last touched two launches (>= 0.8 GB of
@@ -63,16 +62,8 @@ def op_bench(env, steps, warmup, nsets=3, settle_s=0.4):
         x, _, y, _ = sets[it[0] % nsets]
         xb, gy, _, gx = sets[(it[0] + 1) % nsets]
         it[0] += 1
-        if record:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record()
         rubiksnet_cuda.rubiks_shift_3d_forward_float(x, shift, s1, p0, False, y)
-        if record:
-            e[1].record()
         rubiksnet_cuda.rubiks_shift_3d_backward_float(xb, shift, gy, s1, p0, gx, gshift, True, 1.0, False)
-        if record:
-            e[2].record()
-            events.append(e)
 
     # The chip enters from a low-power state (sclk 95 MHz idle) and its power management needs a few hundred
     # milliseconds of continuous load to settle: the first ~10 ms run FASTER-then-SLOWER than steady state
@@ -86,15 +77,33 @@ def op_bench(env, steps, warmup, nsets=3, settle_s=0.4):
         torch.cuda.synchronize()
     for _ in range(warmup):
         step()
-    # The K timed steps run bare: three event records per step inside the bracket cost ~15 us/step (7%) of
-    # marker packets (tools/launch_gap_probe.py).  Per-kernel durations come from a second pass of the same K
-    # steps with HIP events on the launch stream, right after the bracket closes.
+    # The K timed steps run bare.  Per-kernel launch durations come from two more passes of the same K launches
+    # right after the bracket closes -- K forwards, then K backwards (+ finalize), each pass bracketed by ONE pair of
+    # HIP events on the launch stream: event records between the kernels of a step cost ~15 us/step of marker
+    # packets and idle gaps (tools/launch_gap_probe.py), which also changes the clock regime being measured.
     elapsed = dp.timed_region(env, lambda: step(False), steps)
-    for _ in range(steps):
-        step(True)
-    torch.cuda.synchronize()
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
-    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
+
+    def kernel_pass(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    def fwd_only():
+        x, _, y, _ = sets[it[0] % nsets]
+        it[0] += 1
+        rubiksnet_cuda.rubiks_shift_3d_forward_float(x, shift, s1, p0, False, y)
+
+    def bwd_only():
+        xb, gy, _, gx = sets[it[0] % nsets]
+        it[0] += 1
+        rubiksnet_cuda.rubiks_shift_3d_backward_float(xb, shift, gy, s1, p0, gx, gshift, True, 1.0, False)
+
+    fwd_ms = kernel_pass(fwd_only)
+    bwd_ms = kernel_pass(bwd_only)
     return {
         "elapsed_s": elapsed, "numel": numel, "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
         "bytes_fwd": 8 * numel, "bytes_bwd": 12 * numel,
@@ -161,6 +170,7 @@ def cpu_baseline(budget_s=12.0):
     from oracle import oracle as orc
 
     orc.build()
+    native = orc.use_native()                     # -march=native build for this host's cores
     threads = os.cpu_count() or 1
     orc.set_threads(threads)
     _, T, C, H, W = SHAPE
@@ -185,8 +195,10 @@ def cpu_baseline(budget_s=12.0):
     bytes_total = 20 * n * T * C * H * W
     return {
         "value": bytes_total / dt / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
-        "sample": "%d clips of [8,64,56,56] fp32 fwd+bwd (same shift/stride/pad as the GPU run), oracle/librubiks_oracle.so, %d OpenMP threads, %.2f s"
-                  % (n, threads, dt),
+        "sample": "%d clips of [8,64,56,56] fp32 fwd+bwd (same shift/stride/pad as the GPU run), oracle C restatement "
+                  "(-O3 %s, OpenMP over (n,t) planes forward / (c,row) backward), %d threads, %.2f s"
+                  % (n, "-march=native" if native else "-march=x86-64-v3", threads, dt),
+        "threads_effective": threads,
         "clips_per_s": n / dt,
     }
 
@@ -195,6 +207,7 @@ def cpu_baseline(budget_s=12.0):
 MODEL_LEGS = {
     "tiny-train": ("tiny", "rubiks3d", None, "train"),
     "tiny-fwd-b64": ("tiny", "rubiks3d", None, "forward"),          # configs[2]
+    "small-train": ("small", "rubiks3d", None, "train"),            # the SE tier (fused squeeze / scale)
     "large-train": ("large", "rubiks3d", None, "train"),            # configs[3], per-GPU share of 256 / 8
     "large-aq-bf16-train": ("large", "rubiks3d-aq", torch.bfloat16, "train"),   # configs[4]
 }
@@ -237,6 +250,26 @@ def model_bench(env, leg, per_gpu_batch, steps, warmup):
         "ms_per_step": 1e3 * dt / steps, "clips_per_s": per_gpu_batch * env.world_size * steps / dt,
         "parallelism": "dp%d" % env.world_size,
     }
+
+
+def feeder_bench(env, batch=32, iters=12):
+    """the synthetic feeder alone -- pinned uint8 clips -> H2D on a side stream -> the device
+    transform (transpose + /255 + normalise) -- and the transform kernel by itself."""
+    from rubiksnet_amd.input_pipeline import SyntheticClipLoader, stacked_u8_to_clips
+
+    loader = SyntheticClipLoader(batch=batch, device=env.device)
+    it = iter(loader)
+    for _ in range(3):
+        next(it)
+    dt = dp.timed_region(env, lambda: next(it), iters)
+    u8 = torch.randint(0, 256, (batch, 224, 224, 24), dtype=torch.uint8, device=env.device)
+    out = torch.empty(batch, 24, 224, 224, device=env.device)
+    for _ in range(3):
+        stacked_u8_to_clips(u8, 8, out=out)
+    dk = dp.timed_region(env, lambda: stacked_u8_to_clips(u8, 8, out=out), iters) / iters
+    return {"clips_per_s": batch * env.world_size * iters / dt, "per_gpu_batch": batch,
+            "what": "pinned uint8 [B,224,224,24] -> H2D (side stream) -> transform, double buffered",
+            "transform_us": 1e6 * dk, "transform_GBps": 5 * u8.numel() / dk / 1e9}
 
 
 def allreduce_probe(env, mbytes=34, iters=10):
@@ -292,7 +325,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--models", default="tiny-train,tiny-fwd-b64,large-train,large-aq-bf16-train",
+    ap.add_argument("--models", default="tiny-train,tiny-fwd-b64,small-train,large-train,large-aq-bf16-train",
                     help="comma list of model legs (%s) or 'none'" % ", ".join(MODEL_LEGS))
     ap.add_argument("--model-batch", type=int, default=32, help="clips per GPU for the train-step legs")
     ap.add_argument("--model-steps", type=int, default=6)
@@ -332,6 +365,10 @@ def main():
                 models[leg] = {"error": repr(exc)}
             torch.cuda.empty_cache()
     probe = allreduce_probe(env)
+    try:
+        feeder = feeder_bench(env)
+    except Exception as exc:
+        feeder = {"error": repr(exc)}
 
     cpu = None
     if env.is_main and not args.no_cpu:      # after every timed GPU leg; the other ranks wait at the final barrier
@@ -363,8 +400,8 @@ def main():
                 "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": r["bwd_ms"], "algorithmic_bytes": r["bytes_bwd"],
-                "kernel_timing": "HIP events on the launch stream over a second pass of the same K steps "
-                                 "(event records inside the wall-clock bracket cost ~15 us/step)",
+                "kernel_timing": "HIP events on the launch stream: K back-to-back launches of this kernel (rotating "
+                                 "buffer sets) between one pair of events, right after the wall-clock bracket",
                 "forward": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS, "avg_launch_ms": r["fwd_ms"],
                             "algorithmic_bytes": r["bytes_fwd"]},
                 "fwd_plus_bwd": {"achieved": both_gbs, "frac": both_gbs / HBM_PEAK_GBS,
@@ -374,6 +411,7 @@ def main():
             "rk2d": rk2d,
             "model": models.get("tiny-train"),
             "models": models,
+            "input_pipeline": feeder,
             "rccl_ranks": torch.distributed.get_world_size() if env.distributed else 1,
             "allreduce_probe": probe,
         }

@@ -30,6 +30,9 @@
  *     (the reference's gpuAssert does, rubiks3d_kernels.cu:963-971).  The reference's
  *     Python asserts `ret == 0` (rubiks3d/primitive.py:79,139).
  *   - re-entrant, no global mutable state; safe from autograd worker threads.
+ *   - ONE environment switch, read once per process: RK_SHIFT_KERNELS = auto | column | generic selects which
+ *     kernel families the shift operators may use (rk_common.hpp; every family is bit-identical for y and d(x),
+ *     tests/test_fallback_paths_gpu.py).  RK_FORCE_GENERIC=1 is the older spelling of `generic`.
  */
 #ifndef RUBIKS_HIP_H_
 #define RUBIKS_HIP_H_
@@ -215,6 +218,31 @@ int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, in
                     size_t ws_bytes, rk_stream_t stream);
 int rk_pw_wgrad_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws,
                      size_t ws_bytes, rk_stream_t stream);
+
+/* ---- input side of the network on the device -- widening row f4 of SURVEY 8(f) ----------------------
+ * Replaces, per batch instead of per sample on CPU workers, the reference's transform tail
+ * Stack -> ToTorchFormatTensor(div=True) -> GroupNormalize (rubiksnet/transforms.py:329-363, :66-79; wired up
+ * in scripts/test_models.py:136-143): hwc [nclips, H, W, CS] uint8 (CS = 3 * frames, channel-interleaved RGB
+ * frames as Stack(roll=False) lays them out) -> chw [nclips, CS, H, W],
+ * ((v / 255) - mean3[c % 3]) / std3[c % 3], every step rounded in fp32 as the reference's tensor ops round it
+ * (the f32 result is bit-identical); H * W * CS % 16 == 0, hwc 16-byte aligned.                              */
+int rk_clip_u8_to_chw_f32(const unsigned char* hwc, const float* mean3, const float* std3, float* chw, int nclips,
+                          int H, int W, int CS, rk_stream_t stream);
+int rk_clip_u8_to_chw_bf16(const unsigned char* hwc, const float* mean3, const float* std3, void* chw, int nclips,
+                           int H, int W, int CS, rk_stream_t stream);
+
+/* ---- squeeze-and-excitation gate of RubiksNet-Small -- widening row f3 of SURVEY 8(f) --------------
+ * SELayer (rubiksnet/backbone.py:56-71): y = x * sigmoid(W2 relu(W1 mean_hw(x))).  x, y, dy, dx [F, C, P];
+ * mean / gate / dgate [F, C] f32.  squeeze: mean over P; scale: y = x * gate; scale_backward: dx = dy * gate and
+ * dgate = sum_p dy * x in one pass (the caller adds the squeeze's share dmean / P to dx through autograd).      */
+#define RK_DECL_SE(SFX)                                                                                       \
+    int rk_se_squeeze_##SFX(const void* x, float* mean, int F, int C, int P, rk_stream_t stream);             \
+    int rk_se_scale_##SFX(const void* x, const float* gate, void* y, int F, int C, int P, rk_stream_t stream); \
+    int rk_se_scale_backward_##SFX(const void* dy, const void* x, const float* gate, void* dx, float* dgate,  \
+                                   int F, int C, int P, rk_stream_t stream);
+RK_DECL_SE(f32)
+RK_DECL_SE(bf16)
+#undef RK_DECL_SE
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,21 @@ def lib():
     return _lib
 
 
+def use_native():
+    """Switch this process to a -march=native build of the same source, compiled on THIS host (bench.py's
+    cpu_baseline leg; the portable build is what travels with the repo).  Returns True when it is in use."""
+    global _lib
+    path = os.path.join(_HERE, "librubiks_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+        handle = ctypes.CDLL(path)
+    except (OSError, subprocess.CalledProcessError):
+        return False
+    handle.oracle_num_threads.restype = ctypes.c_int
+    _lib = handle
+    return True
+
+
 def out_len(size, stride, pad):
     """cuda_src/rubiks.cpp:166 -- NOT the conv formula."""
     return (size + 2 * pad - 1) // stride + 1

@@ -38,6 +38,9 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define RK_T float
 #define RK_FN(name) name##_f32

@@ -95,8 +95,19 @@ void RK_FN(oracle_rk3d_backward_shift_partials)(const RK_T* x, const RK_T* shift
     const RK_T* shH = shift + C;
     const RK_T* shW = shift + 2 * C;
     const size_t HWo = (size_t)Ho * Wo;
-#pragma omp parallel for schedule(static)
-    for (int c = 0; c < C; ++c) {
+    /* threads own (c, block of rows) of the scratch: every address still receives its adds in increasing (n, to)
+     * order, so the sums are the serial ones; C * nblk work items keep all host cores busy (C alone is 64) while a
+     * block of rows keeps each thread's reads of x / gy in runs of several rows */
+    int nblk = 1;
+#ifdef _OPENMP
+    nblk = (omp_get_max_threads() + C - 1) / C;
+#endif
+    if (nblk < 1) nblk = 1;
+    if (nblk > Ho) nblk = Ho;
+    const int rows_per = (Ho + nblk - 1) / nblk;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int c = 0; c < C; ++c)
+      for (int hb = 0; hb < nblk; ++hb) {
         const int flT = RK_FN(floor3d)(shT[c]);
         const int flH = RK_FN(floor3d)(shH[c]);
         const int flW = RK_FN(floor3d)(shW[c]);
@@ -109,7 +120,7 @@ void RK_FN(oracle_rk3d_backward_shift_partials)(const RK_T* x, const RK_T* shift
         for (int n = 0; n < N; ++n)
             for (int to = 0; to < To; ++to) {
                 const RK_T* gp = gy + (((size_t)n * To + to) * C + c) * HWo;
-                for (int ho = 0; ho < Ho; ++ho)
+                for (int ho = hb * rows_per; ho < (hb + 1) * rows_per && ho < Ho; ++ho) {
                     for (int wo = 0; wo < Wo; ++wo) {
                         const int bT = to * sT - pT, bH = ho * sH - pH, bW = wo * sW - pW; /* :261-263 */
                         /* index 0 = "small" (possibly lowered), 1 = "large".  ref3d:359-431:
@@ -135,8 +146,9 @@ void RK_FN(oracle_rk3d_backward_shift_partials)(const RK_T* x, const RK_T* shift
                         accH[ho * Wo + wo] += (-Hs + Hl) * up;
                         accW[ho * Wo + wo] += (-Ws + Wl) * up;
                     }
+                }
             }
-    }
+      }
 }
 
 /* refcpp:344-345 (3D) and :140-143 (2D): shift_grad = scratch.view(D*C, HoWo) @ ones,

@@ -43,6 +43,10 @@ SIGNATURES = {
     "rk_pw_wgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
 }
 for _sfx in ("f32", "bf16"):
+    SIGNATURES["rk_clip_u8_to_chw_" + _sfx] = (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p])
+    SIGNATURES["rk_se_squeeze_" + _sfx] = (_i, [_p, _p, _i, _i, _i, _p])
+    SIGNATURES["rk_se_scale_" + _sfx] = (_i, [_p, _p, _p, _i, _i, _i, _p])
+    SIGNATURES["rk_se_scale_backward_" + _sfx] = (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p])
     SIGNATURES["rk_bn_relu_forward_" + _sfx] = (
         _i, [_p] * 8 + [_i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _i, _p, _sz, _p])
     SIGNATURES["rk_bn_relu_backward_" + _sfx] = (_i, [_p] * 10 + [_i, _i, _i, _i, _p, _sz, _p])

@@ -8,8 +8,10 @@ names (`conv1`, `layer0..4`, `bn1`, `conv2`, `bn2`, `as3`, `se`, `conv3`, `short
 """
 import math
 
+import torch
 import torch.nn as nn
 
+from . import _native, config
 from .fused_bn import bn_relu, bn_relu_skip
 from .pointwise import conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
@@ -38,8 +40,65 @@ _INITIALISERS = (
 )
 
 
+class _SEGate(torch.autograd.Function):
+    """y = x * gate[f, c] on [F, C, H, W] with gate [F, C]: the scale half of the SE layer as one HIP pass; its
+    backward produces d(x) = dy * gate and d(gate) = sum_hw(dy * x) in one pass over (dy, x)."""
+
+    @staticmethod
+    def forward(ctx, x, gate):
+        Fr, C, H, W = x.shape
+        y = torch.empty_like(x)
+        g32 = gate.detach().float().contiguous()
+        _se_call("rk_se_scale_", x, x.data_ptr(), g32.data_ptr(), y.data_ptr(), Fr, C, H * W)
+        ctx.save_for_backward(x, g32)
+        ctx.gate_dtype = gate.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32 = ctx.saved_tensors
+        Fr, C, H, W = x.shape
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        dgate = torch.empty_like(g32)
+        _se_call("rk_se_scale_backward_", x, dy.data_ptr(), x.data_ptr(), g32.data_ptr(), dx.data_ptr(), dgate.data_ptr(),
+                 Fr, C, H * W)
+        return dx, dgate.to(ctx.gate_dtype)
+
+
+class _SESqueeze(torch.autograd.Function):
+    """mean over H*W of every (frame, channel) plane -> [F, C] fp32 (AdaptiveAvgPool2d(1) + view)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        Fr, C, H, W = x.shape
+        mean = torch.empty(Fr, C, dtype=torch.float32, device=x.device)
+        _se_call("rk_se_squeeze_", x, x.data_ptr(), mean.data_ptr(), Fr, C, H * W)
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return mean
+
+    @staticmethod
+    def backward(ctx, dmean):
+        Fr, C, H, W = ctx.shape
+        return (dmean / float(H * W)).to(ctx.dtype).view(Fr, C, 1, 1).expand(Fr, C, H, W)
+
+
+_SE_SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+def _se_call(name, x, *args):
+    dev = x.device
+    with torch.cuda.device(dev):
+        rc = getattr(_native.lib(), name + _SE_SFX[x.dtype])(*args, torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, name)
+
+
 class SELayer(nn.Module):
-    """Squeeze-and-excitation gate (backbone.py:56-71); used by the Small tier."""
+    """Squeeze-and-excitation gate (backbone.py:56-71); used by the Small tier.  Same sub-modules and state-dict keys
+    (`fc.0.weight`, `fc.2.weight`).  On GPU fp32 / bf16 activations the squeeze and the scale are one HIP pass each
+    (rk_se_*); the two tiny Linear layers stay in PyTorch."""
 
     def __init__(self, channel, reduction):
         super().__init__()
@@ -53,6 +112,10 @@ class SELayer(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
+        if x.is_cuda and x.dim() == 4 and x.dtype in _SE_SFX and x.numel() > 0 and config.switches().fused_bn:
+            x = x.contiguous()
+            gate = self.fc(_SESqueeze.apply(x).to(self.fc[0].weight.dtype))
+            return _SEGate.apply(x, gate)
         gate = self.fc(self.avg_pool(x).view(b, c)).view(b, c, 1, 1)
         return x * gate.expand_as(x)
 

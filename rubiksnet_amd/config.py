@@ -1,0 +1,44 @@
+"""Process-wide switches of the MI355X path, read ONCE (at import) into one frozen object.
+
+    RK_FUSED_BN    1 | 0          relu(bn(x)) pairs through the fused HIP operator (fused_bn.py) / stock modules
+    RK_PW          auto | 0 | all 1x1 convolutions on the HIP MFMA GEMM where it wins / never / wherever it can run
+    RK_FUSED_EVAL  1 | 0          inference blocks with BN + residual folded into the two GEMMs / layer by layer
+
+Everything else that used to be tunable from the environment (tile shapes, channel limits, prefetch depths)
+is a constant next to the code it tunes.  The native library has one switch of its own, RK_SHIFT_KERNELS
+(include/rubiks_hip.h).  Tests flip switches with `config.reload()` after changing os.environ.
+"""
+import dataclasses
+import os
+
+__all__ = ["Switches", "switches", "reload"]
+
+
+@dataclasses.dataclass(frozen=True)
+class Switches:
+    fused_bn: bool = True
+    pointwise: str = "auto"          # "auto" | "0" | "all"
+    fused_eval: bool = True
+
+    @staticmethod
+    def from_env(env=None):
+        env = os.environ if env is None else env
+        pw = env.get("RK_PW", "auto")
+        if pw not in ("auto", "0", "all"):
+            raise ValueError("RK_PW must be auto, 0 or all (got %r)" % pw)
+        return Switches(fused_bn=env.get("RK_FUSED_BN", "1") != "0", pointwise=pw,
+                        fused_eval=env.get("RK_FUSED_EVAL", "1") != "0")
+
+
+_current = Switches.from_env()
+
+
+def switches():
+    return _current
+
+
+def reload(env=None):
+    """Re-read the environment (tests only: production code reads the switches once, at import)."""
+    global _current
+    _current = Switches.from_env(env)
+    return _current

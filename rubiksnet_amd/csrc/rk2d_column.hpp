@@ -199,9 +199,7 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
 
 // ----------------------------------------------------------------------------------- host side
 inline bool supported(int quantize) {
-    static const bool off = [] { const char* e = getenv("RK_COLUMN2D"); return e && e[0] == '0'; }();
-    static const bool force_generic = [] { const char* e = getenv("RK_FORCE_GENERIC"); return e && e[0] == '1'; }();
-    return !off && !force_generic && !quantize;
+    return column_kernels_on() && !quantize;
 }
 
 // plane_elems: the plane the threads index (output plane for forward, input plane for backward)
@@ -214,10 +212,8 @@ inline C2Dims make_c2dims(const Dims2& d, int plane_elems) {
     cd.logE = (cd.E == 64) ? 6 : (cd.E == 128 ? 7 : 8);
     cd.nchunks = (plane_elems + cd.E * cd.M - 1) / (cd.E * cd.M);
     // frames per group: enough groups to fill the chip (>= ~4096 thread groups), at least 4 frames each
-    static const int fg_env = [] { const char* e = getenv("RK_COL2D_FG"); return e ? atoi(e) : 0; }();
     int fg = 16;
     while (fg > 4 && (long long)((d.N + fg - 1) / fg) * d.C * cd.nchunks * cd.E < 4096LL * kBlock) fg /= 2;
-    if (fg_env > 0) fg = fg_env;
     cd.FG = fg < d.N ? fg : d.N;
     cd.ngroups = (d.N + cd.FG - 1) / cd.FG;
     return cd;

@@ -340,18 +340,15 @@ __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restri
 
 // ---------------------------------------------------------------------------------------------
 // Host side.
-// false = shape not handled here (stride / padding / W % 4 / RK_FORCE_GENERIC / RK_DMA2D=0)
+// false = shape not handled here (stride / padding / W % 4 / RK_SHIFT_KERNELS)
 inline bool make_fdims(FDims& f, const Dims2& d, int frames_per_group) {
-    static const int on = env_int("RK_DMA2D", 1);
     const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
-    if (!on || !s1p0 || d.W % 4 != 0 || d.W < 4 || env_force_generic()) return false;
+    if (!s1p0 || d.W % 4 != 0 || d.W < 4 || !streaming_kernels_on()) return false;
     BDims& b = f.b;
     b.N = 1; b.T = d.N; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
     if (!choose_bands(b)) return false;
     f.frames = d.N;
-    static const int fg_env = env_int("RK_DMA2D_FG", 0);
-    const int fg = fg_env > 0 ? fg_env : frames_per_group;
-    f.FG = fg < d.N ? fg : d.N;
+    f.FG = frames_per_group < d.N ? frames_per_group : d.N;
     f.ngroups = (d.N + f.FG - 1) / f.FG;
     return true;
 }

@@ -2,7 +2,6 @@
 // Host glue restating cuda_src/rubiks.cpp:161-379 (shape math, dispatch) without ATen:
 // caller-owned buffers and workspace, explicit stream, error codes instead of exit().
 #include "rk3d_generic.hpp"
-#include "rk3d_stream.hpp"
 #include "rk3d_dma.hpp"
 #include "rk3d_plane.hpp"
 #include "rk3d_tile.hpp"
@@ -53,7 +52,6 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && tile3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
     }
-    if (stream3d::forward_supported<T>(d, quantize, x, y)) return stream3d::launch_forward<T>(x, shift, y, d, stream);
     if (col3d::supported(d, quantize)) return col3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);
     const unsigned grid = grid_for(d, (long long)d.N * d.To * d.C);
@@ -95,8 +93,6 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
             if (tile3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
         }
     }
-    if (stream3d::backward_supported<T>(d, quantize, x, gy, gx))
-        return stream3d::launch_backward<T>(x, shift, gy, gx, gshift, d, normalize_grad, t_factor, (T*)ws, stream);
     if (gshift && col3d::supported(d, quantize)) {
         const int P = col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream);
         hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const T*)ws, gshift, d.C, P,

@@ -242,8 +242,7 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
 
 // ----------------------------------------------------------------------------------- host side
 inline bool supported(const Dims3& d, int quantize) {
-    static const bool off = [] { const char* e = getenv("RK_COLUMN"); return e && e[0] == '0'; }();
-    return !off && !quantize && d.sT == 1 && d.pT == 0;
+    return column_kernels_on() && !quantize && d.sT == 1 && d.pT == 0;
 }
 
 // plane_elems: the plane the threads index (output plane for forward, input plane for backward)
@@ -252,9 +251,8 @@ inline CDims make_cdims(const Dims3& d, int plane_elems) {
     cd.d = d;
     // <= 64 elements: one wave, 1 element per thread; <= 256: one wave, up to 4 elements per thread (4 independent
     // chains per thread, wave-only reduction, 4x fewer threads to set up); larger: 256 threads x 4 elements per chunk
-    static const int small_e = [] { const char* e = getenv("RK_COL_SMALL_E"); return e ? atoi(e) : 256; }();
     if (plane_elems <= kWave) { cd.E = kWave; cd.M = 1; }
-    else if (plane_elems <= kBlock) { cd.E = small_e; cd.M = (plane_elems <= small_e) ? 1 : 4; }
+    else if (plane_elems <= kBlock) { cd.E = kBlock; cd.M = 1; }
     else { cd.E = kBlock; cd.M = 4; }
     cd.logE = (cd.E == 64) ? 6 : (cd.E == 128 ? 7 : 8);
     cd.nchunks = (plane_elems + cd.E * cd.M - 1) / (cd.E * cd.M);
@@ -281,8 +279,7 @@ template <typename T>
 inline int launch_backward(const T* x, const T* shift, const T* gy, T* gx, T* ws, const Dims3& d,
                            hipStream_t stream) {
     const CDims cd = make_cdims(d, d.H * d.W);
-    static const bool single_off = [] { const char* e = getenv("RK_COL_SINGLE"); return e && e[0] == '0'; }();
-    const bool single = d.sH >= 2 && d.sW >= 2 && !single_off;
+    const bool single = d.sH >= 2 && d.sW >= 2;
 #define RK_COL_BWD(GX, MM, SG) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG>), dim3(grid_of(cd)), dim3(kBlock), \
                                                   0, stream, x, shift, gy, gx, ws, cd)
 #define RK_COL_SG(GX, MM) do { if (single) RK_COL_BWD(GX, MM, true); else RK_COL_BWD(GX, MM, false); } while (0)

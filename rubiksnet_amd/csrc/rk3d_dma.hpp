@@ -2,7 +2,7 @@
 // fp32, stride 1 / pad 0, W % 4 == 0.  These are the kernels the benchmark shape and the
 // stride-1 layers of the networks run on (56x56, 28x28 whole planes; 112x112 in 4 row bands).
 //
-// Maths (see rk3d_stream.hpp for the derivation): the shift is constant per channel, so an output
+// Maths: the shift is constant per channel, so an output
 // plane is a fixed 2-D translate-and-blend of two input planes and the H/W-interpolated field
 // B(t) of an input plane is shared by the two outputs that touch it,
 //     y[to] = (1-rT) B(to+flT) + rT B(to+flT+1),  B = (1-rH) lerpW(row) + rH lerpW(row+1),
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
 // false = shape not handled by the DMA kernels
 inline bool make_bdims(BDims& b, const Dims3& d) {
     const bool s1p0 = d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0;
-    if (!s1p0 || d.W % 4 != 0 || d.W < 4 || env_force_generic()) return false;
+    if (!s1p0 || d.W % 4 != 0 || d.W < 4 || !streaming_kernels_on()) return false;
     b.N = d.N; b.T = d.T; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
     return choose_bands(b);
 }
@@ -373,16 +373,14 @@ inline void launch_interp_d(const float* src, const float* shift, float* dst, co
     }
 }
 
-// forward / d(x)-only; false = not handled here.  RK_DMA = planes in flight per column (1..3), 0 disables.
+// forward / d(x)-only; false = not handled here.  2 planes in flight per column (1 and 3 measured within 1 %).
 template <bool NEGATE>
 inline bool launch_interp(const float* src, const float* shift, float* dst, const Dims3& d, hipStream_t stream) {
-    static const int depth = env_int("RK_DMA", 2);
+    constexpr int kDepth = 2;
     BDims b;
-    if (depth < 1 || depth > 3 || !make_bdims(b, d) || !aligned16(src) || !aligned16(dst)) return false;
-    if (interp_ring_bytes(b, depth) > 64 * 1024) return false;
-    if (depth == 1) launch_interp_d<NEGATE, 1>(src, shift, dst, b, stream);
-    else if (depth == 2) launch_interp_d<NEGATE, 2>(src, shift, dst, b, stream);
-    else launch_interp_d<NEGATE, 3>(src, shift, dst, b, stream);
+    if (!make_bdims(b, d) || !aligned16(src) || !aligned16(dst)) return false;
+    if (interp_ring_bytes(b, kDepth) > 64 * 1024) return false;
+    launch_interp_d<NEGATE, kDepth>(src, shift, dst, b, stream);
     return true;
 }
 
@@ -400,22 +398,14 @@ inline void launch_bwd_d(const float* x, const float* shift, const float* gy, fl
 }
 
 // d(shift) partials (+ d(x) when gx != nullptr) into ws[C][3][P]; returns P (0 = not handled here).
-// RK_DMA_BWD = "<DG><DX>" planes in flight for gy / x: 11 (default), 21 or 22; 0 disables.
+// One gy plane and one x plane in flight (2 / 2 measured within 1 %: the memory system, not latency, bounds it).
 inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* ws, const Dims3& d,
                       hipStream_t stream) {
-    static const int depth = env_int("RK_DMA_BWD", 11);
     BDims b;
-    if (depth <= 0 || !make_bdims(b, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
-    const int DG = depth / 10, DX = depth % 10;
-    if (!((DG == 1 && DX == 1) || (DG == 2 && DX == 1) || (DG == 2 && DX == 2))) return 0;
-    if (bwd_ring_bytes(b, DG, DX) > 64 * 1024) return 0;
-#define RK_BWD_CASE(G, X)                                                                          \
-    if (DG == G && DX == X) {                                                                      \
-        if (gx) launch_bwd_d<true, G, X>(x, shift, gy, gx, ws, b, d, stream);                      \
-        else launch_bwd_d<false, G, X>(x, shift, gy, gx, ws, b, d, stream);                        \
-    }
-    RK_BWD_CASE(1, 1) RK_BWD_CASE(2, 1) RK_BWD_CASE(2, 2)
-#undef RK_BWD_CASE
+    if (!make_bdims(b, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
+    if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return 0;
+    if (gx) launch_bwd_d<true, 1, 1>(x, shift, gy, gx, ws, b, d, stream);
+    else launch_bwd_d<false, 1, 1>(x, shift, gy, gx, ws, b, d, stream);
     return b.N * b.nbands;
 }
 

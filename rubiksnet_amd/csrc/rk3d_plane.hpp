@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k3d_plane_interp(const float* __restri
 // SP = 2 on the default bands for wider ones (112x112: four 28-row bands, 3 slots = 39 KB); see the header.
 inline bool make_pdims(PDims& p, int& SP, const Dims3& d) {
     const bool s1p0 = d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0;
-    if (!s1p0 || d.W % 4 != 0 || d.W < 4 || env_force_generic()) return false;
+    if (!s1p0 || d.W % 4 != 0 || d.W < 4 || !streaming_kernels_on()) return false;
     BDims& b = p.b;
     b.N = d.N; b.T = d.T; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
     if (!choose_bands(b)) return false;

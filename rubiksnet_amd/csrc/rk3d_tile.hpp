@@ -433,7 +433,7 @@ template <typename G> inline bool tile_dims(TDims& t, const Dims3& d) {
     return true;
 }
 inline bool s1p0(const Dims3& d) {
-    return d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0 && !env_force_generic();
+    return d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0 && streaming_kernels_on();
 }
 
 template <int H, int W, int GCO, int RING, bool NEGATE>

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
 int make_bn(BnDims& d, int F, int C, int P) {
     if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;
     if ((long long)F * C * P > 0x7fffffffLL * 4) return RK_ERR_BAD_DIMS;
-    static const int chunk = [] { const char* e = getenv("RK_BN_CHUNK"); return e ? atoi(e) : 8192; }();
+    constexpr int chunk = 8192;          // elements per workgroup (4096 .. 16384 measured within 2 %)
     d.F = F; d.C = C; d.P = P;
     int fb = (chunk + P - 1) / P;
     fb = fb < 1 ? 1 : (fb > F ? F : fb);

@@ -1,0 +1,163 @@
+// rk_clip.hip -- input side of the network on the device and the squeeze-and-excitation
+// gate of RubiksNet-Small (row f3).
+//
+// rk_clip_u8_to_chw_*: the reference's per-sample CPU transforms Stack -> ToTorchFormatTensor(div=True) ->
+// GroupNormalize (rubiksnet/transforms.py:329-363, :66-79) as ONE pass on the GPU: a clip arrives as the stacked
+// HWC uint8 image [H, W, 3T] (what Stack produces; what a JPEG decoder produces per frame, frames interleaved along
+// the channel axis), leaves as [3T, H, W] floats, ((v / 255) - mean[c % 3]) / std[c % 3], each operation rounded in
+// fp32 exactly as `img.float().div(255)` followed by `t.sub_(m).div_(s)` rounds it.  The reference notes "this
+// transpose takes 80% of the loading time/CPU" (transforms.py:357); here it is 1 B read + 4 B written per element.
+// A workgroup owns 256 consecutive pixels of one row band: their 256 * CS bytes are one contiguous run (16-byte
+// loads), staged in LDS, then written channel by channel (consecutive lanes -> consecutive floats).
+//
+// rk_se_*: SELayer (rubiksnet/backbone.py:56-71): squeeze = per-(frame, channel) mean over H*W, excite = two tiny
+// Linear layers + sigmoid (left to PyTorch: [F, C] x [C, C/r]), scale = x * gate.  The reference runs avg-pool,
+// view, 2 x Linear, ReLU, sigmoid, expand_as and a broadcast multiply as separate kernels and autograd saves x and
+// the expanded gate; here squeeze and scale are one pass each, and the backward of the scale produces d(x) and
+// d(gate) (a per-plane dot product) in one pass over (dy, x).
+#include "rk_common.hpp"
+
+using namespace rk;
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void store_out(T* p, float v) { st(p, v); }
+
+// ------------------------------------------------------------------------------------------ clip transform
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_clip_u8_to_chw(const unsigned char* __restrict__ src,
+                                                           const float* __restrict__ mean3,
+                                                           const float* __restrict__ std3, T* __restrict__ dst,
+                                                           int HW, int CS) {
+    extern __shared__ unsigned char tile[];                       // [256 pixels][CS]
+    const int clip = blockIdx.y;
+    const long long p0 = (long long)blockIdx.x * kBlock;          // first pixel of this workgroup
+    const int npix = (HW - p0) < kBlock ? (int)(HW - p0) : kBlock;
+    const unsigned char* in = src + ((long long)clip * HW + p0) * CS;
+    const int nbytes = npix * CS;
+    // the run starts 16-byte aligned when p0 * CS is (256 * CS always is) and the clip base is (HW * CS % 16 == 0,
+    // checked by the launcher); the tail is copied bytewise
+    const int n16 = nbytes / 16;
+    for (int i = threadIdx.x; i < n16; i += kBlock)
+        reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(in)[i];
+    for (int i = n16 * 16 + threadIdx.x; i < nbytes; i += kBlock) tile[i] = in[i];
+    __syncthreads();
+    const int px = threadIdx.x;
+    if (px >= npix) return;
+    T* out = dst + (long long)clip * CS * HW + p0 + px;
+    for (int c = 0; c < CS; ++c) {
+        const int k = c % 3;
+        const float v = (float)tile[px * CS + c] / 255.0f;        // ToTorchFormatTensor: .float().div(255)
+        store_out(out + (long long)c * HW, (v - mean3[k]) / std3[k]);   // GroupNormalize: sub_(m).div_(s)
+    }
+}
+
+// ------------------------------------------------------------------------------------------ SE squeeze / scale
+// one wave per (frame, channel) plane
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_se_squeeze(const T* __restrict__ x, float* __restrict__ mean, long long planes,
+                                                       int P) {
+    const long long plane = (long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const T* p = x + plane * P;
+    float s = 0.f;
+    for (int i = lane; i < P; i += kWave) s += ld(p + i);
+    s = wave_sum(s);
+    if (lane == 0) mean[plane] = s / (float)P;
+}
+
+// y = x * gate[plane]
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_se_scale(const T* __restrict__ x, const float* __restrict__ gate, T* __restrict__ y,
+                                                     long long planes, int P) {
+    const long long plane = (long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const float g = gate[plane];
+    const T* p = x + plane * P;
+    T* o = y + plane * P;
+    for (int i = lane; i < P; i += kWave) st(o + i, ld(p + i) * g);
+}
+
+// dx = dy * gate[plane] (+ dmean[plane] / P: the squeeze's share of d(x)), dgate[plane] = sum(dy * x)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_se_scale_backward(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const float* __restrict__ gate, T* __restrict__ dx,
+                                                              float* __restrict__ dgate, long long planes, int P) {
+    const long long plane = (long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const float g = gate[plane];
+    const T* pd = dy + plane * P;
+    const T* px = x + plane * P;
+    T* o = dx + plane * P;
+    float s = 0.f;
+    for (int i = lane; i < P; i += kWave) {
+        const float d = ld(pd + i);
+        s = fmaf(d, ld(px + i), s);
+        st(o + i, d * g);
+    }
+    s = wave_sum(s);
+    if (lane == 0) dgate[plane] = s;
+}
+
+unsigned plane_grid(long long planes) { return (unsigned)((planes + kBlock / kWave - 1) / (kBlock / kWave)); }
+
+template <typename T>
+int clip_impl(const unsigned char* src, const float* mean3, const float* std3, void* dst, int nclips, int H, int W, int CS,
+              rk_stream_t stream) {
+    if (!src || !mean3 || !std3 || !dst) return RK_ERR_NULL_POINTER;
+    if (nclips <= 0 || H <= 0 || W <= 0 || CS <= 0 || CS % 3 != 0 || CS > 192) return RK_ERR_BAD_DIMS;
+    const long long HW = (long long)H * W;
+    if (HW * CS * nclips > 0x7fffffffLL || ((HW * CS) % 16) != 0 || ((uintptr_t)src & 15)) return RK_ERR_BAD_DIMS;
+    const dim3 grid((unsigned)((HW + kBlock - 1) / kBlock), (unsigned)nclips);
+    hipLaunchKernelGGL((k_clip_u8_to_chw<T>), grid, dim3(kBlock), (size_t)kBlock * CS, (hipStream_t)stream, src, mean3, std3,
+                       (T*)dst, (int)HW, CS);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_clip_u8_to_chw_f32(const unsigned char* hwc, const float* mean3, const float* std3, float* chw, int nclips, int H,
+                          int W, int CS, rk_stream_t stream) {
+    return clip_impl<float>(hwc, mean3, std3, chw, nclips, H, W, CS, stream);
+}
+int rk_clip_u8_to_chw_bf16(const unsigned char* hwc, const float* mean3, const float* std3, void* chw, int nclips, int H,
+                           int W, int CS, rk_stream_t stream) {
+    return clip_impl<__hip_bfloat16>(hwc, mean3, std3, chw, nclips, H, W, CS, stream);
+}
+
+#define RK_SE_IMPL(SFX, T)                                                                                          \
+    int rk_se_squeeze_##SFX(const void* x, float* mean, int F, int C, int P, rk_stream_t stream) {                  \
+        if (!x || !mean) return RK_ERR_NULL_POINTER;                                                                \
+        if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;                                                     \
+        const long long planes = (long long)F * C;                                                                  \
+        hipLaunchKernelGGL((k_se_squeeze<T>), dim3(plane_grid(planes)), dim3(kBlock), 0, (hipStream_t)stream,       \
+                           (const T*)x, mean, planes, P);                                                           \
+        return launch_status();                                                                                     \
+    }                                                                                                               \
+    int rk_se_scale_##SFX(const void* x, const float* gate, void* y, int F, int C, int P, rk_stream_t stream) {     \
+        if (!x || !gate || !y) return RK_ERR_NULL_POINTER;                                                          \
+        if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;                                                     \
+        const long long planes = (long long)F * C;                                                                  \
+        hipLaunchKernelGGL((k_se_scale<T>), dim3(plane_grid(planes)), dim3(kBlock), 0, (hipStream_t)stream,         \
+                           (const T*)x, gate, (T*)y, planes, P);                                                    \
+        return launch_status();                                                                                     \
+    }                                                                                                               \
+    int rk_se_scale_backward_##SFX(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int F, \
+                                   int C, int P, rk_stream_t stream) {                                              \
+        if (!dy || !x || !gate || !dx || !dgate) return RK_ERR_NULL_POINTER;                                        \
+        if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;                                                     \
+        const long long planes = (long long)F * C;                                                                  \
+        hipLaunchKernelGGL((k_se_scale_backward<T>), dim3(plane_grid(planes)), dim3(kBlock), 0,                     \
+                           (hipStream_t)stream, (const T*)dy, (const T*)x, gate, (T*)dx, dgate, planes, P);         \
+        return launch_status();                                                                                     \
+    }
+RK_SE_IMPL(f32, float)
+RK_SE_IMPL(bf16, __hip_bfloat16)
+#undef RK_SE_IMPL
+
+}  // extern "C"

@@ -4,6 +4,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "rubiks_hip.h"
 
@@ -52,6 +54,28 @@ template <typename A> __device__ __forceinline__ A group_sum(A v, int group, A* 
     __syncthreads();
     return r;
 }
+
+// ---- the library's one switch -------------------------------------------------------
+// RK_SHIFT_KERNELS = auto (default) | column | generic, read once per process:
+//   auto    LDS-DMA streaming kernels (plane-group / column-walk / tile, 2-D twins) where a shape qualifies,
+//           then the column kernels, then the per-plane generic kernels
+//   column  no LDS-DMA streaming kernels (what a buffer that is not 16-byte aligned gets anyway)
+//   generic per-plane generic kernels only (RK_FORCE_GENERIC=1 is the older spelling)
+// Every family is bit-identical to the oracle for y and d(x); tests/test_fallback_paths_gpu.py runs the parity
+// suite on each setting.  Tile shapes, prefetch depths and channel limits are constants next to the kernels.
+enum class ShiftKernels { Auto, Column, Generic };
+inline ShiftKernels shift_kernels() {
+    static const ShiftKernels v = [] {
+        const char* e = getenv("RK_SHIFT_KERNELS");
+        if (e && !strcmp(e, "generic")) return ShiftKernels::Generic;
+        if (e && !strcmp(e, "column")) return ShiftKernels::Column;
+        const char* f = getenv("RK_FORCE_GENERIC");
+        return (f && f[0] == '1') ? ShiftKernels::Generic : ShiftKernels::Auto;
+    }();
+    return v;
+}
+inline bool streaming_kernels_on() { return shift_kernels() == ShiftKernels::Auto; }
+inline bool column_kernels_on() { return shift_kernels() != ShiftKernels::Generic; }
 
 // ---- host helpers ----------------------------------------------------------------
 inline int out_len(int in, int stride, int pad) { return (in + 2 * pad - 1) / stride + 1; }

@@ -187,21 +187,12 @@ __device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slo
 
 // ---------------------------------------------------------------------------------------------
 // Host side: band choice.
-inline bool env_force_generic() {
-    static const bool v = [] { const char* e = getenv("RK_FORCE_GENERIC"); return e && e[0] == '1'; }();
-    return v;
-}
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 inline int rounds_for(int cells) { return (cells + kBlock - 1) / kBlock; }
 
 // Equal bands with (BH + 1) * W4 <= 1024 cells and the same number of rounds on the tap side and on the
 // output side (so rounds 0..ROUNDS-2 are full).  Needs b.H and b.W4; false = no such banding.
 inline bool choose_bands(BDims& b) {
-    static const int min_bands = env_int("RK_MIN_BANDS", 1);
-    for (int nb = min_bands; nb <= b.H; ++nb) {
+    for (int nb = 1; nb <= b.H; ++nb) {
         if (b.H % nb) continue;
         const int bh = b.H / nb, co = bh * b.W4, ci = (bh + 1) * b.W4;
         if (ci > 4 * kBlock) continue;

@@ -598,9 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ 
 // 576 channels yes; 144 and 288 -- 2.25 tiles per side -- and 54 -> 108 no: measured 216 -> 261 us, 176 -> 177 us,
 // 216 -> 270 us against 292 -> 226 us at 72, 135 -> 100 us at 108, 131 -> 98 us at 216)
 inline bool use_wide(int M, int K) {
-    static const int mode = [] { const char* e = getenv("RK_PW_WG_WIDE"); return e ? atoi(e) : 1; }();
-    if (mode == 0 || (M <= 64 && K <= 64)) return false;
-    if (mode == 2) return true;
+    if (M <= 64 && K <= 64) return false;
     const int q = ((M + 63) / 64) * ((K + 63) / 64), slots = 4 * ((M + 127) / 128) * ((K + 127) / 128);
     return 4 * q >= 3 * slots;
 }
@@ -609,7 +607,7 @@ inline int make_wg_wide(WgDims& d, int F, int K, int M, int P) {
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
     d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
     const int pairs = ((M + 127) / 128) * ((K + 127) / 128);
-    static const int want = [] { const char* e = getenv("RK_PW_WG_WIDE_WGS"); return e ? atoi(e) : 768; }();
+    constexpr int want = 768;                                         // workgroups (3 per CU)
     long long S = want / pairs;
     const long long cap = ((long long)(M + K) * d.ntot) / (4LL * M * K);
     if (S > cap) S = cap;
@@ -782,9 +780,9 @@ inline int make_wg(WgDims& d, int F, int K, int M, int P) {
     d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
     // ~1536 wave tasks (6 per CU), but keep the partials (S * M * K floats, written and read once) under a
     // quarter of the operands' bytes
-    static const int want_env = [] { const char* e = getenv("RK_PW_WG_TASKS"); return e ? atoi(e) : 1536; }();
+    constexpr int want_tasks = 1536;
     const int nmk = d.MB * d.KB;
-    long long S = want_env / (nmk < 4 ? 4 : nmk);                   // one partial per workgroup-chunk
+    long long S = want_tasks / (nmk < 4 ? 4 : nmk);                   // one partial per workgroup-chunk
     const long long cap = ((long long)(M + K) * d.ntot) / (4LL * M * K);
     if (S > cap) S = cap;
     if (S < 1) S = 1;
@@ -815,23 +813,18 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
     d.Cin = d.Hin = d.Win = d.Wo = 0;
-    static const int wm_env = [] { const char* e = getenv("RK_PW_WM"); return e ? atoi(e) : 0; }();
     // rows per workgroup tile = 64 wm.  Above 128 rows 64-row tiles win although the streamed operand is then
     // re-read once per tile (L2 / Infinity Cache absorb it; 288 rows: 101 us against 141 / 179 us with 128 / 256-row
     // tiles, which also pad 288 to 384 / 512)
-    int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
-    if (wm_env == 1 || wm_env == 2 || wm_env == 4) wm = wm_env;
+    const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
     d.WM = wm; d.WN = 4 / wm;
     const int mt = 64 * wm;
     const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
     hipStream_t stream = (hipStream_t)stream_;
-    static const int kc_env = [] { const char* e = getenv("RK_PW_KC"); return e ? atoi(e) : 0; }();
     // chunk of 12 or 16 (2 waves per SIMD; 18 needs too many registers): the one that pads K less
-    int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;
-    if (kc_env == 12 || kc_env == 16) kc = kc_env;
+    const int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;
     if constexpr (std::is_same<T, __hip_bfloat16>::value) {
-        static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
-        if (bf16_mfma && !(fuse && (fuse->ka || fuse->ma))) {
+        if (!(fuse && (fuse->ka || fuse->ma))) {                    // bf16 activations: the bf16-MFMA kernel
 #define RK_PW_B(WMV) do { if (a_is_mk) hipLaunchKernelGGL((k_pw_gemm_bf16<WMV, true>), grid, block, 0, stream, A, X, R, Y, d); \
                           else hipLaunchKernelGGL((k_pw_gemm_bf16<WMV, false>), grid, block, 0, stream, A, X, R, Y, d); } while (0)
             if (wm == 1) RK_PW_B(1);
@@ -860,9 +853,8 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
     const T* dY = (const T*)dY_; const T* X = (const T*)X_;
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
     WgDims d;
-    static const bool bf16_mfma = [] { const char* e = getenv("RK_PW_BF16_MFMA"); return !(e && e[0] == '0'); }();
     // the wide (shared-tile) kernel for > 64 channels; bf16 activations keep the bf16-MFMA kernel
-    const bool wide = use_wide(M, K) && !(std::is_same<T, __hip_bfloat16>::value && bf16_mfma);
+    const bool wide = use_wide(M, K) && !std::is_same<T, __hip_bfloat16>::value;
     if (int rc = wide ? make_wg_wide(d, F, K, M, P) : make_wg(d, F, K, M, P)) return rc;
     const uintptr_t am = 4 * sizeof(T) - 1;
     if (((uintptr_t)X & am) || ((uintptr_t)dY & am)) return RK_ERR_BAD_DIMS;
@@ -877,8 +869,7 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
         const int pairs = ((M + 127) / 128) * ((K + 127) / 128);
         hipLaunchKernelGGL((k_pw_wgrad_wide<T>), dim3((unsigned)(d.S * pairs)), dim3(kBlock), 0, stream, dY, X, part, d);
     } else if constexpr (std::is_same<T, __hip_bfloat16>::value) {
-        if (bf16_mfma) hipLaunchKernelGGL(k_pw_wgrad_bf16, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
-        else hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+        hipLaunchKernelGGL(k_pw_wgrad_bf16, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     } else {
         hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     }

@@ -9,12 +9,10 @@ of the gloo tests, other dtypes, eval mode with gradients).  `RK_FUSED_BN=0` for
 Training forward: 12 B/elem (stats pass + normalise pass), backward: 20 B/elem, nothing saved but x and the
 [C] mean / invstd (stock: BN saves x, ReLU saves its output).
 """
-import os
-
 import torch
 import torch.nn.functional as F
 
-from . import _native
+from . import _native, config
 
 __all__ = ["bn_relu", "bn_relu_skip", "fused_bn_enabled"]
 
@@ -22,7 +20,7 @@ _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
 
 
 def fused_bn_enabled():
-    return os.environ.get("RK_FUSED_BN", "1") != "0"
+    return config.switches().fused_bn
 
 
 def _ws(L, Fr, C, P, dev):
@@ -119,7 +117,7 @@ def bn_relu_skip(bn, x):
     second element is an autograd alias of x whose gradient is added inside the BN d(x) kernel (one elementwise pass
     less per block); elsewhere it is x itself."""
     if (_fusable(bn, x) and (bn.training or (bn.running_mean is None and bn.running_var is None))
-            and torch.is_grad_enabled() and x.requires_grad and os.environ.get("RK_BN_SKIP", "1") != "0"):
+            and torch.is_grad_enabled() and x.requires_grad):
         x = x.contiguous()
         momentum = 0.0 if bn.momentum is None else bn.momentum
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:

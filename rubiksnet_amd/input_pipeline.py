@@ -1,0 +1,103 @@
+"""Input side of the network on the device.
+
+The reference prepares every sample on CPU workers: PIL frames -> `Stack` (one H x W x 3T uint8 array) ->
+`ToTorchFormatTensor(div=True)` (HWC -> CHW, float, / 255: "this transpose takes 80% of the loading time/CPU",
+rubiksnet/transforms.py:357) -> `GroupNormalize(mean, std)` (transforms.py:66-79), then a pinned-memory DataLoader
+ships 4 bytes per element to the GPU (scripts/test_models.py:123-148).  Here the host hands over the stacked uint8
+clips (1 byte per element over PCIe) and `stacked_u8_to_clips` does transpose + /255 + normalise in ONE HIP kernel
+(rk_clip_u8_to_chw_*, 1 B read + 4 B written per element), bit-identical to the reference's tensor ops in fp32.
+
+`SyntheticClipLoader` is the benchmark's feeder: random uint8 clips in pinned host memory, copied on a side HIP
+stream and transformed there, double buffered, so the copy and the transform of batch i+1 overlap the step on
+batch i.  (Dataset indexing, JPEG decoding and the PIL crops stay out of scope)
+"""
+import torch
+
+from . import _native
+
+__all__ = ["stacked_u8_to_clips", "SyntheticClipLoader", "IMAGENET_MEAN", "IMAGENET_STD"]
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # RubiksNet.input_mean / input_std (models.py:106-107)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+def stacked_u8_to_clips(stacked, n_frames, mean=IMAGENET_MEAN, std=IMAGENET_STD, dtype=torch.float32, out=None):
+    """stacked: uint8 [B, H, W, 3 * n_frames] on the GPU (Stack(roll=False) layout: RGB of frame 0, frame 1, ...).
+    Returns the network's input [B, n_frames, 3, H, W], normalised, in `dtype` (float32 or bfloat16)."""
+    if not (stacked.is_cuda and stacked.dtype == torch.uint8 and stacked.dim() == 4 and stacked.is_contiguous()):
+        raise RuntimeError("stacked must be a contiguous CUDA (HIP) uint8 tensor [B, H, W, 3T] (no CPU fallback)")
+    if dtype not in _SFX:
+        raise ValueError("dtype must be float32 or bfloat16, got %s" % dtype)
+    B, H, W, CS = stacked.shape
+    if CS != 3 * n_frames:
+        raise ValueError("last dim is %d, expected 3 * n_frames = %d" % (CS, 3 * n_frames))
+    dev = stacked.device
+    if out is None:
+        out = torch.empty(B, CS, H, W, dtype=dtype, device=dev)
+    elif tuple(out.shape) not in ((B, CS, H, W), (B, n_frames, 3, H, W)) or out.dtype != dtype or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous %s tensor [B, 3T, H, W]" % dtype)
+    ms = torch.tensor([list(mean), list(std)], dtype=torch.float32, device=dev)    # fp32(mean), fp32(std) as sub_/div_ use
+    if B:
+        with torch.cuda.device(dev):
+            rc = getattr(_native.lib(), "rk_clip_u8_to_chw_" + _SFX[dtype])(
+                stacked.data_ptr(), ms[0].data_ptr(), ms[1].data_ptr(), out.data_ptr(), B, H, W, CS,
+                torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_clip_u8_to_chw")
+    return out.view(B, n_frames, 3, H, W)
+
+
+class SyntheticClipLoader:
+    """Endless iterator of (clips [B, T, 3, H, W] normalised, labels [B]) on `device`.
+
+    Two pinned host buffers of random uint8 clips stand in for decoded frames.  Batch i+1 is copied host -> device and
+    transformed on a side stream while the caller works on batch i; `__next__` makes the caller's current stream wait
+    on that batch's event (no host synchronisation) and starts the next one."""
+
+    def __init__(self, batch, n_frames=8, size=224, num_classes=174, device="cuda:0", dtype=torch.float32, seed=0,
+                 depth=2):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("SyntheticClipLoader feeds a GPU (no CPU path)")
+        g = torch.Generator().manual_seed(seed)
+        self.n_frames, self.dtype = n_frames, dtype
+        self._host = [torch.randint(0, 256, (batch, size, size, 3 * n_frames), dtype=torch.uint8, generator=g).pin_memory()
+                      for _ in range(depth)]
+        self._labels = [torch.randint(0, num_classes, (batch,), generator=g).pin_memory() for _ in range(depth)]
+        self._stage = [torch.empty_like(h, device=self.device) for h in self._host]
+        self._out = [torch.empty(batch, 3 * n_frames, size, size, dtype=dtype, device=self.device) for _ in range(depth)]
+        self._lab = [torch.empty_like(l, device=self.device) for l in self._labels]
+        self._ready = [torch.cuda.Event() for _ in range(depth)]
+        self._consumed = [torch.cuda.Event() for _ in range(depth)]
+        self._stream = torch.cuda.Stream(self.device)
+        self._i = 0
+        for slot in range(depth):
+            self._consumed[slot].record(torch.cuda.current_stream(self.device))
+            self._launch(slot)
+
+    def _launch(self, slot):
+        """Queue copy + transform of the next batch of `slot` on the side stream (after its previous tenant was consumed)."""
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(self._consumed[slot])
+            self._stage[slot].copy_(self._host[slot], non_blocking=True)
+            self._lab[slot].copy_(self._labels[slot], non_blocking=True)
+            stacked_u8_to_clips(self._stage[slot], self.n_frames, dtype=self.dtype, out=self._out[slot])
+            self._ready[slot].record(self._stream)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        depth = len(self._host)
+        slot = self._i % depth
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._ready[slot])                            # device-side wait, the host does not block
+        if self._i > 0:
+            # everything the caller queued on the batch handed out one call ago is on `cur` by now: when it has run,
+            # that slot may be refilled -- which then overlaps the work on the batch returned here
+            prev = (self._i - 1) % depth
+            self._consumed[prev].record(cur)
+            self._launch(prev)
+        self._i += 1
+        out = self._out[slot]
+        return out.view(-1, self.n_frames, 3, out.shape[2], out.shape[3]), self._lab[slot]

@@ -9,20 +9,25 @@ counts, d(weight) always runs on the HIP kernels (fp32: 2.6x / 2.3x / 2.0x / 1.2
 transposes), and forward / d(input) do where they win -- the
 memory-bound 112x112 / 56x56 stages; elsewhere they stay on aten (MIOpen).  Other dtypes, 7x7 planes, strided
 shortcuts, CPU tensors: `conv(x)`.  `RK_PW=0` disables the HIP path, `RK_PW=all` forces the HIP GEMM wherever
-the kernel's constraints allow.
-Forward, d(input) and d(weight) are HIP MFMA kernels (`RK_PW_WGRAD=0`: d(weight) through aten / MIOpen).
+the kernel's constraints allow (config.py).  Forward, d(input) and d(weight) are HIP MFMA kernels.
 """
-import os
-
 import torch
 
-from . import _native
+from . import _native, config
+
+# measured win regions of the forward / d(input) GEMM against MIOpen (tools/pointwise_probe.py, DESIGN 3.5)
+_BF16_CMAX = 128            # bf16-MFMA GEMM, H*W >= 784
+_F32_CMAX_56 = 128          # fp32, H*W >= 3136
+_F32_CMAX_28 = 160          # fp32, H*W >= 784: 108 ch ties MIOpen (77 vs 76 us), 144 ch wins (123 vs 215)
+_F32_CMAX_14 = 320          # fp32, H*W >= 196: a tie on its own (288 ch: 101 vs 106 us), a win with the residual add fused
+_FUSED_EVAL_CMAX = 320      # inference fusion: channel limit of rk_pw_gemm_fused_f32's register tile
+_FUSED_EVAL_PMIN = 196      # ... and smallest plane it pays for
 
 __all__ = ["conv1x1", "stem_conv", "pointwise_mode", "fused_eval_block"]
 
 
 def pointwise_mode():
-    return os.environ.get("RK_PW", "auto")
+    return config.switches().pointwise
 
 
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}      # storage of the activations; weights are fp32
@@ -45,9 +50,6 @@ def _as(weight, dtype):
 def _wgrad(dy, x, weight):
     # the HIP kernels win on every probed shape: fp32 113 vs 295 us, bf16 (bf16 MFMA) 55 vs 133 us at
     # [256,54->54,56x56] -- MIOpen's d(weight) needs two layout transposes
-    if os.environ.get("RK_PW_WGRAD", "1") == "0":
-        return torch.ops.aten.convolution_backward(dy, x, _as(weight, x.dtype), None, *_ATEN_ARGS,
-                                                   [False, True, False])[1].to(weight.dtype)
     Fr, Cin, H, W = x.shape
     Cout = weight.shape[0]
     dev = x.device
@@ -126,16 +128,12 @@ def _eligible(conv, x, has_residual=False):
     # measured win region of the GEMM (tools/pointwise_probe.py); with a residual to fuse, the 28x28 tie
     # (77 vs 76 us) tips over: the epilogue add replaces a separate elementwise pass
     if x.dtype == torch.bfloat16:                        # bf16-MFMA GEMM: 43 vs 137 us at 56x56, 32 vs 80 us at 28x28
-        cmax = int(os.environ.get("RK_PW_BF16_CMAX", "128"))
-        return P >= 784 and K <= cmax and M <= cmax
-    cmax = int(os.environ.get("RK_PW_F32_CMAX28", "160"))
+        return P >= 784 and K <= _BF16_CMAX and M <= _BF16_CMAX
     if P >= 3136:
-        return K <= 128 and M <= 128
+        return K <= _F32_CMAX_56 and M <= _F32_CMAX_56
     if P >= 784:
-        return K <= cmax and M <= cmax                   # 28x28: 108 ch ties MIOpen (77 vs 76 us), 144 ch wins (123 vs 215)
-    # 14x14: about a tie on its own (288 ch: 101 vs 106 us), a win when the residual add rides on the epilogue
-    c14 = int(os.environ.get("RK_PW_F32_CMAX14", "320"))
-    return P >= 196 and K <= c14 and M <= c14
+        return K <= _F32_CMAX_28 and M <= _F32_CMAX_28
+    return P >= 196 and K <= _F32_CMAX_14 and M <= _F32_CMAX_14
 
 
 def conv1x1(conv, x, residual=None):
@@ -154,7 +152,7 @@ def conv1x1(conv, x, residual=None):
     # d(input) alone also wins one step wider: 144 channels at 28x28 (Large): 194 vs MIOpen's 363 us
     P = x.shape[2] * x.shape[3]
     hip_dx = hip_gemm or (x.dtype == torch.float32 and pointwise_mode() == "auto" and P >= 784
-                          and max(conv.in_channels, conv.out_channels) <= 160)
+                          and max(conv.in_channels, conv.out_channels) <= _F32_CMAX_28)
     return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual, hip_dx)
 
 
@@ -164,17 +162,13 @@ def conv1x1(conv, x, residual=None):
 # residual add on the conv3 GEMM: per block two GEMMs and the shift touch memory, nothing else.
 
 def _bn_affine(bn):
-    """(a, b) with bn(x) = a x + b in eval mode, cached on the module until a parameter / statistic changes."""
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_mean.data_ptr())
-    cached = getattr(bn, "_rk_affine", None)
-    if cached is None or cached[0] != key:
-        with torch.no_grad():
-            a = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
-            b = (bn.bias.float() - bn.running_mean.float() * a).contiguous()
-        cached = (key, a, b)
-        bn._rk_affine = cached
-    return cached[1], cached[2]
+    """(a, b) with bn(x) = a x + b in eval mode.  Recomputed on every call -- two [C]-sized ops -- because no cache
+    key sees in-place edits made through `.data` (EMA updates, checkpoint surgery; the reference itself initialises
+    with `fc.weight.data.normal_`)."""
+    with torch.no_grad():
+        a = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+        b = (bn.bias.float() - bn.running_mean.float() * a).contiguous()
+    return a, b
 
 
 def _gemm_fused(conv, x, pro=None, epi=None, residual=None):
@@ -197,7 +191,7 @@ def _plain_1x1(conv, x):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
             and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
-            and max(conv.in_channels, conv.out_channels) <= int(os.environ.get("RK_FUSED_EVAL_CMAX", "320")))
+            and max(conv.in_channels, conv.out_channels) <= _FUSED_EVAL_CMAX)
 
 
 def _eval_bn(bn):
@@ -219,15 +213,20 @@ def _stride_one(as3):
 
 def fused_eval_block(block, x):
     """Inference forward of a RubiksShiftBlock with bn1 / bn2 / the residual add fused into the two 1x1 GEMMs, or None
-    when the block does not qualify (training mode, gradients, bf16, SE layer, strided or wide layers, small planes,
-    `RK_FUSED_EVAL=0`) -- the caller then runs the layer-by-layer path."""
-    if (os.environ.get("RK_FUSED_EVAL", "1") == "0" or pointwise_mode() == "0" or block.training
-            or torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4)
+    when the block does not qualify (training mode, a gradient is actually wanted, bf16, SE layer, strided or wide
+    layers, small planes, `RK_FUSED_EVAL=0`) -- the caller then runs the layer-by-layer path.  "A gradient is wanted"
+    means grad mode is on AND the input or one of the block's parameters requires grad: a plain `model.eval()`
+    forward of a frozen model takes the same path, and gives the same logits, with or without `torch.no_grad()`."""
+    sw = config.switches()
+    if (not sw.fused_eval or sw.pointwise == "0" or block.training
+            or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4)
             or block.se is not None or x.numel() == 0):
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in block.parameters())):
         return None
     P = x.shape[2] * x.shape[3]
     identity = isinstance(block.shortcut, torch.nn.Identity)
-    if (P % 4 or P < int(os.environ.get("RK_FUSED_EVAL_PMIN", "196"))
+    if (P % 4 or P < _FUSED_EVAL_PMIN
             or not (_plain_1x1(block.conv2, x) and _plain_1x1(block.conv3, x))
             or not (_eval_bn(block.bn1) and _eval_bn(block.bn2)) or not (identity or _plain_1x1(block.shortcut, x))
             or not _stride_one(block.as3)):
@@ -270,7 +269,7 @@ def stem_conv(conv, x):
     """`conv(x)` for the backbone's 3x3 / stride-2 / pad-1 first layer (forward on the HIP GEMM; backward on aten)."""
     # under autocast the stock layer would produce a bf16 activation: leave it to autocast (an fp32 output here would
     # keep the next BatchNorm / shift in fp32 storage)
-    ok = (pointwise_mode() != "0" and os.environ.get("RK_STEM", "1") != "0" and not torch.is_autocast_enabled()
+    ok = (pointwise_mode() != "0" and not torch.is_autocast_enabled()
           and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
           and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
           and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None

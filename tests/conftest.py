@@ -36,3 +36,13 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _switches_from_the_real_environment():
+    """rubiksnet_amd.config reads RK_* once; tests that flip a switch call config.reload() after setenv, and every
+    test starts from whatever the (restored) environment says."""
+    from rubiksnet_amd import config
+
+    config.reload()
+    yield

@@ -8,6 +8,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+
+def _reload_switches():
+    from rubiksnet_amd import config
+    config.reload()
+
 pytestmark = pytest.mark.gpu
 
 SHAPES = [
@@ -135,6 +140,7 @@ def test_block_matches_stock_batchnorm(monkeypatch):
     outs = []
     for enabled in (True, False):
         monkeypatch.setenv("RK_FUSED_BN", "1" if enabled else "0")
+        _reload_switches()
         assert fused_bn.fused_bn_enabled() is enabled
         blk = copy.deepcopy(block)
         xi = x.clone().requires_grad_(True)

@@ -1,7 +1,8 @@
-"""The 3-D operator has four kernel families behind one entry point (LDS-DMA streaming, register-staged
-streaming, column, per-plane generic).  The default dispatch exercises the first and the column kernels; this
-re-runs a slice of the parity suite in a subprocess with the faster families switched off, so the fallbacks a
-production box would land on (odd alignment, RK_* overrides) stay bit-exact too."""
+"""The shift operators have several kernel families behind one entry point (LDS-DMA streaming: plane-group / column-walk /
+tile and the 2-D twins; column; per-plane generic).  The default dispatch exercises the streaming and column kernels; this
+re-runs the parity suites in a subprocess on each setting of the library's one switch, RK_SHIFT_KERNELS
+(rk_common.hpp), so the fallbacks a production box would land on (a buffer that is not 16-byte aligned, a shape no
+streaming kernel takes) stay bit-exact too."""
 import os
 import subprocess
 import sys
@@ -13,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("env", [
-    {"RK_DMA": "0", "RK_DMA_BWD": "0"},            # register-staged streaming kernels (rk3d_stream.hpp)
-    {"RK_DMA": "0", "RK_DMA_BWD": "0", "RK_COLUMN": "0", "RK_DMA2D": "0", "RK_COLUMN2D": "0"},   # + no column / 2-D streaming kernels
-    {"RK_FORCE_GENERIC": "1"},                     # per-plane generic kernels only
-], ids=["register-staged", "no-column-no-2d-streaming", "generic-only"])
+    {"RK_SHIFT_KERNELS": "column"},                # no LDS-DMA streaming kernels
+    {"RK_SHIFT_KERNELS": "generic"},               # per-plane generic kernels only
+    {"RK_FORCE_GENERIC": "1"},                     # older spelling of the same
+], ids=["column", "generic", "force-generic"])
 def test_parity_suite_on_fallback_kernels(env):
     e = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "bit_exact or shift_grad",

@@ -3,6 +3,11 @@ import numpy as np
 import pytest
 import torch
 
+
+def _reload_switches():
+    from rubiksnet_amd import config
+    config.reload()
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -107,7 +112,9 @@ def test_fused_paths_match_the_stock_backbone(monkeypatch):
     results = []
     for fast in (True, False):
         monkeypatch.setenv("RK_FUSED_BN", "1" if fast else "0")
+        _reload_switches()
         monkeypatch.setenv("RK_PW", "auto" if fast else "0")
+        _reload_switches()
         net = copy.deepcopy(ref)
         logits = net(clips)
         loss = torch.nn.functional.cross_entropy(logits, labels)
@@ -156,6 +163,7 @@ def test_fused_inference_blocks_match_layer_by_layer(monkeypatch, variant):
     with torch.no_grad():
         for fused in ("1", "0"):
             monkeypatch.setenv("RK_FUSED_EVAL", fused)
+            _reload_switches()
             outs.append(net(clips))
     if variant == "rubiks3d":
         assert len(calls) >= 6                               # the fused path really ran (>= 3 blocks x 2 GEMMs)

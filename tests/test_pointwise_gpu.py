@@ -7,6 +7,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+
+def _reload_switches():
+    from rubiksnet_amd import config
+    config.reload()
+
 pytestmark = pytest.mark.gpu
 
 CASES = [   # frames, Cin, Cout, H, W
@@ -27,6 +32,8 @@ def test_forward_and_gradients(monkeypatch, case):
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", "all")
+
+    _reload_switches()
     Fr, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(Fr, Cin, H, W, generator=g)
@@ -54,6 +61,8 @@ def test_fused_residual(monkeypatch, mode):
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", mode)
+
+    _reload_switches()
     torch.manual_seed(1)
     conv = nn.Conv2d(12, 20, 1, bias=False).cuda()
     x = torch.randn(3, 12, 8, 8, device="cuda", requires_grad=True)
@@ -76,6 +85,8 @@ def test_bf16_activations_fp32_weight(monkeypatch, case):
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", "all")
+
+    _reload_switches()
     Fr, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(Fr, Cin, H, W, generator=g).bfloat16()
@@ -103,6 +114,8 @@ def test_ineligible_layers_take_the_stock_path(monkeypatch):
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", "all")
+
+    _reload_switches()
     x = torch.randn(2, 6, 7, 7, device="cuda", requires_grad=True)          # 49 pixels: P % 4 != 0
     conv = nn.Conv2d(6, 8, 1, bias=False).cuda()
     y = conv1x1(conv, x)
@@ -111,6 +124,7 @@ def test_ineligible_layers_take_the_stock_path(monkeypatch):
     s2 = nn.Conv2d(6, 8, 1, stride=2, bias=False).cuda()                    # strided shortcut
     assert torch.equal(conv1x1(s2, x), s2(x))
     monkeypatch.setenv("RK_PW", "0")
+    _reload_switches()
     x4 = torch.randn(2, 6, 8, 8, device="cuda", requires_grad=True)
     assert "Conv1x1Func" not in type(conv1x1(conv, x4).grad_fn).__name__
 
