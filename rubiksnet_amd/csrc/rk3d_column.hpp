@@ -23,6 +23,8 @@
 // Channels with an exactly-integer shift component take the per-element reference formulation
 // (shared with the generic kernels) for the whole column.
 #pragma once
+#include <type_traits>
+
 #include "rk3d_generic.hpp"
 
 namespace rk {
@@ -119,7 +121,13 @@ __global__ __launch_bounds__(kBlock) void k3d_forward_column(const T* __restrict
 // for one j of {0, 1} at most, likewise k -- and the reference's tree collapses, exactly (the other three taps
 // are zeros: 0*w and x+0 are exact), to Q = wj (v wk), QH = +-(v wk), QW = +-(wj v): one load per element and
 // plane instead of four predicated ones (the four stride-(1,2,2) layers of each network run here).
-template <typename T, bool WRITE_GX, int kM, bool SINGLE>
+// VEC (kM == 4, fp32, input planes of a multiple of 4 elements, 16-byte aligned tensors): a thread owns 4 CONSECUTIVE
+// input elements, so the two big streams of a strided layer's backward -- x and gx, 4x the size of gy -- move as
+// 16-byte accesses instead of 4-byte ones; the gy taps stay scalar (L1-served; neighbouring elements share them).
+// Same arithmetic per element, bit-identical: [32,8,54,112,112] stride (1,2,2) 585 -> 373 us, [32,8,108,56,56]
+// 365 -> 240 us.  (The forward is the other way round -- its big stream is the GATHERED one, and consecutive
+// outputs per thread spread a wave's tap loads over 8x the cache lines: 213 -> 330 us; it stays element-strided.)
+template <typename T, bool WRITE_GX, int kM, bool SINGLE, bool VEC = false>
 __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restrict__ x, const T* __restrict__ shift,
                                                               const T* __restrict__ gy, T* __restrict__ gx,
                                                               T* __restrict__ part, CDims cd) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
             T wj[kM], wk[kM], sj[kM], sk[kM];                         // SINGLE: the tap's H / W weights and signs
 #pragma unroll
             for (int m = 0; m < kM; ++m) {
-                const int i = id.chunk * cd.E * kM + m * cd.E + e;
+                const int i = VEC ? id.chunk * cd.E * kM + e * kM + m : id.chunk * cd.E * kM + m * cd.E + e;
                 iidx[m] = i < HW ? i : -1;
                 const int ii = i < HW ? i : 0;
                 const int h = ii / d.W, w = ii - h * d.W;
@@ -174,11 +182,19 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
                     tap[m][SINGLE ? 0 : 3] = (live && r1 >= 0 && c1 >= 0) ? r1 * d.Wo + c1 : -1;
                 }
             }
+            auto load4 = [&](const T* plane, T (&dst)[kM], bool on) {    // my elements of one x plane
+                if constexpr (VEC) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (on && iidx[0] >= 0) v = *reinterpret_cast<const float4*>(plane + iidx[0]);
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                } else {
 #pragma unroll
-            for (int m = 0; m < kM; ++m) {
-                xa[m] = 0; Qprev[m] = 0;
-                xb[m] = iidx[m] >= 0 ? xc[iidx[m]] : (T)0;             // x[0]
-            }
+                    for (int m = 0; m < kM; ++m) dst[m] = (on && iidx[m] >= 0) ? plane[iidx[m]] : (T)0;
+                }
+            };
+#pragma unroll
+            for (int m = 0; m < kM; ++m) { xa[m] = 0; Qprev[m] = 0; }
+            load4(xc, xb, true);                                       // x[0]
             // step on gy plane tg; to = tg - fl'T - 1 is the input plane whose gx is completed
             const int t_first = fT.fl, t_last = d.T + fT.fl;
             for (int tg = t_first; tg <= t_last; ++tg) {
@@ -189,6 +205,8 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
                 T* out = WRITE_GX ? oc + (emit ? (size_t)to * tsi : 0) : nullptr;
                 const bool has_next = to + 2 < d.T;
                 const T* xn = xc + (has_next ? (size_t)(to + 2) * tsi : 0);
+                T xnext[kM], res[kM];
+                load4(xn, xnext, has_next);
 #pragma unroll
                 for (int m = 0; m < kM; ++m) {
                     T Q, QH, QW;
@@ -218,11 +236,16 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
                     sH += QH * mx;
                     sW += QW * mx;
                     if (WRITE_GX) {
-                        if (emit && iidx[m] >= 0) out[iidx[m]] = (1 - rT) * Qprev[m] + rT * Q;
+                        res[m] = (1 - rT) * Qprev[m] + rT * Q;
+                        if (!VEC && emit && iidx[m] >= 0) out[iidx[m]] = res[m];
                         Qprev[m] = Q;
                     }
                     xa[m] = xb[m];
-                    xb[m] = (has_next && iidx[m] >= 0) ? xn[iidx[m]] : (T)0;
+                    xb[m] = xnext[m];
+                }
+                if constexpr (VEC && WRITE_GX) {
+                    if (emit && iidx[0] >= 0)
+                        *reinterpret_cast<float4*>(out + iidx[0]) = make_float4(res[0], res[1], res[2], res[3]);
                 }
             }
             accT = sT; accH = sH; accW = sW;
@@ -264,6 +287,11 @@ inline unsigned grid_of(const CDims& cd) {
     return (unsigned)((groups + per_block - 1) / per_block);
 }
 
+// 16-byte accesses on the streamed planes: fp32, plane a multiple of 4 elements, 16-byte aligned tensors
+template <typename T> inline bool vec_ok(int plane_elems, const void* a, const void* b) {
+    return std::is_same<T, float>::value && plane_elems % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0;
+}
+
 template <typename T>
 inline int launch_forward(const T* x, const T* shift, T* y, const Dims3& d, hipStream_t stream) {
     const CDims cd = make_cdims(d, d.Ho * d.Wo);
@@ -280,11 +308,12 @@ inline int launch_backward(const T* x, const T* shift, const T* gy, T* gx, T* ws
                            hipStream_t stream) {
     const CDims cd = make_cdims(d, d.H * d.W);
     const bool single = d.sH >= 2 && d.sW >= 2;
-#define RK_COL_BWD(GX, MM, SG) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG>), dim3(grid_of(cd)), dim3(kBlock), \
-                                                  0, stream, x, shift, gy, gx, ws, cd)
-#define RK_COL_SG(GX, MM) do { if (single) RK_COL_BWD(GX, MM, true); else RK_COL_BWD(GX, MM, false); } while (0)
-    if (gx) { if (cd.M == 1) RK_COL_SG(true, 1); else RK_COL_SG(true, 4); }
-    else { if (cd.M == 1) RK_COL_SG(false, 1); else RK_COL_SG(false, 4); }
+    const bool vec = cd.M == 4 && vec_ok<T>(d.H * d.W, x, gx);
+#define RK_COL_BWD(GX, MM, SG, VC) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG, VC>), dim3(grid_of(cd)), dim3(kBlock), \
+                                                      0, stream, x, shift, gy, gx, ws, cd)
+#define RK_COL_SG(GX, MM, VC) do { if (single) RK_COL_BWD(GX, MM, true, VC); else RK_COL_BWD(GX, MM, false, VC); } while (0)
+    if (gx) { if (cd.M == 1) RK_COL_SG(true, 1, false); else if (vec) RK_COL_SG(true, 4, true); else RK_COL_SG(true, 4, false); }
+    else { if (cd.M == 1) RK_COL_SG(false, 1, false); else if (vec) RK_COL_SG(false, 4, true); else RK_COL_SG(false, 4, false); }
 #undef RK_COL_SG
 #undef RK_COL_BWD
     return d.N * cd.nchunks;
