@@ -102,6 +102,18 @@ int rk3d_backward_f64(const double* x, const double* shift, const double* gy,
                       int normalize_grad, double normalize_t_factor, int quantize,
                       void* workspace, size_t workspace_bytes, rk_stream_t stream);
 
+/* Two-phase form of rk3d_backward_f32, the phases of the reference's own host glue (rubiks.cpp:324-376):
+ * _partials = K2 + K3/K4: writes gx (or skips it when NULL) and the per-channel partial sums workspace[C][3][P],
+ * P returned through *partials; _finalize = addmv row-sum (:344-345) + K5 normalise (:352-358) into gshift[3][C].
+ * rk3d_backward_f32 is exactly _partials followed by _finalize (bench.py times the two kernels separately).     */
+int rk3d_backward_partials_f32(const float* x, const float* shift, const float* gy, float* gx,
+                               int N, int T, int C, int H, int W,
+                               int stride_T, int stride_H, int stride_W, int pad_T, int pad_H, int pad_W,
+                               int quantize, void* workspace, size_t workspace_bytes, int* partials,
+                               rk_stream_t stream);
+int rk3d_backward_finalize_f32(const void* workspace, int C, int partials, float* gshift,
+                               int normalize_grad, float normalize_t_factor, rk_stream_t stream);
+
 /* ------------------------------------------------------------------------- 2D
  * Replaces rubiks2d_forward (cuda_src/rubiks.cpp:44-67) + rubiks2d_forward_cuda
  * (rubiks2d_kernels.cu:408-432) + K6 (:94-145).  The reference dispatches

@@ -31,6 +31,8 @@ SIGNATURES = {
     "rk3d_backward_workspace_bytes": (_sz, _DIMS3 + [_i]),
     "rk3d_backward_f32": (_i, [_p] * 5 + _DIMS3 + [_i, ctypes.c_float, _i, _p, _sz, _p]),
     "rk3d_backward_f64": (_i, [_p] * 5 + _DIMS3 + [_i, ctypes.c_double, _i, _p, _sz, _p]),
+    "rk3d_backward_partials_f32": (_i, [_p] * 4 + _DIMS3 + [_i, _p, _sz, ctypes.POINTER(ctypes.c_int), _p]),
+    "rk3d_backward_finalize_f32": (_i, [_p, _i, _i, _p, _i, ctypes.c_float, _p]),
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
     "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_bn_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -62,10 +62,12 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     return launch_status();
 }
 
+// `P_out` != nullptr: two-phase use -- stop after the partials (ws[C][3][*P_out]) and report their count instead of
+// running the row-sum + K5 (rk3d_backward_finalize_* does that).
 template <typename T>
 int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int N, int Tn, int C, int H, int W,
                   int sT, int sH, int sW, int pT, int pH, int pW, int normalize_grad, T t_factor, int quantize,
-                  void* ws, size_t ws_bytes, rk_stream_t stream_) {
+                  void* ws, size_t ws_bytes, rk_stream_t stream_, int* P_out = nullptr) {
     if (!shift || !gy || (!gx && !gshift)) return RK_ERR_NULL_POINTER;
     if (gshift && !x) return RK_ERR_NULL_POINTER;
     Dims3 d;
@@ -75,39 +77,25 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         const size_t need = rk3d_backward_workspace_bytes(N, Tn, C, H, W, sT, sH, sW, pT, pH, pW, (int)sizeof(T));
         if (!ws || ws_bytes < need) return RK_ERR_WORKSPACE;
     }
+    // row-sum of the P partials per channel + K5 -- or, in two-phase use, just report P
+    auto finish = [&](int P) {
+        if (P_out) { *P_out = P; return launch_status(); }
+        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const T*)ws, gshift, d.C, P,
+                           normalize_grad, t_factor);
+        return launch_status();
+    };
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && gshift) {
-            if (const int P = dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const float*)ws, gshift,
-                                   d.C, P, normalize_grad, t_factor);
-                return launch_status();
-            }
-            if (const int P = tile3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k3d_finalize<float>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const float*)ws, gshift,
-                                   d.C, P, normalize_grad, t_factor);
-                return launch_status();
-            }
+            if (const int P = dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) return finish(P);
+            if (const int P = tile3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) return finish(P);
         } else if (!quantize && gx) {
             if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (tile3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
         }
     }
-    if (gshift && col3d::supported(d, quantize)) {
-        const int P = col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream);
-        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(finalize_block(P)), 0, stream, (const T*)ws, gshift, d.C, P,
-                           normalize_grad, t_factor);
-        return launch_status();
-    }
+    if (gshift && col3d::supported(d, quantize)) return finish(col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream));
 
-    if (gshift) {   // rubiks.cpp:324-358
-        T* part = (T*)ws;
-        set_group(d, d.Ho * d.Wo);
-        hipLaunchKernelGGL((k3d_backward_shift_generic<T>), dim3(grid_for(d, (long long)d.N * d.To * d.C)),
-                           dim3(kBlock), 0, stream, x, shift, gy, part, d);
-        hipLaunchKernelGGL((k3d_finalize<T>), dim3(d.C), dim3(finalize_block(d.N * d.To)), 0, stream, (const T*)part, gshift, d.C,
-                           d.N * d.To, normalize_grad, t_factor);
-    }
     if (gx) {       // rubiks.cpp:363-376
         set_group(d, d.H * d.W);
         const unsigned grid = grid_for(d, (long long)d.N * d.T * d.C);
@@ -117,6 +105,12 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         else
             hipLaunchKernelGGL((k3d_backward_input_generic<T, false>), dim3(grid), dim3(kBlock), 0, stream, shift,
                                gy, gx, d);
+    }
+    if (gshift) {   // rubiks.cpp:324-358
+        set_group(d, d.Ho * d.Wo);
+        hipLaunchKernelGGL((k3d_backward_shift_generic<T>), dim3(grid_for(d, (long long)d.N * d.To * d.C)),
+                           dim3(kBlock), 0, stream, x, shift, gy, (T*)ws, d);
+        return finish(d.N * d.To);
     }
     return launch_status();
 }
@@ -160,6 +154,26 @@ int rk3d_backward_f64(const double* x, const double* shift, const double* gy, do
                       rk_stream_t stream) {
     return backward_impl<double>(x, shift, gy, gx, gshift, N, T, C, H, W, sT, sH, sW, pT, pH, pW, normalize_grad,
                                  t_factor, quantize, ws, ws_bytes, stream);
+}
+
+// Two-phase form of the fp32 backward (the reference's own host glue has these phases, rubiks.cpp:324-376: K2 + K3/K4,
+// then addmv row-sum + K5): phase 1 writes d(x) and the per-channel partials ws[C][3][P] and returns P through
+// *partials; phase 2 sums them and normalises.  rk3d_backward_f32 == phase 1 + phase 2.
+int rk3d_backward_partials_f32(const float* x, const float* shift, const float* gy, float* gx, int N, int T, int C,
+                               int H, int W, int sT, int sH, int sW, int pT, int pH, int pW, int quantize, void* ws,
+                               size_t ws_bytes, int* partials, rk_stream_t stream) {
+    if (!partials || !ws) return RK_ERR_NULL_POINTER;
+    float* not_null = (float*)ws;        // "d(shift) wanted": the partials land in ws, nothing is written through this
+    return backward_impl<float>(x, shift, gy, gx, not_null, N, T, C, H, W, sT, sH, sW, pT, pH, pW, 0, 1.0f, quantize, ws,
+                                ws_bytes, stream, partials);
+}
+int rk3d_backward_finalize_f32(const void* ws, int C, int partials, float* gshift, int normalize_grad, float t_factor,
+                               rk_stream_t stream) {
+    if (!ws || !gshift) return RK_ERR_NULL_POINTER;
+    if (C <= 0 || partials <= 0) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL((k3d_finalize<float>), dim3(C), dim3(finalize_block(partials)), 0, (hipStream_t)stream,
+                       (const float*)ws, gshift, C, partials, normalize_grad, t_factor);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -129,6 +129,33 @@ def test_gradcheck_fp64():
         assert torch.autograd.gradcheck(fn, (x, shift), eps=1e-6, atol=1e-7, nondet_tol=0.0)
 
 
+def test_two_phase_backward_equals_the_one_call_form():
+    """rk3d_backward_partials_f32 + rk3d_backward_finalize_f32 (the phases of rubiks.cpp:324-376) == rk3d_backward_f32,
+    bit for bit, on a streaming shape, a tile shape and a strided (column) shape."""
+    import ctypes
+
+    from rubiksnet_amd import _native, rubiksnet_cuda
+
+    L = _native.lib()
+    for (N, T, C, H, W), s in (((2, 8, 6, 56, 56), (1, 1, 1)), ((2, 4, 8, 14, 14), (1, 1, 1)), ((1, 4, 5, 28, 28), (1, 2, 2))):
+        torch.manual_seed(N * C + H)
+        x = torch.rand(N, T, C, H, W, device="cuda:0") * 2 - 1
+        shift = torch.rand(3, C, device="cuda:0") * 2 - 1
+        Ho, Wo = (H - 1) // s[1] + 1, (W - 1) // s[2] + 1
+        gy = torch.rand(N, T, C, Ho, Wo, device="cuda:0") * 2 - 1
+        gx1, gs1 = torch.empty_like(x), torch.empty_like(shift)
+        rubiksnet_cuda.rubiks_shift_3d_backward_float(x, shift, gy, list(s), [0, 0, 0], gx1, gs1, True, 0.5, False)
+        nbytes = int(L.rk3d_backward_workspace_bytes(N, T, C, H, W, *s, 0, 0, 0, 4))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+        gx2, gs2, P = torch.empty_like(x), torch.empty_like(shift), ctypes.c_int(0)
+        st = torch.cuda.current_stream().cuda_stream
+        _native.check(L.rk3d_backward_partials_f32(x.data_ptr(), shift.data_ptr(), gy.data_ptr(), gx2.data_ptr(), N, T, C, H,
+                                                   W, *s, 0, 0, 0, 0, ws.data_ptr(), nbytes, ctypes.byref(P), st), "partials")
+        assert P.value > 0
+        _native.check(L.rk3d_backward_finalize_f32(ws.data_ptr(), C, P.value, gs2.data_ptr(), 1, 0.5, st), "finalize")
+        assert torch.equal(gx1, gx2) and torch.equal(gs1, gs2)
+
+
 def test_errors_are_raised_not_fatal():
     from rubiksnet_amd import rubiksnet_cuda
     from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_forward
