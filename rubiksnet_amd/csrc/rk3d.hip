@@ -86,7 +86,12 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
     };
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && gshift) {
-            if (const int P = dma3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) return finish(P);
+            // one-call form: row-sum + K5 happen inside the launch; two-phase form: plain partials
+            if (const int P = dma3d::launch_bwd(x, shift, gy, gx, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
+                                                t_factor, stream)) {
+                if (P_out) *P_out = P;
+                return launch_status();
+            }
             if (const int P = tile3d::launch_bwd(x, shift, gy, gx, (float*)ws, d, stream)) return finish(P);
         } else if (!quantize && gx) {
             if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
@@ -131,7 +136,8 @@ size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W, int sT, 
         if (chunks > per_n) per_n = chunks;
     }
     const size_t P = (size_t)N * per_n;
-    return (size_t)C * 3 * P * (size_t)elem_size;
+    // fp32: the streaming backward keeps its partials as 8-byte {value, tag} granules (rk3d_dma.hpp)
+    return (size_t)C * 3 * P * (size_t)(elem_size == 4 ? 8 : elem_size);
 }
 
 int rk3d_forward_f32(const float* x, const float* shift, float* y, int N, int T, int C, int H, int W, int sT,

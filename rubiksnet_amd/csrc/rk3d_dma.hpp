@@ -37,6 +37,9 @@
 // Loads and stores are non-temporal: every plane is read once by one CU and every output written
 // once.  Measured on [32,8,64,56,56]: nt stores + nt loads 197 us fwd+bwd vs 216 us without.
 #pragma once
+#include <atomic>
+#include <chrono>
+
 #include "rk_dma.hpp"
 
 namespace rk {
@@ -299,13 +302,73 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     accT = sT; accH = sH; accW = sW;
 }
 
+// Row-sum + K5 inside the backward launch (FUSED; replaces the separate k3d_finalize launch, 4.65 us + a kernel
+// boundary per call).  The producers do NOT wait for anything: each writes its three partials as 8-byte granules
+// {fp32 value, 32-bit launch tag} with ONE device-scope (sc1, write-through) store each -- the "data-tagged granule"
+// hand-off of MI355X_MICROARCH.md (price-list rows handoff-1to1 / R2) -- and exits.  The LAST C blocks of the grid
+// are finalizers, one wave per channel: they poll that channel's 3P granules with device-scope loads (s_sleep
+// between sweeps) until every one carries this launch's tag, then sum them in index order in fp64 -- the same
+// arithmetic as k3d_finalize on 64 threads, independent of arrival order -- and apply rubiks3d_kernels.cu:932-960.
+// They are dispatched behind the producers (and would be harmless ahead of them: 64 one-wave blocks against 768
+// producer slots, nothing waits on a finalizer).  The workspace is uninitialised memory; a stale granule can
+// pass for this launch's only if its upper 32 bits equal the tag (per-process counter seeded from the clock;
+// p = 2^-32 per granule on memory this kernel never wrote before).  A finalizer that has polled for ~100 ms gives
+// up and writes NaN: loud, never a hang.
+// (The first fused version -- last-ARRIVING producer finalizes, ticket by CAS -- cost +10 us: the store -> vmcnt(0)
+// -> CAS round trips sat on every producer's exit while it held its LDS slot.)
+struct Fin {
+    unsigned long long* gran;     // [C][3][P] granules
+    float* gshift;                // [3][C]
+    unsigned tag;                 // != 0, unique per launch
+    int producers;                // N * C * nbands blocks; blocks beyond are finalizers
+    int normalize;
+    float t_factor;
+};
+
+__device__ __forceinline__ void finalizer_wave(const Fin& fin, int c, int C, int P) {
+    const int lane = threadIdx.x;
+    const unsigned long long* g = fin.gran + (size_t)c * 3 * P;
+    double s[3] = {0, 0, 0};
+    bool ok = true;
+    for (int k = 0; k < 3; ++k)
+        for (int i = lane; i < P; i += kWave) {
+            unsigned long long v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; (unsigned)(v >> 32) != fin.tag && spin < 200000; ++spin) {
+                __builtin_amdgcn_s_sleep(32);
+                v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = ok && (unsigned)(v >> 32) == fin.tag;
+            s[k] += (double)__uint_as_float((unsigned)v);
+        }
+    for (int k = 0; k < 3; ++k) s[k] = wave_sum(s[k]);
+    const bool all_ok = __all(ok);
+    if (lane == 0) {
+        float gT = (float)s[0], gH = (float)s[1], gW = (float)s[2];
+        if (fin.normalize) {
+            float a, b, w;
+            if (fin.t_factor < 0) { a = gT; b = 0; w = 0; }
+            else { a = gT * fin.t_factor; b = gH; w = gW; }
+            const float mag = sqrtf(a * a + b * b + w * w);
+            if (mag > 0) { gT = a / mag; gH = b / mag; gW = w / mag; }
+        }
+        if (!all_ok) gT = gH = gW = __uint_as_float(0x7fc00000u);
+        fin.gshift[c] = gT;
+        fin.gshift[C + c] = gH;
+        fin.gshift[2 * C + c] = gW;
+    }
+}
+
 // (forcing <= 128 VGPRs with __launch_bounds__(256, 4) on an earlier version spilled and ran 13% slower)
-template <int ROUNDS, bool WRITE_GX, int DG, int DX>
+template <int ROUNDS, bool WRITE_GX, int DG, int DX, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restrict__ x,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gy,
                                                            float* __restrict__ gx,
-                                                           float* __restrict__ part, BDims d, Dims3 gd) {
+                                                           float* __restrict__ part, BDims d, Dims3 gd, Fin fin) {
+    if (FUSED && (int)blockIdx.x >= fin.producers) {
+        if (threadIdx.x < kWave) finalizer_wave(fin, (int)blockIdx.x - fin.producers, d.C, d.N * d.nbands);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[3][kBlock / kWave];
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
@@ -344,10 +407,17 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
     accW = group_sum(accW, kBlock, red[2]);
     if (threadIdx.x == 0) {
         const int P = d.N * d.nbands;
-        float* o = part + (size_t)c * 3 * P + (size_t)n * d.nbands + band;
-        o[0] = accT;
-        o[P] = accH;
-        o[2 * P] = accW;
+        const size_t at = (size_t)c * 3 * P + (size_t)n * d.nbands + band;
+        if (FUSED) {
+            const unsigned long long hi = (unsigned long long)fin.tag << 32;
+            __hip_atomic_store(fin.gran + at, hi | __float_as_uint(accT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fin.gran + at + P, hi | __float_as_uint(accH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fin.gran + at + 2 * P, hi | __float_as_uint(accW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            part[at] = accT;
+            part[at + P] = accH;
+            part[at + 2 * P] = accW;
+        }
     }
 }
 
@@ -384,28 +454,48 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
     return true;
 }
 
-template <bool WRITE_GX, int DG, int DX>
+template <bool WRITE_GX, int DG, int DX, bool FUSED>
 inline void launch_bwd_d(const float* x, const float* shift, const float* gy, float* gx, float* ws, const BDims& b,
-                         const Dims3& d, hipStream_t stream) {
+                         const Dims3& d, const Fin& fin, hipStream_t stream) {
     const size_t lds = bwd_ring_bytes(b, DG, DX);
-    const dim3 grid((unsigned)(b.N * b.C * b.nbands)), block(kBlock);
+    const dim3 grid((unsigned)(b.N * b.C * b.nbands + (FUSED ? b.C : 0))), block(kBlock);
     switch (rounds_of(b)) {
-        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
-        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
-        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
-        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d); break;
+        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
     }
 }
 
-// d(shift) partials (+ d(x) when gx != nullptr) into ws[C][3][P]; returns P (0 = not handled here).
-// One gy plane and one x plane in flight (2 / 2 measured within 1 %: the memory system, not latency, bounds it).
-inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* ws, const Dims3& d,
-                      hipStream_t stream) {
+inline unsigned next_launch_tag() {
+    static std::atomic<unsigned> tag{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
+    unsigned t = tag.fetch_add(1, std::memory_order_relaxed);
+    return t ? t : tag.fetch_add(1, std::memory_order_relaxed);
+}
+
+// d(shift) (+ d(x) when gx != nullptr).  One gy plane and one x plane in flight (2 / 2 measured within 1 %: the
+// memory system, not latency, bounds it).  gshift != nullptr: row-sum + K5 fused into the launch (ws holds 8-byte
+// granules [C][3][P]); gshift == nullptr: plain float partials ws[C][3][P] for a separate finalize (two-phase API).
+// Returns P (0 = not handled here).
+inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                      const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
     BDims b;
     if (!make_bdims(b, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
     if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return 0;
-    if (gx) launch_bwd_d<true, 1, 1>(x, shift, gy, gx, ws, b, d, stream);
-    else launch_bwd_d<false, 1, 1>(x, shift, gy, gx, ws, b, d, stream);
+    Fin fin;
+    fin.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.gshift = gshift;
+    fin.tag = next_launch_tag();
+    fin.producers = b.N * b.C * b.nbands;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+    if (gshift) {
+        if (gx) launch_bwd_d<true, 1, 1, true>(x, shift, gy, gx, ws, b, d, fin, stream);
+        else launch_bwd_d<false, 1, 1, true>(x, shift, gy, gx, ws, b, d, fin, stream);
+    } else {
+        if (gx) launch_bwd_d<true, 1, 1, false>(x, shift, gy, gx, ws, b, d, fin, stream);
+        else launch_bwd_d<false, 1, 1, false>(x, shift, gy, gx, ws, b, d, fin, stream);
+    }
     return b.N * b.nbands;
 }
 

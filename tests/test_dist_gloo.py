@@ -134,3 +134,24 @@ def test_ddp_gloo_world2(tmp_path, oracle):
         assert torch.allclose(r0["grads"][k], want, atol=1e-6), k
     unit = per_rank[0]["as3.shift"].norm(dim=0)
     assert np.allclose(unit.numpy(), 1.0, atol=1e-5)          # each replica's shift grad is unit-norm per channel
+
+
+def test_bench_launches_itself_for_two_ranks_dry_run():
+    """`python bench.py --gpus 2` with no torchrun environment re-executes itself under torch.distributed.run on
+    127.0.0.1; without a GPU it takes the dry-run path (launcher, rendezvous, barrier + max-over-ranks
+    timing, all-reduce probe on gloo) and rank 0 prints ONE JSON line."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = ""           # force the CPU path even on a GPU box
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dry-run"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry_run"] is True and out["backend"] == "gloo"
+    assert out["allreduce_probe"]["ranks"] == 2 and out["allreduce_probe"]["bus_GBps"] > 0
+    assert out["steps"] == 2 and out["scaling"] == "weak" and out["metric"].startswith("RubiksShift3D")
