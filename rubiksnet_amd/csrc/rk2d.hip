@@ -42,7 +42,8 @@ size_t workspace2(const Dims2& d, size_t elem) {
     int P = dma2d::backward2_partials(d, dma2d::kFramesF32 < dma2d::kFrames16 ? dma2d::kFramesF32 : dma2d::kFrames16);
     const int Pc = col2d::backward_partials(d);
     P = P > Pc ? P : Pc;
-    return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * elem;
+    // the streaming backwards keep their fp32 partials as 8-byte {value, tag} granules (rk_dma.hpp)
+    return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * (elem < 8 ? 8 : elem);
 }
 
 unsigned grid2(const Dims2& d) {
@@ -96,19 +97,15 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
         if (!quantize) {
             if (!enable_shift_grad) {
                 if (dma2d::launch_interp2<true>(gy, shift, gx, d, stream)) return launch_status();
-            } else if (const int P = dma2d::launch_backward2(gy, x, shift, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(P)), 0, stream, (const CT*)ws, gshift, C, P,
-                                   normalize_grad);
-                return launch_status();
+            } else if (dma2d::launch_backward2(gy, x, shift, gx, gshift, ws, normalize_grad, d, stream)) {
+                return launch_status();                               // row-sum + K9 happened inside the launch
             }
         }
     } else if constexpr (!std::is_same<T, double>::value) {
         if (!quantize) {
             if (!enable_shift_grad) {
                 if (stage2d::launch_interp2<T, true>(gy, shift, gx, d, stream)) return launch_status();
-            } else if (const int P = stage2d::launch_backward2<T>(gy, x, shift, gx, (float*)ws, d, stream)) {
-                hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(P)), 0, stream, (const CT*)ws, gshift, C, P,
-                                   normalize_grad);
+            } else if (stage2d::launch_backward2<T>(gy, x, shift, gx, gshift, ws, normalize_grad, d, stream)) {
                 return launch_status();
             }
         }

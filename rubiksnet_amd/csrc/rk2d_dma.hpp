@@ -263,16 +263,41 @@ __device__ __forceinline__ void backward2_loop(const float* __restrict__ xp, con
     accH = sH; accW = sW;
 }
 
+// K9 (rubiks2d_kernels.cu:381-397) on the row sums, written in the storage type of gshift
+template <typename S> struct Fin2 {
+    Fin f;
+    S* gshift;                    // [2][C]
+    int normalize;
+};
+template <typename S>
+__device__ __forceinline__ void finalizer_wave2(const Fin2<S>& fin, int c, int C, int P) {
+    double s[2];
+    const bool ok = fin_collect<2>(fin.f, c, P, s);
+    if (threadIdx.x == 0) {
+        float gH = (float)s[0], gW = (float)s[1];
+        if (fin.normalize) {
+            const float mag = sqrtf(gH * gH + gW * gW);
+            if (mag > 0) { gH = gH / mag; gW = gW / mag; }
+        }
+        if (!ok) gH = gW = __uint_as_float(0x7fc00000u);
+        st(fin.gshift + c, gH);
+        st(fin.gshift + C + c, gW);
+    }
+}
+
 template <int ROUNDS, int DG, int DX>
 __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restrict__ gy,
                                                            const float* __restrict__ x,
                                                            const float* __restrict__ shift,
-                                                           float* __restrict__ gx, float* __restrict__ part,
-                                                           FDims fd, Dims2 gd) {
+                                                           float* __restrict__ gx, FDims fd, Dims2 gd, Fin2<float> fin) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[2][kBlock / kWave];
     (void)gd;
     const BDims& d = fd.b;
+    if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
+        if (threadIdx.x < kWave) finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands);
+        return;
+    }
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
     const int c = col % d.C, g = col / d.C;
     const float s0 = shift[c], s1 = shift[d.C + c];
@@ -332,9 +357,9 @@ __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restri
     accW = group_sum(accW, kBlock, red[1]);
     if (threadIdx.x == 0) {
         const int P = fd.ngroups * d.nbands;
-        float* o = part + (size_t)c * 2 * P + (size_t)g * d.nbands + band;
-        o[0] = accH;
-        o[P] = accW;
+        const size_t at = (size_t)c * 2 * P + (size_t)g * d.nbands + band;
+        fin_publish(fin.f, at, accH);
+        fin_publish(fin.f, at + P, accW);
     }
 }
 
@@ -380,22 +405,28 @@ inline int backward2_partials(const Dims2& d, int frames_per_group) {
     return make_fdims(f, d, frames_per_group) ? f.ngroups * f.b.nbands : 0;
 }
 
-// d(x) + d(shift) partials into ws[C][2][P]; returns P (0 = not handled here)
-inline int launch_backward2(const float* gy, const float* x, const float* shift, float* gx, float* ws,
-                            const Dims2& d, hipStream_t stream) {
+// d(x) + d(shift) (row-sum + K9 inside the launch: ws holds granules [C][2][P]); false = not handled here
+inline bool launch_backward2(const float* gy, const float* x, const float* shift, float* gx, float* gshift, void* ws,
+                             int normalize, const Dims2& d, hipStream_t stream) {
     constexpr int DG = 1, DX = 1;
     FDims f;
-    if (!make_fdims(f, d, kFramesF32) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return 0;
+    if (!make_fdims(f, d, kFramesF32) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
     const size_t lds = bwd_ring_bytes(f.b, DG, DX);
-    if (lds > 64 * 1024) return 0;
-    const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
+    if (lds > 64 * 1024) return false;
+    Fin2<float> fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    const dim3 grid((unsigned)(fin.f.producers + f.b.C)), block(kBlock);
     switch (rounds_of(f.b)) {
-        case 1: hipLaunchKernelGGL((k2d_dma_backward<1, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
-        case 2: hipLaunchKernelGGL((k2d_dma_backward<2, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
-        case 3: hipLaunchKernelGGL((k2d_dma_backward<3, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
-        default: hipLaunchKernelGGL((k2d_dma_backward<4, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
+        case 1: hipLaunchKernelGGL((k2d_dma_backward<1, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+        case 2: hipLaunchKernelGGL((k2d_dma_backward<2, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+        case 3: hipLaunchKernelGGL((k2d_dma_backward<3, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+        default: hipLaunchKernelGGL((k2d_dma_backward<4, DG, DX>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
     }
-    return f.ngroups * f.b.nbands;
+    return true;
 }
 
 }  // namespace dma2d

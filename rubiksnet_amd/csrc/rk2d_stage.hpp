@@ -239,10 +239,14 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
 template <typename T, int ROUNDS>
 __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const T* __restrict__ shift, T* __restrict__ gx,
-                                                             float* __restrict__ part, FDims fd, Dims2 gd) {
+                                                             FDims fd, Dims2 gd, dma2d::Fin2<T> fin) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[2][kBlock / kWave];
     const BDims& d = fd.b;
+    if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
+        if (threadIdx.x < kWave) dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands);
+        return;
+    }
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
     const int c = col % d.C, g = col / d.C;
     const float s0 = ld(shift + c), s1 = ld(shift + d.C + c);
@@ -303,9 +307,9 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict
     accW = group_sum(accW, kBlock, red[1]);
     if (threadIdx.x == 0) {
         const int P = fd.ngroups * d.nbands;
-        float* o = part + (size_t)c * 2 * P + (size_t)g * d.nbands + band;
-        o[0] = accH;
-        o[P] = accW;
+        const size_t at = (size_t)c * 2 * P + (size_t)g * d.nbands + band;
+        fin_publish(fin.f, at, accH);
+        fin_publish(fin.f, at + P, accW);
     }
 }
 
@@ -328,21 +332,27 @@ inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d,
     return true;
 }
 
-// d(x) + d(shift) partials into ws[C][2][P]; returns P (0 = not handled here)
+// d(x) + d(shift) (row-sum + K9 inside the launch: ws holds granules [C][2][P]); false = not handled here
 template <typename T>
-inline int launch_backward2(const T* gy, const T* x, const T* shift, T* gx, float* ws, const Dims2& d,
-                            hipStream_t stream) {
+inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* gshift, void* ws, int normalize,
+                             const Dims2& d, hipStream_t stream) {
     FDims f;
-    if (!dma2d::make_fdims(f, d, dma2d::kFrames16) || !aligned8(gy) || !aligned8(x) || !aligned8(gx)) return 0;
+    if (!dma2d::make_fdims(f, d, dma2d::kFrames16) || !aligned8(gy) || !aligned8(x) || !aligned8(gx)) return false;
     const size_t lds = ring_bytes(f.b);
-    const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
+    dma2d::Fin2<T> fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    const dim3 grid((unsigned)(fin.f.producers + f.b.C)), block(kBlock);
     switch (rounds_of(f.b)) {
-        case 1: hipLaunchKernelGGL((k2d_stage_backward<T, 1>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
-        case 2: hipLaunchKernelGGL((k2d_stage_backward<T, 2>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
-        case 3: hipLaunchKernelGGL((k2d_stage_backward<T, 3>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
-        default: hipLaunchKernelGGL((k2d_stage_backward<T, 4>), grid, block, lds, stream, gy, x, shift, gx, ws, f, d); break;
+        case 1: hipLaunchKernelGGL((k2d_stage_backward<T, 1>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+        case 2: hipLaunchKernelGGL((k2d_stage_backward<T, 2>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+        case 3: hipLaunchKernelGGL((k2d_stage_backward<T, 3>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+        default: hipLaunchKernelGGL((k2d_stage_backward<T, 4>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
     }
-    return f.ngroups * f.b.nbands;
+    return true;
 }
 
 }  // namespace stage2d

@@ -37,9 +37,6 @@
 // Loads and stores are non-temporal: every plane is read once by one CU and every output written
 // once.  Measured on [32,8,64,56,56]: nt stores + nt loads 197 us fwd+bwd vs 216 us without.
 #pragma once
-#include <atomic>
-#include <chrono>
-
 #include "rk_dma.hpp"
 
 namespace rk {
@@ -302,47 +299,18 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     accT = sT; accH = sH; accW = sW;
 }
 
-// Row-sum + K5 inside the backward launch (FUSED; replaces the separate k3d_finalize launch, 4.65 us + a kernel
-// boundary per call).  The producers do NOT wait for anything: each writes its three partials as 8-byte granules
-// {fp32 value, 32-bit launch tag} with ONE device-scope (sc1, write-through) store each -- the "data-tagged granule"
-// hand-off of MI355X_MICROARCH.md (price-list rows handoff-1to1 / R2) -- and exits.  The LAST C blocks of the grid
-// are finalizers, one wave per channel: they poll that channel's 3P granules with device-scope loads (s_sleep
-// between sweeps) until every one carries this launch's tag, then sum them in index order in fp64 -- the same
-// arithmetic as k3d_finalize on 64 threads, independent of arrival order -- and apply rubiks3d_kernels.cu:932-960.
-// They are dispatched behind the producers (and would be harmless ahead of them: 64 one-wave blocks against 768
-// producer slots, nothing waits on a finalizer).  The workspace is uninitialised memory; a stale granule can
-// pass for this launch's only if its upper 32 bits equal the tag (per-process counter seeded from the clock;
-// p = 2^-32 per granule on memory this kernel never wrote before).  A finalizer that has polled for ~100 ms gives
-// up and writes NaN: loud, never a hang.
-// (The first fused version -- last-ARRIVING producer finalizes, ticket by CAS -- cost +10 us: the store -> vmcnt(0)
-// -> CAS round trips sat on every producer's exit while it held its LDS slot.)
-struct Fin {
-    unsigned long long* gran;     // [C][3][P] granules
+// Row-sum + K5 inside the backward launch (FUSED): rk_dma.hpp, "Row-sum of the d(shift) partials INSIDE the backward
+// launch".  K5 = rubiks3d_kernels.cu:932-960.
+struct Fin3 {
+    Fin f;
     float* gshift;                // [3][C]
-    unsigned tag;                 // != 0, unique per launch
-    int producers;                // N * C * nbands blocks; blocks beyond are finalizers
     int normalize;
     float t_factor;
 };
-
-__device__ __forceinline__ void finalizer_wave(const Fin& fin, int c, int C, int P) {
-    const int lane = threadIdx.x;
-    const unsigned long long* g = fin.gran + (size_t)c * 3 * P;
-    double s[3] = {0, 0, 0};
-    bool ok = true;
-    for (int k = 0; k < 3; ++k)
-        for (int i = lane; i < P; i += kWave) {
-            unsigned long long v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int spin = 0; (unsigned)(v >> 32) != fin.tag && spin < 200000; ++spin) {
-                __builtin_amdgcn_s_sleep(32);
-                v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ok = ok && (unsigned)(v >> 32) == fin.tag;
-            s[k] += (double)__uint_as_float((unsigned)v);
-        }
-    for (int k = 0; k < 3; ++k) s[k] = wave_sum(s[k]);
-    const bool all_ok = __all(ok);
-    if (lane == 0) {
+__device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, int P) {
+    double s[3];
+    const bool ok = fin_collect<3>(fin.f, c, P, s);
+    if (threadIdx.x == 0) {
         float gT = (float)s[0], gH = (float)s[1], gW = (float)s[2];
         if (fin.normalize) {
             float a, b, w;
@@ -351,7 +319,7 @@ __device__ __forceinline__ void finalizer_wave(const Fin& fin, int c, int C, int
             const float mag = sqrtf(a * a + b * b + w * w);
             if (mag > 0) { gT = a / mag; gH = b / mag; gW = w / mag; }
         }
-        if (!all_ok) gT = gH = gW = __uint_as_float(0x7fc00000u);
+        if (!ok) gT = gH = gW = __uint_as_float(0x7fc00000u);
         fin.gshift[c] = gT;
         fin.gshift[C + c] = gH;
         fin.gshift[2 * C + c] = gW;
@@ -364,9 +332,9 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gy,
                                                            float* __restrict__ gx,
-                                                           float* __restrict__ part, BDims d, Dims3 gd, Fin fin) {
-    if (FUSED && (int)blockIdx.x >= fin.producers) {
-        if (threadIdx.x < kWave) finalizer_wave(fin, (int)blockIdx.x - fin.producers, d.C, d.N * d.nbands);
+                                                           float* __restrict__ part, BDims d, Dims3 gd, Fin3 fin) {
+    if (FUSED && (int)blockIdx.x >= fin.f.producers) {
+        if (threadIdx.x < kWave) finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
@@ -409,10 +377,9 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
         const int P = d.N * d.nbands;
         const size_t at = (size_t)c * 3 * P + (size_t)n * d.nbands + band;
         if (FUSED) {
-            const unsigned long long hi = (unsigned long long)fin.tag << 32;
-            __hip_atomic_store(fin.gran + at, hi | __float_as_uint(accT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(fin.gran + at + P, hi | __float_as_uint(accH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(fin.gran + at + 2 * P, hi | __float_as_uint(accW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fin_publish(fin.f, at, accT);
+            fin_publish(fin.f, at + P, accH);
+            fin_publish(fin.f, at + 2 * P, accW);
         } else {
             part[at] = accT;
             part[at + P] = accH;
@@ -456,7 +423,7 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
 
 template <bool WRITE_GX, int DG, int DX, bool FUSED>
 inline void launch_bwd_d(const float* x, const float* shift, const float* gy, float* gx, float* ws, const BDims& b,
-                         const Dims3& d, const Fin& fin, hipStream_t stream) {
+                         const Dims3& d, const Fin3& fin, hipStream_t stream) {
     const size_t lds = bwd_ring_bytes(b, DG, DX);
     const dim3 grid((unsigned)(b.N * b.C * b.nbands + (FUSED ? b.C : 0))), block(kBlock);
     switch (rounds_of(b)) {
@@ -465,12 +432,6 @@ inline void launch_bwd_d(const float* x, const float* shift, const float* gy, fl
         case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
         default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
     }
-}
-
-inline unsigned next_launch_tag() {
-    static std::atomic<unsigned> tag{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
-    unsigned t = tag.fetch_add(1, std::memory_order_relaxed);
-    return t ? t : tag.fetch_add(1, std::memory_order_relaxed);
 }
 
 // d(shift) (+ d(x) when gx != nullptr).  One gy plane and one x plane in flight (2 / 2 measured within 1 %: the
@@ -482,11 +443,11 @@ inline int launch_bwd(const float* x, const float* shift, const float* gy, float
     BDims b;
     if (!make_bdims(b, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
     if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return 0;
-    Fin fin;
-    fin.gran = reinterpret_cast<unsigned long long*>(ws);
+    Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = b.N * b.C * b.nbands;
     fin.gshift = gshift;
-    fin.tag = next_launch_tag();
-    fin.producers = b.N * b.C * b.nbands;
     fin.normalize = normalize;
     fin.t_factor = t_factor;
     if (gshift) {

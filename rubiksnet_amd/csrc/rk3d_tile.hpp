@@ -26,7 +26,7 @@
 // -> k3d_finalize.  Channels with an exactly-integer shift component use the per-element helpers of
 // rk3d_generic.hpp for d(x) / d(shift) (lowered-index quirk :290-298), one wave per channel column.
 #pragma once
-#include "rk_dma.hpp"
+#include "rk3d_dma.hpp"
 
 namespace rk {
 namespace tile3d {
@@ -271,11 +271,15 @@ __global__ __launch_bounds__(kBlock) void k3d_tile_interp(const float* __restric
 
 // ---------------------------------------------------------------------------------------------
 // Backward: d(x) (WRITE_GX) + d(shift) partials part[c][3][P = N], p = n.
-template <int H, int W, int GCO, int kRing, bool WRITE_GX>
+template <int H, int W, int GCO, int kRing, bool WRITE_GX, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k3d_tile_backward(const float* __restrict__ x, const float* __restrict__ shift,
                                                             const float* __restrict__ gy, float* __restrict__ gx,
-                                                            float* __restrict__ part, TDims d, Dims3 gd) {
+                                                            float* __restrict__ part, TDims d, Dims3 gd, dma3d::Fin3 fin) {
     using G = Geo<H, W, GCO>;
+    if (FUSED && (int)blockIdx.x >= fin.f.producers) {                // row-sum + K5 inside the launch (rk_dma.hpp)
+        if (threadIdx.x < kWave) dma3d::finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N);
+        return;
+    }
     using SG = SlotGeo<G>;
     constexpr int S = kRing - 2;                                     // x runs S planes ahead, like gy beyond f0+k+1
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -409,16 +413,18 @@ __global__ __launch_bounds__(kBlock) void k3d_tile_backward(const float* __restr
         }
         aT = wave_sum(aT); aH = wave_sum(aH); aW = wave_sum(aW);
         if (lane == 0) {
-            float* o = part + (size_t)c * 3 * d.N + it.n;
-            o[0] = aT; o[d.N] = aH; o[2 * d.N] = aW;
+            const size_t at = (size_t)c * 3 * d.N + it.n;
+            if (FUSED) { fin_publish(fin.f, at, aT); fin_publish(fin.f, at + d.N, aH); fin_publish(fin.f, at + 2 * d.N, aW); }
+            else { part[at] = aT; part[at + d.N] = aH; part[at + 2 * d.N] = aW; }
         }
     }
 #pragma unroll
     for (int g = 0; g < G::GC; ++g) {
         const float a = wave_sum(sT[g]), b = wave_sum(sH[g]), w = wave_sum(sW[g]);
         if (lane == 0 && g < it.nch && tab[g].state == 1) {
-            float* o = part + (size_t)(it.c0 + g) * 3 * d.N + it.n;
-            o[0] = a; o[d.N] = b; o[2 * d.N] = w;
+            const size_t at = (size_t)(it.c0 + g) * 3 * d.N + it.n;
+            if (FUSED) { fin_publish(fin.f, at, a); fin_publish(fin.f, at + d.N, b); fin_publish(fin.f, at + 2 * d.N, w); }
+            else { part[at] = a; part[at + d.N] = b; part[at + 2 * d.N] = w; }
         }
     }
 }
@@ -456,22 +462,33 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
 }
 
 template <int H, int W, int GCO, int RING>
-inline int launch_bwd_hw(const float* x, const float* shift, const float* gy, float* gx, float* ws, const Dims3& d,
-                         hipStream_t stream) {
+inline int launch_bwd_hw(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                         const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
     using G = Geo<H, W, GCO>;
     TDims t;
     if (!tile_dims<G>(t, d)) return 0;
-    const unsigned grid = (unsigned)(((long long)t.N * t.NG + 3) / 4);
+    const unsigned producers = (unsigned)(((long long)t.N * t.NG + 3) / 4);
     const size_t lds = 4 * wave_lds_bytes<G>(RING + RING - 2);
-    if (gx) hipLaunchKernelGGL((k3d_tile_backward<H, W, GCO, RING, true>), dim3(grid), dim3(kBlock), lds, stream, x, shift, gy, gx, ws, t, d);
-    else hipLaunchKernelGGL((k3d_tile_backward<H, W, GCO, RING, false>), dim3(grid), dim3(kBlock), lds, stream, x, shift, gy, gx, ws, t, d);
+    dma3d::Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = (int)producers;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+#define RK_TILE_BWD(GX, FU) hipLaunchKernelGGL((k3d_tile_backward<H, W, GCO, RING, GX, FU>), dim3(producers + (FU ? d.C : 0)), \
+                                               dim3(kBlock), lds, stream, x, shift, gy, gx, ws, t, d, fin)
+    if (gshift) { if (gx) RK_TILE_BWD(true, true); else RK_TILE_BWD(false, true); }
+    else { if (gx) RK_TILE_BWD(true, false); else RK_TILE_BWD(false, false); }
+#undef RK_TILE_BWD
     return d.N;
 }
-// d(shift) partials (+ d(x) when gx != nullptr) into ws[C][3][P]; returns P (0 = not handled here)
-inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* ws, const Dims3& d,
-                      hipStream_t stream) {
+// d(shift) (+ d(x) when gx != nullptr); gshift != nullptr: row-sum + K5 fused into the launch (ws = granules), else
+// plain partials ws[C][3][P].  Returns P (0 = not handled here)
+inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                      const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
     if (!s1p0(d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
-    return launch_bwd_hw<14, 14, 2, 3>(x, shift, gy, gx, ws, d, stream);
+    return launch_bwd_hw<14, 14, 2, 3>(x, shift, gy, gx, gshift, ws, d, normalize, t_factor, stream);
 }
 
 }  // namespace tile3d

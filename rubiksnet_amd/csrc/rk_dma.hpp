@@ -3,6 +3,9 @@
 // with a shared zero cell, compile-time tap selection, and the host-side band choice.  See rk3d_dma.hpp
 // for the description of the scheme.
 #pragma once
+#include <atomic>
+#include <chrono>
+
 #include "rk3d_generic.hpp"
 
 namespace rk {
@@ -183,6 +186,59 @@ __device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slo
             if (o < b.cells_in && !cs.in_act[i]) slot[o] = z;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-sum of the d(shift) partials INSIDE the backward launch (instead of a separate finalize launch, ~4.5 us + a
+// kernel boundary per call).  Producers do not wait for anything: a workgroup (or wave) writes each of its D
+// partials as an 8-byte granule {fp32 value, 32-bit launch tag} with ONE device-scope (sc1, write-through) store
+// -- the "data-tagged granule" hand-off of MI355X_MICROARCH.md (price-list rows handoff-1to1 / R2) -- and exits.  The
+// LAST C blocks of the grid are finalizers, one wave per channel: they poll that channel's D*P granules with
+// device-scope loads (s_sleep between sweeps) until every one carries this launch's tag, then sum them in index
+// order in fp64 -- independent of arrival order, so results stay deterministic -- and the caller applies K5 / K9.
+// Finalizers are dispatched behind the producers (and would be harmless ahead of them: C one-wave blocks against
+// hundreds of producer slots; nothing waits on a finalizer).  The workspace is uninitialised memory: a stale
+// granule passes for this launch's only if its upper 32 bits equal the tag (per-process counter seeded from the
+// clock; p = 2^-32 per granule on memory these kernels never wrote).  A finalizer that has polled ~150 ms gives up
+// and the caller writes NaN: loud, never a hang.
+// (The first fused version -- the last-ARRIVING producer finalizes, ticket by CAS -- cost +10 us: the store ->
+// vmcnt(0) -> CAS round trips sat on every producer's exit while it held its LDS slot.)
+struct Fin {
+    unsigned long long* gran;     // [C][D][P] granules
+    unsigned tag;                 // != 0, unique per launch
+    int producers;                // producer blocks; blocks beyond are finalizers
+};
+inline unsigned next_launch_tag() {
+    static std::atomic<unsigned> tag{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
+    unsigned t = tag.fetch_add(1, std::memory_order_relaxed);
+    return t ? t : tag.fetch_add(1, std::memory_order_relaxed);
+}
+__device__ __forceinline__ void fin_publish(const Fin& fin, size_t at, float v) {
+    __hip_atomic_store(fin.gran + at, ((unsigned long long)fin.tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave (lanes 0..63 of the block): s[k] = sum_i granule[c][k][i] over this launch's P partials; false = timed out
+template <int D>
+__device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double (&s)[D]) {
+    const int lane = threadIdx.x;
+    const unsigned long long* g = fin.gran + (size_t)c * D * P;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        s[k] = 0;
+        for (int i = lane; i < P; i += kWave) {
+            unsigned long long v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; (unsigned)(v >> 32) != fin.tag && spin < 200000; ++spin) {
+                __builtin_amdgcn_s_sleep(32);
+                v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = ok && (unsigned)(v >> 32) == fin.tag;
+            s[k] += (double)__uint_as_float((unsigned)v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) s[k] = wave_sum(s[k]);
+    return __all(ok) != 0;
 }
 
 // ---------------------------------------------------------------------------------------------
