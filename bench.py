@@ -266,8 +266,10 @@ def model_bench(env, leg, per_gpu_batch, steps, warmup):
                 dp.train_step(model, opt, clips, labels)
         desc = "train step (fwd+bwd+Adam%s), %s" % (", DDP all-reduce" if env.distributed else "",
                                                      "bf16 autocast" if amp is not None else "fp32")
+    # untimed run-in: a fresh process needs ~40 steps before a train step reaches its sustained time (Tiny: 35.6 ms
+    # averaged over steps 3-8, 30.9 over 3-22, 28.4 over 3-152: MIOpen / allocator warm-up, then the clock settle)
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.3:          # same clock / power settle as the operator leg (untimed)
+    while time.perf_counter() - t0 < 1.5:
         step()
         torch.cuda.synchronize()
     for _ in range(warmup):
