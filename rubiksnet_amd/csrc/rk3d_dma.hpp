@@ -162,6 +162,20 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
 //   x : ring of D landing slots; a wave only reads back the cells it DMA'd itself (its own aligned
 //       cells), into the 2-plane register window (x[to], x[to+1]) at the top of the step, which
 //       frees the slot for the plane D steps ahead.
+// Pairing of the fields of gy plane k with the x window (xa = x[k-1], xb = x[k]), as coefficients so that the SAME loop
+// serves channels whose temporal shift is exactly integer:
+//     gT += Q (cb xb + ca xa),   gH += QH (mb xb + ma xa),   gW += QW (mb xb + ma xa).
+// Ordinary channel: (cb, ca, mb, ma) = (1, -1, 1-r'T, r'T) -- bit for bit the former x[k] - x[k-1] and fma(uT, xb, rT xa).
+// Integer temporal shift (every channel of create_3d_from_2d(init_mode="tsm"), the reference's default,
+// layer.py:137-141): the reference lowers the small temporal index by one (rubiks3d_kernels.cu:290-298) and uses that
+// lowered plane, with weight 1 - rT = 1, in the H and W faces too (:362-431), which in this adjoint form reads
+//     gT = sum_k <x[k], Q(k-1)> - <x[k-1], Q(k)>,   gH = sum_k <x[k-1], QH(k)>,   gW = sum_k <x[k-1], QW(k)>:
+// walk B (this plane order, coefficients (0, -1, 0, 1)) gives the second gT term, gH, gW and d(x); walk A (gy planes
+// one step later, t_first - 1, coefficients (1, 0, 0, 0)) gives the first gT term.  Walk A runs FIRST and its
+// stores to gx are overwritten by walk B's (same thread, same addresses, in order).  Twice the traffic for such a
+// channel instead of the per-element path on one workgroup per column.  The walk loop sits INSIDE each tap-offset
+// copy: around the switch over the copies the compiler hoists the set-up of all four out of it (256 VGPRs).
+
 template <int ROUNDS, bool WRITE_GX, int DG, int DX, int OFF>
 __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
                                                   float* __restrict__ op, float4* ring, const BDims& d,
@@ -187,15 +201,26 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     const float* xsrc0 = xp + (size_t)b.out0 * 4;
     float* out0 = WRITE_GX ? op + (size_t)b.out0 * 4 : nullptr;
 
+    float sT = 0.f, sH = 0.f, sW = 0.f;
+    int issued = 0;
+    const bool t_integer = rT == 0;                               // wave-uniform
+#pragma nounroll
+    for (int walk = t_integer ? 0 : 1; walk < 2; ++walk) {
+    const float cb = t_integer ? (walk == 0 ? 1.f : 0.f) : 1.f, ca = t_integer ? (walk == 0 ? 0.f : -1.f) : -1.f;
+    const float mb = t_integer ? 0.f : uT, ma = t_integer ? (walk == 0 ? 0.f : 1.f) : rT;
+    if (walk == 1 && t_integer) {
+        // walk A's trailing prefetches (planes it never consumed) must land before walk B's prologue zero-fills the
+        // same slots, and every wave must be done reading the ring
+        wait_vmcnt(0);
+        __syncthreads();
+    }
     float4 xa[ROUNDS], xb[ROUNDS], Qprev[ROUNDS];
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) xa[i] = xb[i] = Qprev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float sT = 0.f, sH = 0.f, sW = 0.f;
 
     // step k: gy plane tg = t_first + k is in gy slot k % RG; to = k - 1; x[k] (-> xb) is in x slot k % RX
-    const int t_first = fT.fl, steps = d.T + 1;
+    const int t_first = fT.fl - (t_integer && walk == 0 ? 1 : 0), steps = d.T + 1;
     auto in_range = [&](int t) { return t >= 0 && t < d.T; };
-    int issued = 0;
     auto feed = [&](int tg, int gs, int tx, int xs) {               // DMA when the plane exists, zeros when not
         if (in_range(tg)) {
             dma_taps<ROUNDS>(gsrc0 + (ptrdiff_t)tg * (ptrdiff_t)tstride, gaddr + gs * gslot_bytes, cs);
@@ -242,8 +267,8 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
             const float la = tap<OFF>(qa0, qa1, m) * uW + tap<OFF>(qa0, qa1, m + 1) * rW;
             const float lb = tap<OFF>(qb0, qb1, m) * uW + tap<OFF>(qb0, qb1, m + 1) * rW;
             q[m] = uH * la + rH * lb;                             // the reference's tree, contraction off
-            const float dx = xbv[m] - xav[m];
-            const float mx = fmaf(uT, xbv[m], rT * xav[m]);
+            const float dx = fmaf(cb, xbv[m], ca * xav[m]);
+            const float mx = fmaf(mb, xbv[m], ma * xav[m]);
             sT = fmaf(q[m], dx, sT);
             sH = fmaf(la - lb, mx, sH);
             sW = fmaf(col[m] - col[m + 1], mx, sW);
@@ -296,6 +321,7 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     step(0, std::false_type{});
 #pragma nounroll
     for (int k = 1; k < steps; ++k) step(k, std::true_type{});
+    }
     accT = sT; accH = sH; accW = sW;
 }
 
@@ -328,7 +354,7 @@ __device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, in
 
 // (forcing <= 128 VGPRs with __launch_bounds__(256, 4) on an earlier version spilled and ran 13% slower)
 template <int ROUNDS, bool WRITE_GX, int DG, int DX, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k3d_dma_backward(const float* __restrict__ x,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gy,
                                                            float* __restrict__ gx,
@@ -344,8 +370,8 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
     const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
     float accT = 0.f, accH = 0.f, accW = 0.f;
 
-    if (split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0) {
-        // exactly-integer component (lowered-index quirk / zero-shift copy branch): rare, per element.
+    if (split_shift(s1).r == 0 || split_shift(s2).r == 0) {
+        // exactly-integer H or W component (lowered-index quirk / zero-shift copy branch): rare, per element.
         // Band 0 does the whole column; the other bands contribute zero partials.
         if (band == 0) {
             if (WRITE_GX)
@@ -362,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_backward(const float* __restri
         const float* gp = gy + ((size_t)n * d.T * d.C + c) * HW;
         float* op = WRITE_GX ? gx + ((size_t)n * d.T * d.C + c) * HW : nullptr;
         const Band b = make_band(d, band, fH.fl);
-        switch (((fW.fl % 4) + 4) % 4) {   // wave-uniform; one specialised copy of the loop per tap offset
+        const int off = ((fW.fl % 4) + 4) % 4;
+        switch (off) {   // wave-uniform; one specialised copy of the loop per tap offset
             case 0: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 0>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
             case 1: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 1>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
             case 2: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 2>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;

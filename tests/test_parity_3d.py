@@ -269,6 +269,33 @@ def test_backward_halves_match_fused(oracle, kind):
     np.testing.assert_allclose(to_np(gs_only), raw_ref, rtol=0, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("hw", [(56, 56), (28, 28), (112, 112), (14, 14)])
+@pytest.mark.parametrize("wide", [False, True])
+def test_tsm_init_integer_temporal_shifts(oracle, hw, wide):
+    """create_3d_from_2d(init_mode="tsm") (reference layer.py:137-141): EVERY channel has an exactly-integer temporal
+    shift (+1 / -1 / 0 folds, here also +-2, +-3 when `wide`) next to fractional (H, W) shifts.  The streaming
+    backward walks such a channel twice with the lowered-index pairing (rk3d_dma.hpp) instead of per element."""
+    H, W = hw
+    rng = np.random.default_rng(H * 131 + wide)
+    C = 16
+    x = rand(rng, (2, 5, C, H, W), np.float32)
+    gy = rand(rng, x.shape, np.float32)
+    shift = rng.uniform(-1.7, 1.7, (3, C)).astype(np.float32)
+    folds = np.array([1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0] * 2, np.float32)
+    shift[0] = folds if not wide else rng.choice([-3.0, -2.0, -1.0, 0.0, 1.0, 2.0, 3.0, 5.0], C)
+    np.testing.assert_array_equal(_run_fwd(x, shift, 1, 0, False), oracle.rk3d_forward(x, shift, 1, 0, False))
+    gx_ref, _, raw_ref = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64),
+                                              normalize_grad=False, return_raw=True)
+    gx32_ref, _ = oracle.rk3d_backward(gy, x, shift, 1, 0)
+    gx, gs = _run_bwd(gy, x, shift, 1, 0, False, normalize=False)
+    np.testing.assert_array_equal(gx, gx32_ref)
+    scale = max(1.0, float(np.abs(raw_ref).max()))
+    np.testing.assert_allclose(gs, raw_ref, rtol=0, atol=1e-5 * scale)
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
+    _, gs_only = rubiks_shift_3d_backward(to_dev(gy), to_dev(x), to_dev(shift), 1, 0, False, need_x_grad=False)
+    np.testing.assert_allclose(to_np(gs_only), raw_ref, rtol=0, atol=1e-5 * scale)
+
+
 def test_empty_batch_and_single_element(oracle):
     """Edge sizes: N = 0 (the reference launches over zero elements and returns an empty tensor) and 1x1x1 planes."""
     from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d, rubiks_shift_3d_forward
