@@ -90,6 +90,31 @@ __global__ __launch_bounds__(256) void k_band(const f32x4* __restrict__ src, f32
         }
 }
 
+// ---- variant C: 2R + 1W (the backward's mix): dst = a + b over the same walk as k_walk.
+__global__ __launch_bounds__(256) void k_walk2(const f32x4* __restrict__ a, const f32x4* __restrict__ bsrc,
+                                               f32x4* __restrict__ dst, P p) {
+    extern __shared__ float pad[];
+    const int chunks = p.T / p.S;
+    int b = blockIdx.x;
+    const int c = b % p.C; b /= p.C;
+    int n, ch;
+    if (p.order == 0) { ch = b % chunks; n = b / chunks; } else { n = b % p.N; ch = b / p.N; }
+    const size_t tstride = (size_t)p.C * PL;
+    const size_t base = (((size_t)n * p.T + (size_t)ch * p.S) * p.C + c) * PL;
+    f32x4 ca[RND], cb[RND], na[RND], nb[RND];
+    ld_plane(na, a + base);
+    ld_plane(nb, bsrc + base);
+    for (int k = 0; k < p.S; ++k) {
+#pragma unroll
+        for (int i = 0; i < RND; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+        if (k + 1 < p.S) { ld_plane(na, a + base + (size_t)(k + 1) * tstride); ld_plane(nb, bsrc + base + (size_t)(k + 1) * tstride); }
+#pragma unroll
+        for (int i = 0; i < RND; ++i) ca[i] += cb[i];
+        st_plane(ca, dst + base + (size_t)k * tstride);
+    }
+    if (threadIdx.x == 1023) pad[0] = 0.f;
+}
+
 int main(int argc, char** argv) {
     const size_t planes = 32 * 8 * 64;
     const size_t bytes = planes * PL * 16;
@@ -175,5 +200,26 @@ int main(int argc, char** argv) {
         const double req = bytes * (1.0 + (double)p.cells_in / p.cells_out);
         printf("%-34s %8.1f %8.1f %8.2f %8.2f\n", name, med, ts[0], 2.0 * bytes / med / 1e6, req / med / 1e6);
     }
+    printf("\n# part 3: 2R + 1W (dst = a + b), same walk as part 1\n%-28s %8s %8s %8s\n", "N,T,C,S,order,lds", "us(med)", "us(min)", "TB/s");
+    for (int lds : {0, 40 * 1024, 52 * 1024})
+        for (int S : {8, 4, 2, 1}) {
+            P p{32, 8, 64, S, 0};
+            const unsigned grid = (unsigned)(32 * 64 * (8 / S));
+            std::vector<float> ts;
+            for (int it = 0; it < 14; ++it) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_walk2, dim3(grid), dim3(256), (size_t)lds, 0, src[it % SETS], dst[it % SETS], dst[(it + 1) % SETS], p);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (it >= 2) ts.push_back(ms * 1e3f);
+            }
+            std::sort(ts.begin(), ts.end());
+            const float med = ts[ts.size() / 2];
+            char name[64];
+            snprintf(name, sizeof name, "32,8,64,%d,0,%d", S, lds / 1024);
+            printf("%-28s %8.1f %8.1f %8.2f\n", name, med, ts[0], 3.0 * bytes / med / 1e6);
+        }
     return 0;
 }
