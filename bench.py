@@ -135,9 +135,10 @@ def op_bench(env, steps, warmup, nsets=3, settle_s=0.4):
     }
 
 
-def op2d_bench(env, iters=20):
+def op2d_bench(env, iters=60, settle_s=0.3):
     """the 2-D operator of the -aq networks on the same number of elements
-    ([256,64,56,56] = 32 clips x 8 frames), fp32 and bf16.  Median of event-bracketed launches."""
+    ([256,64,56,56] = 32 clips x 8 frames), fp32 and bf16.  Same method as the 3-D leg: an untimed run-in (the
+    chip's clock / power transient), then `iters` back-to-back launches of one kernel between ONE pair of events."""
     dev = env.device
     out = {}
     for dtype, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
@@ -150,26 +151,39 @@ def op2d_bench(env, iters=20):
         g = torch.Generator(device="cpu").manual_seed(1)
         shift = (torch.rand(2, shape[1], generator=g) * 1.8 - 0.9).to(dev).to(dtype)
         gs = torch.empty_like(shift)
-        ev = []
-        for i in range(iters):
-            x, _, y, _ = sets[i % 3]
-            xb, gy, _, gx = sets[(i + 1) % 3]
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record()
+        it = [0]
+
+        def fwd():
+            x, _, y, _ = sets[it[0] % 3]
+            it[0] += 1
             rubiksnet_cuda.rubiks2d_forward(x, shift, [1, 1], [0, 0], False, y)
-            e[1].record()
+
+        def bwd():
+            xb, gy, _, gx = sets[it[0] % 3]
+            it[0] += 1
             rubiksnet_cuda.rubiks2d_backward(gy, xb, shift, [1, 1], [0, 0], True, True, False, gx, gs)
-            e[2].record()
-            ev.append(e)
-        torch.cuda.synchronize()
-        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
-        tf = med([e[0].elapsed_time(e[1]) for e in ev[3:]]) * 1e-3
-        tb = med([e[1].elapsed_time(e[2]) for e in ev[3:]]) * 1e-3
+
+        def timed(fn):
+            t_end = time.perf_counter() + settle_s
+            while time.perf_counter() < t_end:
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e-3
+
+        tf, tb = timed(fwd), timed(bwd)
         es, n = x.element_size(), x.numel()
         out[name] = {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": 2 * es * n / tf / 1e9,
                      "bwd_GBps": 3 * es * n / tb / 1e9,
                      "fwd_plus_bwd_frac_of_hbm_peak": 5 * es * n / (tf + tb) / 1e9 / HBM_PEAK_GBS}
     out["shape"] = [SHAPE[0] * SHAPE[1]] + list(SHAPE[2:])
+    out["timing"] = "untimed run-in, then back-to-back launches of one kernel between one pair of HIP events"
     return out
 
 

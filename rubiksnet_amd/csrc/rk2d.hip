@@ -12,6 +12,7 @@
 #include "rk2d_generic.hpp"
 #include "rk2d_dma.hpp"
 #include "rk2d_stage.hpp"
+#include "rk2d_raw16.hpp"
 #include "rk2d_column.hpp"
 
 using namespace rk;
@@ -40,8 +41,9 @@ void set_group2(Dims2& d, int plane_elems) {
 size_t workspace2(const Dims2& d, size_t elem) {
     // the smaller group size gives the larger partial count: an upper bound for every storage type
     int P = dma2d::backward2_partials(d, dma2d::kFramesF32 < dma2d::kFrames16 ? dma2d::kFramesF32 : dma2d::kFrames16);
-    const int Pc = col2d::backward_partials(d);
+    const int Pc = col2d::backward_partials(d), Pr = raw16::backward2_partials(d);
     P = P > Pc ? P : Pc;
+    P = P > Pr ? P : Pr;
     // the streaming backwards keep their fp32 partials as 8-byte {value, tag} granules (rk_dma.hpp)
     return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * (elem < 8 ? 8 : elem);
 }
@@ -62,6 +64,7 @@ int forward2(const void* x_, const void* shift_, void* y_, int N, int C, int H, 
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && dma2d::launch_interp2<false>(x, shift, y, d, stream)) return launch_status();
     } else if constexpr (!std::is_same<T, double>::value) {
+        if (!quantize && raw16::launch_interp2<T, false>(x, shift, y, d, stream)) return launch_status();   // W % 8 == 0
         if (!quantize && stage2d::launch_interp2<T, false>(x, shift, y, d, stream)) return launch_status();
     }
     // small planes only: on larger ones the per-plane kernel below is the faster forward (stride-2 56x56 ->
@@ -104,8 +107,10 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
     } else if constexpr (!std::is_same<T, double>::value) {
         if (!quantize) {
             if (!enable_shift_grad) {
+                if (raw16::launch_interp2<T, true>(gy, shift, gx, d, stream)) return launch_status();
                 if (stage2d::launch_interp2<T, true>(gy, shift, gx, d, stream)) return launch_status();
-            } else if (stage2d::launch_backward2<T>(gy, x, shift, gx, gshift, ws, normalize_grad, d, stream)) {
+            } else if (raw16::launch_backward2<T>(gy, x, shift, gx, gshift, ws, normalize_grad, d, stream) ||
+                       stage2d::launch_backward2<T>(gy, x, shift, gx, gshift, ws, normalize_grad, d, stream)) {
                 return launch_status();
             }
         }
