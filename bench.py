@@ -187,6 +187,64 @@ def op2d_bench(env, iters=60, settle_s=0.3):
     return out
 
 
+def secondary_points(env, iters=40, settle_s=0.2):
+    """SURVEY 8(d) secondary points of the 3-D operator: the two real-model extremes -- the stride-(1,2,2) layer
+    [32,8,54,112,112] and the small-plane layer [32,8,216,14,14] -- and the benchmark shape with quantize=True.
+    Algorithmic bytes: 4 (numel_in + numel_out) forward, 4 (numel_out + 2 numel_in) backward.  Timed like the
+    other operator legs (run-in, then back-to-back launches of one kernel between one pair of events)."""
+    dev = env.device
+    out = {}
+    points = (("stride_1_2_2", (32, 8, 54, 112, 112), [1, 2, 2], False),
+              ("planes_14x14", (32, 8, 216, 14, 14), [1, 1, 1], False),
+              ("quantize", SHAPE, [1, 1, 1], True))
+    for name, shape, stride, quantize in points:
+        N, T, C, H, W = shape
+        Ho, Wo = (H - 1) // stride[1] + 1, (W - 1) // stride[2] + 1
+        oshape = (N, T, C, Ho, Wo)
+        g = torch.Generator(device="cpu").manual_seed(2)
+        shift = (torch.rand(3, C, generator=g) * 2 - 1).to(dev)
+        sets = []
+        for _ in range(3):
+            sets.append((torch.empty(shape, device=dev).uniform_(-1, 1), torch.empty(oshape, device=dev).uniform_(-1, 1),
+                         torch.empty(oshape, device=dev), torch.empty(shape, device=dev)))
+        gs = torch.empty(3, C, device=dev)
+        it = [0]
+
+        def fwd():
+            x, _, y, _ = sets[it[0] % 3]
+            it[0] += 1
+            rubiksnet_cuda.rubiks_shift_3d_forward_float(x, shift, stride, [0, 0, 0], quantize, y)
+
+        def bwd():
+            x, gy, _, gx = sets[it[0] % 3]
+            it[0] += 1
+            rubiksnet_cuda.rubiks_shift_3d_backward_float(x, shift, gy, stride, [0, 0, 0], gx, gs, True, 1.0, quantize)
+
+        def timed(fn):
+            t_end = time.perf_counter() + settle_s
+            while time.perf_counter() < t_end:
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e-3
+
+        tf, tb = timed(fwd), timed(bwd)
+        nin, nout = N * T * C * H * W, N * T * C * Ho * Wo
+        bf, bb = 4 * (nin + nout), 4 * (nout + 2 * nin)
+        out[name] = {"x": list(shape), "stride": stride, "quantize": quantize, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6,
+                     "fwd_GBps": bf / tf / 1e9, "bwd_GBps": bb / tb / 1e9,
+                     "fwd_plus_bwd_frac_of_hbm_peak": (bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS}
+        del sets
+        torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the newest PMC summary committed under profiles/
     (tools/pmc.sh + tools/make_profile_summary.py: separate rocprofv3 --pmc passes, FETCH_SIZE doubled)."""
@@ -422,6 +480,7 @@ def main():
 
     traffic, traffic_src = pmc_traffic("backward")
     rk2d = op2d_bench(env) if env.is_main else None
+    secondary = secondary_points(env) if env.is_main else None
 
     if env.is_main:
         out = {
@@ -460,6 +519,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "rk2d": rk2d,
+            "secondary": secondary,
             "model": models.get("tiny-train"),
             "models": models,
             "input_pipeline": feeder,

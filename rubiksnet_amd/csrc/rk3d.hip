@@ -5,6 +5,7 @@
 #include "rk3d_dma.hpp"
 #include "rk3d_plane.hpp"
 #include "rk3d_tile.hpp"
+#include "rk3d_translate.hpp"
 #include "rk3d_column.hpp"
 
 #include <type_traits>
@@ -51,6 +52,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
         if (!quantize && plane3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && tile3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
+        if (quantize && xlate3d::launch<false>(x, shift, y, d, stream)) return launch_status();   // plane translation
     }
     if (col3d::supported(d, quantize)) return col3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);
@@ -85,6 +87,20 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         return launch_status();
     };
     if constexpr (std::is_same<T, float>::value) {
+        // quantize: d(x) is a plane translation; d(shift) does not depend on quantize (K2 takes the fractional
+        // shift, rubiks.cpp:324-358), so it comes from the streaming backward without its d(x) half
+        if (quantize && gx && xlate3d::launch<true>(gy, shift, gx, d, stream)) {
+            if (!gshift) return launch_status();
+            gx = nullptr;
+            int P = dma3d::launch_bwd(x, shift, gy, nullptr, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
+                                      t_factor, stream);
+            if (!P) P = tile3d::launch_bwd(x, shift, gy, nullptr, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
+                                           t_factor, stream);
+            if (P) {
+                if (P_out) *P_out = P;
+                return launch_status();
+            }
+        }
         if (!quantize && gshift) {
             // one-call form: row-sum + K5 happen inside the launch; two-phase form: plain partials
             if (const int P = dma3d::launch_bwd(x, shift, gy, gx, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,

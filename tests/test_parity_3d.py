@@ -85,6 +85,32 @@ def test_shift_grad_matches_fp64_oracle(oracle, cfg, kind, dtype):
         np.testing.assert_allclose(g, g_ref, rtol=0, atol=(2e-5 if dtype == np.float32 else 1e-11))
 
 
+@pytest.mark.parametrize("cfg", [(2, 4, 6, 56, 56, (1, 1, 1), (0, 0, 0)), (3, 5, 6, 14, 14, (1, 1, 1), (0, 0, 0)),
+                                 (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)), (2, 8, 16, 14, 14, (1, 2, 2), (0, 1, 1))])
+@pytest.mark.parametrize("kind", ["generic", "wide", "half"])
+def test_quantize_backward_both_halves(oracle, cfg, kind):
+    """quantize=True backward: d(x) is the nearest-position translation (bit-exact), d(shift) is K2 on the fractional
+    shift (the reference's K2 takes no quantize flag).  On the streaming shapes the two halves come from different
+    kernels (rk3d_translate.hpp + the d(shift)-only streaming backward)."""
+    N, T, C, H, W, s, p = cfg
+    rng = np.random.default_rng(seed_of(cfg, kind, "q"))
+    x = rand(rng, (N, T, C, H, W), np.float32)
+    shift = special_shifts(rng, 3, C, np.float32, kind)
+    gy = rand(rng, oracle.rk3d_forward(x, shift, s, p, True).shape, np.float32)
+    gx_ref, _ = oracle.rk3d_backward(gy, x, shift, s, p, quantize=True)
+    _, _, raw_ref = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64), s, p,
+                                         normalize_grad=False, quantize=True, return_raw=True)
+    gx, raw = _run_bwd(gy, x, shift, s, p, True, normalize=False)
+    np.testing.assert_array_equal(gx, gx_ref)
+    scale = max(1.0, float(np.abs(raw_ref).max()))
+    np.testing.assert_allclose(raw, raw_ref, rtol=0, atol=1e-5 * scale)
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
+    gx_only, none_s = rubiks_shift_3d_backward(to_dev(gy), to_dev(x), to_dev(shift), s, p, False, quantize=True,
+                                               need_shift_grad=False)
+    assert none_s is None
+    np.testing.assert_array_equal(to_np(gx_only), gx_ref)
+
+
 def test_autograd_function_and_module(oracle):
     """rubiks_shift_3d (Function) and RubiksShift3D (Module) wire the same numbers through autograd."""
     from rubiksnet_amd.shiftlib import RubiksShift3D
