@@ -6,6 +6,7 @@
 #include "rk3d_plane.hpp"
 #include "rk3d_tile.hpp"
 #include "rk3d_translate.hpp"
+#include "rk3d_stride2.hpp"
 #include "rk3d_column.hpp"
 
 #include <type_traits>
@@ -53,6 +54,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && tile3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (quantize && xlate3d::launch<false>(x, shift, y, d, stream)) return launch_status();   // plane translation
+        if (!quantize && s2::launch_forward(x, shift, y, d, stream)) return launch_status();       // stride (1,2,2)
     }
     if (col3d::supported(d, quantize)) return col3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);

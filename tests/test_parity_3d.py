@@ -22,7 +22,9 @@ SHAPES = [
     (2, 3, 4, 9, 7, (1, 2, 2), (0, 1, 1)),
     (1, 6, 3, 10, 11, (2, 1, 3), (1, 2, 0)),       # stride/pad in T too
     (1, 1, 2, 5, 5, (1, 1, 1), (0, 0, 0)),         # T = 1
-    (2, 8, 3, 112, 112, (1, 2, 2), (0, 0, 0)),     # first stage of the nets
+    (2, 8, 3, 112, 112, (1, 2, 2), (0, 0, 0)),     # first stage of the nets (stride-2 streaming kernels, 4 bands)
+    (2, 3, 4, 56, 56, (1, 2, 2), (0, 0, 0)),       # stride-2 streaming, one band
+    (1, 2, 5, 16, 24, (1, 2, 2), (0, 0, 0)),       # stride-2 streaming, small ragged plane (Wo4 = 3)
     (1, 4, 3, 112, 112, (1, 1, 1), (0, 0, 0)),     # 112x112 stride 1: 4 row bands on the streaming path
     (1, 3, 2, 96, 64, (1, 1, 1), (0, 0, 0)),       # 4 bands of 24 rows, 16 float4 columns
     (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)),       # one band, ragged last round
