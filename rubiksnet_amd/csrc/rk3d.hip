@@ -115,6 +115,11 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
                 if (P_out) *P_out = P;
                 return launch_status();
             }
+            if (const int P = s2::launch_backward(x, shift, gy, gx, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
+                                                  t_factor, stream)) {      // stride (1,2,2)
+                if (P_out) *P_out = P;
+                return launch_status();
+            }
         } else if (!quantize && gx) {
             if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();

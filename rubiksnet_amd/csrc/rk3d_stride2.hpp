@@ -198,6 +198,222 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_forward(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward: d(x) (WRITE_GX) + d(shift) partials part[c][3][P], P = N * nbands, in ONE walk (adjoint form of
+// rk3d_dma.hpp, with the NEGATED shift (fl', r')).  Through the stride un-mapping (K4, :586-589) an x element
+// (hi, wi) has exactly ONE valid gy tap per plane: hi + fl'H + dh = 2 ho with dh = 1 (tap "row b", weight r'H) for
+// the window's upper row hi = 2 ho - fl'H - 1 and dh = 0 (tap "row a", weight 1 - r'H) for the lower one, columns
+// alike, so the reference's trilinear tree with its seven zero taps collapses to
+//     A(tau)[hi, wi] = wH (g wW),   gx[to] = (1 - r'T) A(to + fl'T) + r'T A(to + fl'T + 1)     (same roundings),
+// and the face differences of d(shift) (:432-441) become  -/+ (g wW) and -/+ (wH g)  times the x pairing of
+// rk3d_dma.hpp.  A thread owns the gy cell (ho, 4 wo4 .. +3) -- DMA'd into a one-slot ring at its own position --
+// and the 2 x 8 window of x (from the band's tap slot, as in the forward); d(x) leaves through an LDS tile with the
+// slot's geometry (window values land at their unaligned columns, cells no window covers stay zero), copied out as
+// aligned 16-byte nt stores by the lanes that DMA the same cells of x.  gx rows that no band covers (fl'H != -1)
+// are zero-filled by the first / last band up front.  Any exactly-integer shift component: per-element path.
+template <int DR, bool WRITE_GX, int OFF>
+__device__ __forceinline__ void backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
+                                              float* __restrict__ op, float4* ring, const SDims& d, const SBand& b,
+                                              const Frac<float>& fT, const Frac<float>& fH, const Frac<float>& fW,
+                                              int flW_eff, size_t tstride_in, size_t tstride_out, float& accT,
+                                              float& accH, float& accW) {
+    const int slot_f4 = b.cells_in + 1;                           // x slots: + zero cell; out tile: + dump cell
+    BCells<DR> cs;
+    make_feed<DR>(cs, b);
+    float4* const xring = ring;                                   // 2 slots
+    float4* const otile = ring + 2 * slot_f4;
+    float4* const gslot = otile + slot_f4;                        // kBlock own cells + zero cell
+    init_slots<DR>(xring, 2, slot_f4, b, cs);
+    if (WRITE_GX)
+        for (int o = threadIdx.x; o < slot_f4; o += kBlock) otile[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x == 0) gslot[kBlock] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const Window w = make_window(d, b, (flW_eff - OFF) / 4);
+
+    const float rT = fT.r, rH = fH.r, rW = fW.r;
+    const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
+    const unsigned xaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(xring));
+    const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(gslot)) +
+                           __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
+    const unsigned slot_bytes = (unsigned)slot_f4 * 16u;
+    const float* xsrc0 = xp + (ptrdiff_t)b.src0 * 4;
+    const float* gsrc0 = gp + (size_t)b.out0 * 4;                 // this band's first gy cell
+    float* out0 = WRITE_GX ? op + (ptrdiff_t)b.src0 * 4 : nullptr;
+    const int off0 = (int)threadIdx.x * 16;
+    const bool wave_live = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~(kWave - 1))) < b.cells_out;
+    const int gidx = w.live ? (int)threadIdx.x : kBlock;
+    // byte addresses (relative to the tile) of the window's three cells per row; outside the plane -> the dump cell
+    unsigned wa[3], wb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { wa[k] = (unsigned)w.a[k] * 16u; wb[k] = (unsigned)w.b[k] * 16u; }
+
+    const int t_first = fT.fl, steps = d.T + 1;                   // gy plane of step k is t_first + k; x plane is k
+    auto in_range = [&](int t) { return t >= 0 && t < d.T; };
+    int issued = 0;
+    auto feed = [&](int k) {                                      // gy plane t_first + k, x plane k
+        if (wave_live) {
+            if (in_range(t_first + k)) {
+                if (w.live) dma16s(gsrc0 + (ptrdiff_t)(t_first + k) * (ptrdiff_t)tstride_out, off0, gaddr);
+                ++issued;
+            } else if (w.live) {
+                gslot[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (in_range(k)) {
+            dma_taps<DR>(xsrc0 + (size_t)k * tstride_in, xaddr + (k & 1) * slot_bytes, cs);
+            issued += cs.n_tap_wave;
+        } else {
+            zero_taps<DR>(xring + (k & 1) * slot_f4, cs);
+        }
+    };
+    feed(0);
+    int mark = issued;
+
+    float xa[16], xb[16], Qprev[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xa[i] = xb[i] = Qprev[i] = 0.f;
+    float sT = 0.f, sH = 0.f, sW = 0.f;
+
+#pragma nounroll
+    for (int k = 0; k < steps; ++k) {
+        wait_vmcnt(issued - mark);                                // my pieces of gy(t_first + k) and x[k] have landed
+        __syncthreads();                                          // everyone's have; step k-1 (tile copy-out too) retired
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave_live) {
+            g4 = gslot[gidx];
+            const float4* cur = xring + (k & 1) * slot_f4;
+            const float4 a0 = lds_b128(cur + w.a[0]), a1 = lds_b128(cur + w.a[1]), a2 = lds_b128(cur + w.a[2]);
+            const float4 b0 = lds_b128(cur + w.b[0]), b1 = lds_b128(cur + w.b[1]), b2 = lds_b128(cur + w.b[2]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xa[e] = xb[e]; xa[8 + e] = xb[8 + e];
+                xb[e] = tap12<OFF>(a0, a1, a2, e);
+                xb[8 + e] = tap12<OFF>(b0, b1, b2, e);
+            }
+        }
+        if (k + 1 < steps) feed(k + 1);                           // (the DMA waits for the LDS reads above)
+        mark = issued;
+        if (wave_live) {
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            float q[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float wW = (e & 1) ? uW : rW;               // even e: column 2 wo - fl'W - 1 (tap w1), odd: tap w0
+                const float gw = g[e >> 1] * wW;
+                q[e] = rH * gw;                                   // upper row: tap "row b"
+                q[8 + e] = uH * gw;                               // lower row: tap "row a"
+                const float ca = rH * g[e >> 1], cb = uH * g[e >> 1];   // H-blend of the single tap, per row
+                const float sgn = (e & 1) ? 1.f : -1.f;
+                {
+                    const float dx = xb[e] - xa[e], mx = fmaf(uT, xb[e], rT * xa[e]);
+                    sT = fmaf(q[e], dx, sT);
+                    sH = fmaf(-gw, mx, sH);
+                    sW = fmaf(sgn * ca, mx, sW);
+                }
+                {
+                    const float dx = xb[8 + e] - xa[8 + e], mx = fmaf(uT, xb[8 + e], rT * xa[8 + e]);
+                    sT = fmaf(q[8 + e], dx, sT);
+                    sH = fmaf(gw, mx, sH);
+                    sW = fmaf(sgn * cb, mx, sW);
+                }
+            }
+            if (WRITE_GX && k >= 1) {                             // window of output plane to = k - 1 -> tile
+                char* tile = reinterpret_cast<char*>(otile);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = OFF + e;                        // constant
+                    *reinterpret_cast<float*>(tile + wa[j >> 2] + 4 * (j & 3)) = uT * Qprev[e] + rT * q[e];
+                    *reinterpret_cast<float*>(tile + wb[j >> 2] + 4 * (j & 3)) = uT * Qprev[8 + e] + rT * q[8 + e];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Qprev[i] = q[i];
+        }
+        if (WRITE_GX && k >= 1) {
+            __syncthreads();                                      // the tile of plane k - 1 is complete
+            char* out = reinterpret_cast<char*>(out0 + (size_t)(k - 1) * tstride_in) + off0;
+            const char* tile = reinterpret_cast<const char*>(otile) + off0;
+#pragma unroll
+            for (int i = 0; i < DR; ++i)
+                if (cs.in_act[i])
+                    stream_store(reinterpret_cast<float4*>(out + 4096 * i), *reinterpret_cast<const float4*>(tile + 4096 * i));
+            issued += cs.n_tap_wave;
+        }
+    }
+    accT = sT; accH = sH; accW = sW;
+}
+
+template <int DR, bool WRITE_GX, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k3d_s2_backward(const float* __restrict__ x, const float* __restrict__ shift,
+                                                          const float* __restrict__ gy, float* __restrict__ gx,
+                                                          float* __restrict__ part, SDims d, Dims3 gd, dma3d::Fin3 fin) {
+    if (FUSED && (int)blockIdx.x >= fin.f.producers) {
+        if (threadIdx.x < kWave) dma3d::finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) float4 ring[];
+    __shared__ float red[3][kBlock / kWave];
+    const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
+    const int c = col % d.C, n = col / d.C;
+    const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
+    float accT = 0.f, accH = 0.f, accW = 0.f;
+    const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r'
+
+    if (fT.r == 0 || fH.r == 0 || fW.r == 0) {
+        // exactly-integer component (lowered-index quirk, zero-shift branch): rare, per element; band 0 does the column
+        if (band == 0) {
+            if (WRITE_GX)
+                for (int t = 0; t < d.T; ++t)
+                    backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+            for (int to = 0; to < d.T; ++to)
+                shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
+        }
+    } else {
+        const size_t tin = (size_t)d.C * d.H * d.W, tout = (size_t)d.C * d.Ho * d.Wo;
+        const float* xp = x + ((size_t)n * d.T * d.C + c) * d.H * d.W;
+        const float* gp = gy + ((size_t)n * d.T * d.C + c) * d.Ho * d.Wo;
+        float* op = WRITE_GX ? gx + ((size_t)n * d.T * d.C + c) * d.H * d.W : nullptr;
+        const int flH_eff = -fH.fl - 1, flW_eff = -fW.fl - 1;     // first row / column of the window of output (0, 0)
+        if (WRITE_GX) {
+            // rows of gx no band's window reaches: [0, flH_eff) by the first band, [H + flH_eff, H) by the last
+            auto zero_rows = [&](int lo, int hi) {
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > d.H ? d.H : hi;
+                for (int t = 0; t < d.T; ++t)
+                    for (int cell = lo * d.W4 + (int)threadIdx.x; cell < hi * d.W4; cell += kBlock)
+                        stream_store(reinterpret_cast<float4*>(op + (size_t)t * tin) + cell, make_float4(0.f, 0.f, 0.f, 0.f));
+            };
+            if (band == 0) zero_rows(0, flH_eff);
+            if (band == d.nbands - 1) zero_rows(2 * d.Ho + flH_eff, d.H);
+        }
+        const SBand b = make_sband(d, band, flH_eff);
+#define RK_S2_BWD(O) backward_loop<DR, WRITE_GX, O>(xp, gp, op, ring, d, b, fT, fH, fW, flW_eff, tin, tout, accT, accH, accW)
+        switch (((flW_eff % 4) + 4) % 4) {                          // wave-uniform
+            case 0: RK_S2_BWD(0); break;
+            case 1: RK_S2_BWD(1); break;
+            case 2: RK_S2_BWD(2); break;
+            default: RK_S2_BWD(3); break;
+        }
+#undef RK_S2_BWD
+    }
+
+    accT = group_sum(accT, kBlock, red[0]);
+    accH = group_sum(accH, kBlock, red[1]);
+    accW = group_sum(accW, kBlock, red[2]);
+    if (threadIdx.x == 0) {
+        const int P = d.N * d.nbands;
+        const size_t at = (size_t)c * 3 * P + (size_t)n * d.nbands + band;
+        if (FUSED) {
+            fin_publish(fin.f, at, accT);
+            fin_publish(fin.f, at + P, accH);
+            fin_publish(fin.f, at + 2 * P, accW);
+        } else {
+            part[at] = accT;
+            part[at + P] = accH;
+            part[at + 2 * P] = accW;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side.  false = shape not handled here.
 inline bool make_sdims(SDims& s, const Dims3& d) {
     const bool ok = d.sT == 1 && d.sH == 2 && d.sW == 2 && d.pT == 0 && d.pH == 0 && d.pW == 0;
@@ -224,6 +440,31 @@ inline bool launch_forward(const float* x, const float* shift, float* y, const D
     const dim3 grid((unsigned)(s.N * s.C * s.nbands)), block(kBlock);
     hipLaunchKernelGGL((k3d_s2_forward<4, D>), grid, block, lds, stream, x, shift, y, s);
     return true;
+}
+
+// d(shift) (+ d(x) when gx != nullptr); gshift != nullptr: row-sum + K5 inside the launch (ws = 8-byte granules
+// [C][3][P]), else plain partials ws[C][3][P] for the two-phase ABI.  Returns P (0 = not handled here).
+inline size_t bwd_lds_bytes(const SDims& s) { return ((size_t)3 * (2 * s.BHo * s.W4 + 1) + kBlock + 1) * 16; }
+inline int launch_backward(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                           const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
+    SDims s;
+    if (!make_sdims(s, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
+    const size_t lds = bwd_lds_bytes(s);
+    if (lds > 64 * 1024) return 0;
+    dma3d::Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = s.N * s.C * s.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+    const dim3 block(kBlock);
+#define RK_S2_LAUNCH(GX, FU) hipLaunchKernelGGL((k3d_s2_backward<4, GX, FU>), dim3((unsigned)(fin.f.producers + (FU ? s.C : 0))), \
+                                                block, lds, stream, x, shift, gy, gx, ws, s, d, fin)
+    if (gshift) { if (gx) RK_S2_LAUNCH(true, true); else RK_S2_LAUNCH(false, true); }
+    else { if (gx) RK_S2_LAUNCH(true, false); else RK_S2_LAUNCH(false, false); }
+#undef RK_S2_LAUNCH
+    return s.N * s.nbands;
 }
 
 }  // namespace s2

@@ -159,13 +159,14 @@ def test_gradcheck_fp64():
 
 def test_two_phase_backward_equals_the_one_call_form():
     """rk3d_backward_partials_f32 + rk3d_backward_finalize_f32 (the phases of rubiks.cpp:324-376) == rk3d_backward_f32,
-    bit for bit, on a streaming shape, a tile shape and a strided (column) shape."""
+    bit for bit, on a streaming shape, a tile shape, a strided column shape and a strided streaming shape."""
     import ctypes
 
     from rubiksnet_amd import _native, rubiksnet_cuda
 
     L = _native.lib()
-    for (N, T, C, H, W), s in (((2, 8, 6, 56, 56), (1, 1, 1)), ((2, 4, 8, 14, 14), (1, 1, 1)), ((1, 4, 5, 28, 28), (1, 2, 2))):
+    for (N, T, C, H, W), s in (((2, 8, 6, 56, 56), (1, 1, 1)), ((2, 4, 8, 14, 14), (1, 1, 1)), ((1, 4, 5, 28, 28), (1, 2, 2)),
+                                ((2, 3, 4, 56, 56), (1, 2, 2))):
         torch.manual_seed(N * C + H)
         x = torch.rand(N, T, C, H, W, device="cuda:0") * 2 - 1
         shift = torch.rand(3, C, device="cuda:0") * 2 - 1
@@ -275,23 +276,24 @@ def test_full_size_quantize_is_translation(full):
         assert torch.equal(y[:, :, c], want)
 
 
+@pytest.mark.parametrize("stride", [1, (1, 2, 2)])
 @pytest.mark.parametrize("kind", ["generic", "integer"])
-def test_backward_halves_match_fused(oracle, kind):
-    """d(x)-only, d(shift)-only and the fused backward agree (different kernels on the streaming path)."""
+def test_backward_halves_match_fused(oracle, kind, stride):
+    """d(x)-only, d(shift)-only and the fused backward agree (different kernels on the streaming paths)."""
     from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
 
     rng = np.random.default_rng(21)
-    x = rand(rng, (3, 8, 10, 28, 28), np.float32)
-    gy = rand(rng, x.shape, np.float32)
-    shift = special_shifts(rng, 3, 10, np.float32, kind)
-    args = (to_dev(gy), to_dev(x), to_dev(shift), 1, 0, False)
+    x = rand(rng, (3, 8, 10, 28, 28) if stride == 1 else (3, 5, 6, 56, 56), np.float32)
+    shift = special_shifts(rng, 3, x.shape[2], np.float32, kind)
+    gy = rand(rng, oracle.rk3d_forward(x, shift, stride, 0).shape, np.float32)
+    args = (to_dev(gy), to_dev(x), to_dev(shift), stride, 0, False)
     gx_f, gs_f = rubiks_shift_3d_backward(*args)
     gx_only, none_s = rubiks_shift_3d_backward(*args, need_shift_grad=False)
     none_x, gs_only = rubiks_shift_3d_backward(*args, need_x_grad=False)
     assert none_s is None and none_x is None
     np.testing.assert_array_equal(to_np(gx_f), to_np(gx_only))
     _, _, raw_ref = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64),
-                                         normalize_grad=False, return_raw=True)
+                                         stride, 0, normalize_grad=False, return_raw=True)
     scale = max(1.0, float(np.abs(raw_ref).max()))
     np.testing.assert_allclose(to_np(gs_f), raw_ref, rtol=0, atol=1e-5 * scale)
     np.testing.assert_allclose(to_np(gs_only), raw_ref, rtol=0, atol=1e-5 * scale)
