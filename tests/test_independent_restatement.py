@@ -25,6 +25,8 @@ SHAPES3 = [
     (1, 6, 3, 10, 11, (2, 1, 3), (1, 2, 0)),
     (1, 1, 2, 5, 5, (1, 1, 1), (0, 0, 0)),
     (2, 8, 3, 112, 112, (1, 2, 2), (0, 0, 0)),
+    (2, 3, 4, 56, 56, (1, 2, 2), (0, 0, 0)),
+    (1, 2, 5, 16, 24, (1, 2, 2), (0, 0, 0)),
     (1, 4, 3, 112, 112, (1, 1, 1), (0, 0, 0)),
     (1, 3, 2, 96, 64, (1, 1, 1), (0, 0, 0)),
     (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)),
