@@ -217,23 +217,39 @@ __device__ __forceinline__ void fin_publish(const Fin& fin, size_t at, float v) 
     __hip_atomic_store(fin.gran + at, ((unsigned long long)fin.tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
-// one wave (lanes 0..63 of the block): s[k] = sum_i granule[c][k][i] over this launch's P partials; false = timed out
+// one wave (lanes 0..63 of the block): s[k] = sum_i granule[c][k][i] over this launch's P partials; false = timed out.
+// The D loads of a lane go out together (one round trip, not D dependent ones: the finalizers' sweep is the tail of
+// the launch), then each lane re-polls only what is still missing.
 template <int D>
 __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double (&s)[D]) {
     const int lane = threadIdx.x;
     const unsigned long long* g = fin.gran + (size_t)c * D * P;
+    const unsigned long long done = (unsigned long long)fin.tag << 32;          // a ready granule holding 0.0f
     bool ok = true;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        s[k] = 0;
-        for (int i = lane; i < P; i += kWave) {
-            unsigned long long v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int spin = 0; (unsigned)(v >> 32) != fin.tag && spin < 200000; ++spin) {
-                __builtin_amdgcn_s_sleep(32);
-                v = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ok = ok && (unsigned)(v >> 32) == fin.tag;
-            s[k] += (double)__uint_as_float((unsigned)v);
+    for (int k = 0; k < D; ++k) s[k] = 0;
+    for (int i0 = 0; i0 < P; i0 += kWave) {
+        const int i = i0 + lane;
+        const bool act = i < P;
+        unsigned long long v[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            v[k] = act ? __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done;
+        for (int spin = 0; spin < 400000; ++spin) {
+            bool ready = true;
+#pragma unroll
+            for (int k = 0; k < D; ++k) ready = ready && (unsigned)(v[k] >> 32) == fin.tag;
+            if (ready) break;
+            __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if ((unsigned)(v[k] >> 32) != fin.tag)
+                    v[k] = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            ok = ok && (unsigned)(v[k] >> 32) == fin.tag;
+            s[k] += (double)__uint_as_float((unsigned)v[k]);
         }
     }
 #pragma unroll
