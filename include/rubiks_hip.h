@@ -76,7 +76,9 @@ int rk3d_forward_f64(const double* x, const double* shift, double* y,
                      int quantize, rk_stream_t stream);
 
 /* Bytes of scratch rk3d_backward_* needs (elem_size = 4 or 8).  Replaces the
- * zeros[3C,Ho,Wo] + ones[Ho,Wo] allocations of rubiks.cpp:294-299. */
+ * zeros[3C,Ho,Wo] + ones[Ho,Wo] allocations of rubiks.cpp:294-299.  The scratch needs NO initialisation and may be
+ * reused by the next call on the same stream: the streaming fp32 kernels keep their partials there as 8-byte
+ * {value, launch tag} granules and run the row-sum + K5 inside the backward launch. */
 size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W,
                                      int stride_T, int stride_H, int stride_W,
                                      int pad_T, int pad_H, int pad_W, int elem_size);
@@ -105,7 +107,8 @@ int rk3d_backward_f64(const double* x, const double* shift, const double* gy,
 /* Two-phase form of rk3d_backward_f32, the phases of the reference's own host glue (rubiks.cpp:324-376):
  * _partials = K2 + K3/K4: writes gx (or skips it when NULL) and the per-channel partial sums workspace[C][3][P],
  * P returned through *partials; _finalize = addmv row-sum (:344-345) + K5 normalise (:352-358) into gshift[3][C].
- * rk3d_backward_f32 is exactly _partials followed by _finalize (bench.py times the two kernels separately).     */
+ * rk3d_backward_f32 computes exactly what _partials followed by _finalize compute, bit for bit (same partials,
+ * same summation order); on the streaming shapes it does so in ONE launch (bench.py times both forms).          */
 int rk3d_backward_partials_f32(const float* x, const float* shift, const float* gy, float* gx,
                                int N, int T, int C, int H, int W,
                                int stride_T, int stride_H, int stride_W, int pad_T, int pad_H, int pad_W,
