@@ -13,6 +13,7 @@
 #include "rk2d_dma.hpp"
 #include "rk2d_stage.hpp"
 #include "rk2d_raw16.hpp"
+#include "rk2d_tile.hpp"
 #include "rk2d_column.hpp"
 
 using namespace rk;
@@ -44,6 +45,8 @@ size_t workspace2(const Dims2& d, size_t elem) {
     const int Pc = col2d::backward_partials(d), Pr = raw16::backward2_partials(d);
     P = P > Pc ? P : Pc;
     P = P > Pr ? P : Pr;
+    const int Pt = tile2d::backward2_partials<float>(d);             // (the same count for every storage type)
+    P = P > Pt ? P : Pt;
     // the streaming backwards keep their fp32 partials as 8-byte {value, tag} granules (rk_dma.hpp)
     return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * (elem < 8 ? 8 : elem);
 }
@@ -61,6 +64,9 @@ int forward2(const void* x_, const void* shift_, void* y_, int N, int C, int H, 
     Dims2 d;
     if (int rc = make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    if constexpr (!std::is_same<T, double>::value) {
+        if (!quantize && tile2d::launch_interp2<T, false>(x, shift, y, d, stream)) return launch_status();   // 14x14
+    }
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && dma2d::launch_interp2<false>(x, shift, y, d, stream)) return launch_status();
     } else if constexpr (!std::is_same<T, double>::value) {
@@ -95,6 +101,15 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
     hipStream_t stream = (hipStream_t)stream_;
     if (enable_shift_grad) {
         if (!ws || ws_bytes < workspace2(d, sizeof(CT))) return RK_ERR_WORKSPACE;
+    }
+    if constexpr (!std::is_same<T, double>::value) {
+        if (!quantize) {                                                                       // 14x14 planes
+            if (!enable_shift_grad) {
+                if (tile2d::launch_interp2<T, true>(gy, shift, gx, d, stream)) return launch_status();
+            } else if (tile2d::launch_backward2<T>(gy, x, shift, gx, gshift, ws, normalize_grad, d, stream)) {
+                return launch_status();
+            }
+        }
     }
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize) {

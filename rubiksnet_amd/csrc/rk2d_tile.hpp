@@ -1,0 +1,392 @@
+// rk2d_tile.hpp -- RubiksShift2D on 14x14 planes (stride 1 / pad 0; fp32, f16, bf16): the 35 layer-3 blocks of the
+// -aq networks ([256,288,14,14] per GPU for Large-AQ), which the column kernels of rk2d_column.hpp
+// run at 0.8-1.8 TB/s.  Same idea as rk3d_tile.hpp: the planes of consecutive channels of one frame are contiguous,
+// so the unit is a TILE = 2 consecutive channels x one plane (fp32: 2 x 784 B = 98 aligned 16-byte pieces, 16-bit:
+// 2 x 392 B = 49), LDS-DMA'd RAW (global_load_lds_dwordx4 nt, counted vmcnt) by the WAVE that owns it; a
+// workgroup is 4 independent waves and there is no workgroup barrier.  A wave owns (channel group, group of FG
+// frames) and walks its frames through a ring of R slots; the shift is per channel, so all tap addresses are
+// computed ONCE per wave, relative to a slot, a tap outside the plane pointing at the slot's zero word.
+//
+// A lane owns PAIRS of horizontally adjacent elements (W is even, so a pair never straddles a row): six taps
+// (rows A / B x three columns) feed two outputs, 16-bit taps are widened after the LDS read (ds_read_u16), and the
+// pair leaves as one 8-byte (fp32) or 4-byte (16-bit) nt store.  Arithmetic: interp2d (rubiks2d_kernels.cu:60-66)
+// for the forward (K6 :94-146) and d(x) (K8 :276-378) with contraction off, rounded once for the 16-bit types =>
+// bit-identical to the other 2-D kernels and to the oracle; d(shift) (K7 :164-273) in the adjoint form of
+// rk2d_dma.hpp, integer shifts by extra walks with lowered floors (IntegerPlan), row-sum + K9 inside the launch.
+#pragma once
+#include "rk2d_raw16.hpp"
+
+namespace rk {
+namespace tile2d {
+
+using namespace dma;
+using dma2d::Fin2;
+using dma2d::IntegerPlan;
+using g2d::Dims2;
+
+template <typename T, int H_, int W_> struct Geo {
+    static constexpr int H = H_, W = W_, HW = H_ * W_;
+    static constexpr int ES = (int)sizeof(T);
+    static constexpr int GC = 2;                                  // channels per tile (4 for the 16-bit types: 236 VGPRs)
+    static constexpr int PAIRS = HW / 2;
+    static constexpr int RC = (PAIRS + kWave - 1) / kWave;        // rounds per channel
+    static constexpr int ROUNDS = GC * RC;
+    static constexpr int TILE_B = GC * HW * ES;
+    static constexpr int PIECES = TILE_B / 16;
+    static constexpr int PIECE_ROUNDS = (PIECES + kWave - 1) / kWave;
+    static constexpr int STRIDE = TILE_B + 16;                    // slot: [tile][16 zero bytes]
+    static constexpr unsigned ZOFF = TILE_B;
+    static_assert(W_ % 2 == 0 && TILE_B % 16 == 0, "pairs inside a row; a tile is whole 16-byte pieces");
+};
+
+struct TDims2 {
+    int F, C, NG;                // frames, channels, channel groups (C / GC)
+    int FG, ngroups;             // frames per wave, frame groups
+};
+
+// LDS element -> fp32
+template <typename T> struct LdsElem;
+template <> struct LdsElem<float> {
+    __device__ static __forceinline__ float get(unsigned a) { return *(__attribute__((address_space(3))) const float*)(size_t)a; }
+};
+template <> struct LdsElem<__hip_bfloat16> {
+    __device__ static __forceinline__ float get(unsigned a) {
+        return __uint_as_float((unsigned)(*(__attribute__((address_space(3))) const unsigned short*)(size_t)a) << 16);
+    }
+};
+template <> struct LdsElem<__half> {
+    __device__ static __forceinline__ float get(unsigned a) {
+        return __half2float(__builtin_bit_cast(__half, *(__attribute__((address_space(3))) const unsigned short*)(size_t)a));
+    }
+};
+// own pair (aligned) -> two fp32
+template <typename T> __device__ __forceinline__ void lds_pair(unsigned a, float& v0, float& v1) {
+    if constexpr (sizeof(T) == 4) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v = *(__attribute__((address_space(3))) const f32x2*)(size_t)a;
+        v0 = v.x; v1 = v.y;
+    } else {
+        const unsigned w = *(__attribute__((address_space(3))) const unsigned*)(size_t)a;
+        v0 = raw16::Wide<T>::get(w, 0); v1 = raw16::Wide<T>::get(w, 1);
+    }
+}
+template <typename T> __device__ __forceinline__ void store_pair(char* p, float v0, float v1) {
+    if constexpr (sizeof(T) == 4) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 t = {v0, v1};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x2*>(p));
+    } else {
+        using C4 = stage2d::Cell4<T>;
+        __builtin_nontemporal_store(C4::bits(v0) | (C4::bits(v1) << 16), reinterpret_cast<unsigned*>(p));
+    }
+}
+
+template <typename G> __device__ __forceinline__ int dma_tile(const void* tile, unsigned dst, int lane) {
+#pragma unroll
+    for (int i = 0; i < G::PIECE_ROUNDS; ++i)
+        if (lane + kWave * i < G::PIECES) dma16s<true>(tile, (lane + kWave * i) * 16, dst + 1024u * i);
+    return G::PIECE_ROUNDS;
+}
+
+// one channel of the tile in one walk: fractions, what it does in this walk
+struct ChanW { Frac<float> fH, fW; bool on, store; };
+
+// relative byte offsets (inside a slot) of the six taps of my pair in round (g, rc), my pair's own offset inside a tile
+// (or ZOFF / -1 when this lane has no pair in the round or the channel sits this walk out)
+template <typename G>
+__device__ __forceinline__ void make_round(unsigned (&rel)[6], unsigned& own, int& ooff, const ChanW& ch, int g, int lane,
+                                           int rc) {
+    const int p = lane + kWave * rc;
+    const bool live = ch.on && p < G::PAIRS;
+    const int e = 2 * (p < G::PAIRS ? p : 0);
+    const int h = e / G::W, w = e - h * G::W;
+    const int h0 = h + ch.fH.fl, w0 = w + ch.fW.fl;
+    const bool mh0 = (unsigned)h0 < (unsigned)G::H, mh1 = (unsigned)(h0 + 1) < (unsigned)G::H;
+    const unsigned a = (unsigned)((g * G::HW + h0 * G::W + w0) * G::ES);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool mw = (unsigned)(w0 + k) < (unsigned)G::W;
+        rel[k] = live && mh0 && mw ? a + (unsigned)(k * G::ES) : G::ZOFF;
+        rel[3 + k] = live && mh1 && mw ? a + (unsigned)((G::W + k) * G::ES) : G::ZOFF;
+    }
+    own = live ? (unsigned)((g * G::HW + e) * G::ES) : G::ZOFF;
+    ooff = live && ch.store ? (g * G::HW + e) * G::ES : -1;
+}
+
+struct Item { int c0, f0, nf; bool live; };
+template <typename G> __device__ __forceinline__ Item my_item(const TDims2& d, int wave) {
+    Item it;
+    const long long id = (long long)blockIdx.x * (kBlock / kWave) + wave;
+    it.live = id < (long long)d.NG * d.ngroups;
+    const long long q = it.live ? id : 0;
+    it.c0 = (int)(q % d.NG) * G::GC;
+    it.f0 = (int)(q / d.NG) * d.FG;
+    it.nf = d.F - it.f0 < d.FG ? d.F - it.f0 : d.FG;
+    return it;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward (NEGATE = false: src = x) and d(x) alone (NEGATE = true: src = gy, negated shift).
+template <typename T, int H, int W, int R, bool NEGATE>
+__global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ src, const T* __restrict__ shift,
+                                                          T* __restrict__ dst, TDims2 d) {
+    using G = Geo<T, H, W>;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (kWave - 1);
+    const Item it = my_item<G>(d, wave);
+    if (!it.live) return;                                            // whole wave; no barriers in this kernel
+    char* ring = lds_raw + wave * (R * G::STRIDE);
+    if (lane < R) *reinterpret_cast<float4*>(ring + lane * G::STRIDE + G::ZOFF) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
+
+    unsigned rel[G::ROUNDS][6], own;
+    int ooff[G::ROUNDS];
+    float uH[G::GC], rH[G::GC], uW[G::GC], rW[G::GC];
+#pragma unroll
+    for (int g = 0; g < G::GC; ++g) {
+        float sH = ld(shift + it.c0 + g), sW = ld(shift + d.C + it.c0 + g);
+        if (NEGATE) { sH = -sH; sW = -sW; }
+        ChanW ch;
+        ch.fH = split_shift(sH); ch.fW = split_shift(sW);
+        ch.on = true; ch.store = true;
+        rH[g] = ch.fH.r; rW[g] = ch.fW.r; uH[g] = 1 - rH[g]; uW[g] = 1 - rW[g];
+#pragma unroll
+        for (int rc = 0; rc < G::RC; ++rc) make_round<G>(rel[g * G::RC + rc], own, ooff[g * G::RC + rc], ch, g, lane, rc);
+    }
+    (void)own;
+    const size_t fstride = (size_t)d.C * G::HW;                       // elements between frames
+    const T* col = src + ((size_t)it.f0 * d.C + it.c0) * G::HW;
+    char* ocol = reinterpret_cast<char*>(dst + ((size_t)it.f0 * d.C + it.c0) * G::HW);
+
+    int issued = 0;
+    auto fetch = [&](int k) {                                        // frame k -> slot k % R
+        if (k < it.nf) issued += dma_tile<G>(col + (size_t)k * fstride, ring_addr + (k % R) * G::STRIDE, lane);
+    };
+    // fifo[i] = `issued` right after the fetch of frame k + i: "frame k has landed" <=> outstanding <= issued - fifo[0]
+    int fifo[R - 1];
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) { fetch(i); fifo[i] = issued; }
+    for (int k = 0; k < it.nf; ++k) {
+        wait_vmcnt(issued - fifo[0]);
+        fetch(k + R - 1);                                            // into the slot of frame k - 1
+#pragma unroll
+        for (int i = 0; i + 1 < R - 1; ++i) fifo[i] = fifo[i + 1];
+        fifo[R - 2] = issued;
+        const unsigned sb = ring_addr + (k % R) * G::STRIDE;
+        char* out = ocol + (size_t)k * fstride * G::ES;
+        float o0[G::ROUNDS], o1[G::ROUNDS];
+#pragma unroll
+        for (int g = 0; g < G::GC; ++g)
+#pragma unroll
+            for (int rc = 0; rc < G::RC; ++rc) {
+                const int r = g * G::RC + rc;
+                const float a0 = LdsElem<T>::get(rel[r][0] + sb), a1 = LdsElem<T>::get(rel[r][1] + sb),
+                            a2 = LdsElem<T>::get(rel[r][2] + sb);
+                const float b0 = LdsElem<T>::get(rel[r][3] + sb), b1 = LdsElem<T>::get(rel[r][4] + sb),
+                            b2 = LdsElem<T>::get(rel[r][5] + sb);
+                o0[r] = a0 * uH[g] * uW[g] + a1 * uH[g] * rW[g] + b0 * rH[g] * uW[g] + b1 * rH[g] * rW[g];   // interp2d
+                o1[r] = a1 * uH[g] * uW[g] + a2 * uH[g] * rW[g] + b1 * rH[g] * uW[g] + b2 * rH[g] * rW[g];
+            }
+#pragma unroll
+        for (int r = 0; r < G::ROUNDS; ++r) {
+            if (ooff[r] >= 0) store_pair<T>(out + ooff[r], o0[r], o1[r]);
+            ++issued;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward: d(x) + d(shift); partials [C][2][P = ngroups] as granules, row-sum + K9 by the finalizer blocks.
+template <typename T, int H, int W, int R>
+__global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
+                                                            const T* __restrict__ shift, T* __restrict__ gx, TDims2 d,
+                                                            Fin2<T> fin) {
+    using G = Geo<T, H, W>;
+    if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
+        if (threadIdx.x < kWave) dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, d.ngroups);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (kWave - 1);
+    const Item it = my_item<G>(d, wave);
+    if (!it.live) return;
+    char* gring = lds_raw + wave * (2 * R * G::STRIDE);
+    char* xring = gring + R * G::STRIDE;
+    if (lane < 2 * R) *reinterpret_cast<float4*>(gring + lane * G::STRIDE + G::ZOFF) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(gring));
+    const unsigned xaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(xring));
+    const size_t fstride = (size_t)d.C * G::HW;
+    const size_t base = ((size_t)it.f0 * d.C + it.c0) * G::HW;
+    const T* gcol = gy + base;
+    const T* xcol = x + base;
+    char* ocol = reinterpret_cast<char*>(gx + base);
+
+    IntegerPlan plan[G::GC];
+    bool extra = false;                                              // does any channel of the tile need more than walk 0?
+#pragma unroll
+    for (int g = 0; g < G::GC; ++g) {
+        plan[g] = dma2d::plan_walks(ld(shift + it.c0 + g), ld(shift + d.C + it.c0 + g));
+        extra = extra || plan[g].separate_gx || plan[g].hint || plan[g].wint;
+    }
+    float sumH0[G::GC], sumW0[G::GC], sumH1[G::GC], sumW2[G::GC];
+#pragma unroll
+    for (int g = 0; g < G::GC; ++g) sumH0[g] = sumW0[g] = sumH1[g] = sumW2[g] = 0.f;
+
+    // walk -1: d(x) alone with the true remainder (channels whose |r| < 1e-7 but != 0: K8 has no tolerance);
+    // walk 0: sums (+ d(x) for every ordinary channel); walk 1 / 2: sums with the H / W floor lowered by one.
+#pragma nounroll
+    for (int walk = extra ? -1 : 0; walk < (extra ? 3 : 1); ++walk) {
+        unsigned rel[G::ROUNDS][6], own[G::ROUNDS];
+        int ooff[G::ROUNDS];
+        float uH[G::GC], rH[G::GC], uW[G::GC], rW[G::GC];
+        bool any = false, st_on[G::GC];
+#pragma unroll
+        for (int g = 0; g < G::GC; ++g) {
+            ChanW ch;
+            if (walk < 0) { ch.fH = plan[g].gH; ch.fW = plan[g].gW; ch.on = plan[g].separate_gx; ch.store = true; }
+            else {
+                ch.fH = plan[g].sH; ch.fW = plan[g].sW;
+                if (walk == 1) ch.fH.fl -= 1;
+                if (walk == 2) ch.fW.fl -= 1;
+                ch.on = plan[g].walk_on(walk);
+                ch.store = walk == 0 && !plan[g].separate_gx;
+            }
+            any = any || ch.on;
+            st_on[g] = ch.on && ch.store;                            // wave-uniform
+            rH[g] = ch.fH.r; rW[g] = ch.fW.r; uH[g] = 1 - rH[g]; uW[g] = 1 - rW[g];
+#pragma unroll
+            for (int rc = 0; rc < G::RC; ++rc)
+                make_round<G>(rel[g * G::RC + rc], own[g * G::RC + rc], ooff[g * G::RC + rc], ch, g, lane, rc);
+        }
+        if (!any) continue;                                          // wave-uniform
+        float aH[G::GC], aW[G::GC];
+#pragma unroll
+        for (int g = 0; g < G::GC; ++g) aH[g] = aW[g] = 0.f;
+
+        int issued = 0;
+        auto fetch = [&](int k) {                                    // frame k: gy -> gy slot, x -> x slot k % R
+            if (k < it.nf) {
+                issued += dma_tile<G>(gcol + (size_t)k * fstride, gaddr + (k % R) * G::STRIDE, lane);
+                issued += dma_tile<G>(xcol + (size_t)k * fstride, xaddr + (k % R) * G::STRIDE, lane);
+            }
+        };
+        int fifo[R - 1];
+#pragma unroll
+        for (int i = 0; i < R - 1; ++i) { fetch(i); fifo[i] = issued; }
+        for (int k = 0; k < it.nf; ++k) {
+            wait_vmcnt(issued - fifo[0]);
+            fetch(k + R - 1);
+#pragma unroll
+            for (int i = 0; i + 1 < R - 1; ++i) fifo[i] = fifo[i + 1];
+            fifo[R - 2] = issued;
+            const unsigned gb = gaddr + (k % R) * G::STRIDE, xb = xaddr + (k % R) * G::STRIDE;
+            char* out = ocol + (size_t)k * fstride * G::ES;
+            float o0[G::ROUNDS], o1[G::ROUNDS];
+#pragma unroll
+            for (int g = 0; g < G::GC; ++g)
+#pragma unroll
+                for (int rc = 0; rc < G::RC; ++rc) {
+                    const int r = g * G::RC + rc;
+                    const float a0 = LdsElem<T>::get(rel[r][0] + gb), a1 = LdsElem<T>::get(rel[r][1] + gb),
+                                a2 = LdsElem<T>::get(rel[r][2] + gb);
+                    const float b0 = LdsElem<T>::get(rel[r][3] + gb), b1 = LdsElem<T>::get(rel[r][4] + gb),
+                                b2 = LdsElem<T>::get(rel[r][5] + gb);
+                    float x0, x1;
+                    lds_pair<T>(own[r] + xb, x0, x1);
+                    o0[r] = a0 * uH[g] * uW[g] + a1 * uH[g] * rW[g] + b0 * rH[g] * uW[g] + b1 * rH[g] * rW[g];   // K8
+                    o1[r] = a1 * uH[g] * uW[g] + a2 * uH[g] * rW[g] + b1 * rH[g] * uW[g] + b2 * rH[g] * rW[g];
+                    const float c0 = fmaf(uH[g], a0, rH[g] * b0), c1 = fmaf(uH[g], a1, rH[g] * b1),
+                                c2 = fmaf(uH[g], a2, rH[g] * b2);
+                    const float la0 = fmaf(a0, uW[g], a1 * rW[g]), lb0 = fmaf(b0, uW[g], b1 * rW[g]);
+                    const float la1 = fmaf(a1, uW[g], a2 * rW[g]), lb1 = fmaf(b1, uW[g], b2 * rW[g]);
+                    aH[g] = fmaf(la0 - lb0, x0, aH[g]);
+                    aH[g] = fmaf(la1 - lb1, x1, aH[g]);
+                    aW[g] = fmaf(c0 - c1, x0, aW[g]);
+                    aW[g] = fmaf(c1 - c2, x1, aW[g]);
+                }
+#pragma unroll
+            for (int g = 0; g < G::GC; ++g) {
+                if (!st_on[g]) continue;                             // wave-uniform: no store instruction, none counted
+#pragma unroll
+                for (int rc = 0; rc < G::RC; ++rc) {
+                    const int r = g * G::RC + rc;
+                    if (ooff[r] >= 0) store_pair<T>(out + ooff[r], o0[r], o1[r]);
+                    ++issued;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G::GC; ++g) {
+            if (walk == 0) { sumH0[g] = aH[g]; sumW0[g] = aW[g]; }
+            else if (walk == 1) sumH1[g] = aH[g];
+            else if (walk == 2) sumW2[g] = aW[g];
+        }
+    }
+
+#pragma unroll
+    for (int g = 0; g < G::GC; ++g) {
+        float accH = plan[g].hint ? 0.5f * (sumH0[g] + sumH1[g]) : sumH0[g];
+        float accW = plan[g].wint ? 0.5f * (sumW0[g] + sumW2[g]) : sumW0[g];
+        accH = wave_sum(accH);
+        accW = wave_sum(accW);
+        if (lane == 0) {
+            const int P = d.ngroups;
+            const size_t at = (size_t)(it.c0 + g) * 2 * P + (size_t)(it.f0 / d.FG);
+            fin_publish(fin.f, at, accH);
+            fin_publish(fin.f, at + P, accW);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side.  false / 0 = shape not handled here.
+constexpr int kTileFrames = 16;
+template <typename T, int H, int W> inline bool make_tdims(TDims2& t, const Dims2& d) {
+    using G = Geo<T, H, W>;
+    const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
+    if (!s1p0 || d.H != H || d.W != W || d.C % G::GC != 0 || !streaming_kernels_on()) return false;
+    t.F = d.N; t.C = d.C; t.NG = d.C / G::GC;
+    t.FG = kTileFrames < d.N ? kTileFrames : d.N;
+    t.ngroups = (d.N + t.FG - 1) / t.FG;
+    return true;
+}
+template <typename T> inline int backward2_partials(const Dims2& d) {
+    TDims2 t;
+    return make_tdims<T, 14, 14>(t, d) ? t.ngroups : 0;
+}
+
+template <typename T, bool NEGATE>
+inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d, hipStream_t stream) {
+    constexpr int R = 4;
+    using G = Geo<T, 14, 14>;
+    TDims2 t;
+    if (!make_tdims<T, 14, 14>(t, d) || !aligned16(src) || !aligned16(dst)) return false;
+    const long long waves = (long long)t.NG * t.ngroups;
+    const size_t lds = (size_t)4 * R * G::STRIDE;
+    hipLaunchKernelGGL((k2d_tile_interp<T, 14, 14, R, NEGATE>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), lds, stream,
+                       src, shift, dst, t);
+    return true;
+}
+
+template <typename T>
+inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* gshift, void* ws, int normalize,
+                             const Dims2& d, hipStream_t stream) {
+    constexpr int R = 3;
+    using G = Geo<T, 14, 14>;
+    TDims2 t;
+    if (!make_tdims<T, 14, 14>(t, d) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
+    const long long waves = (long long)t.NG * t.ngroups;
+    const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
+    Fin2<T> fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = (int)((waves + 3) / 4);
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    hipLaunchKernelGGL((k2d_tile_backward<T, 14, 14, R>), dim3((unsigned)(fin.f.producers + t.C)), dim3(kBlock), lds, stream, gy,
+                       x, shift, gx, t, fin);
+    return true;
+}
+
+}  // namespace tile2d
+}  // namespace rk

@@ -45,6 +45,7 @@ SHAPES2 = [
     (9, 4, 12, 16, 1, 0),
     (5, 3, 112, 112, 1, 0),
     (70, 512, 4, 8, 1, 0),
+    (37, 6, 14, 14, 1, 0),
 ]
 KINDS2 = ["generic", "wide", "integer", "half", "oob", "tiny"]
 TOL2D = float(np.float32(1e-7))        # ZERO_TOL = static_cast<T>(1e-7f), rubiks2d_kernels.cu:189

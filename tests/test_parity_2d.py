@@ -19,6 +19,7 @@ SHAPES = [
     (9, 4, 12, 16, 1, 0),
     (5, 3, 112, 112, 1, 0),
     (70, 512, 4, 8, 1, 0),
+    (37, 6, 14, 14, 1, 0),        # tile kernels: ragged last frame group, 3 channel groups
 ]
 
 
@@ -102,7 +103,7 @@ def test_enable_shift_grad_false_and_module(oracle, shape):
 @pytest.mark.parametrize("tdtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["generic", "wide", "integer", "tiny"])
 @pytest.mark.parametrize("shape", [(4, 12, 14, 14), (20, 6, 28, 28), (3, 5, 56, 56), (5, 3, 112, 112), (9, 4, 12, 16),
-                                   (70, 16, 4, 8), (6, 3, 24, 64), (2, 2, 40, 200)])
+                                   (70, 16, 4, 8), (6, 3, 24, 64), (2, 2, 40, 200), (37, 6, 14, 14)])
 def test_half_types_are_the_fp32_oracle_rounded_once(oracle, shape, kind, tdtype):
     """f16 / bf16 storage: the arithmetic is the fp32 operator's, rounded once on store.  So y and d(x)
     must equal the fp32 oracle on the widened inputs, rounded to the storage type -- bit for bit -- on the
