@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    name = name.strip('"')
+    name = name.strip('"').replace("(anonymous namespace)::", "rk::")
     if "rk::" in name:
         return name.split("(")[0].replace("void ", "")
     if "distribution_elementwise" in name:

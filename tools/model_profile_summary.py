@@ -12,7 +12,7 @@ import sys
 
 
 def short(name):
-    name = name.strip('"')
+    name = name.strip('"').replace("(anonymous namespace)::", "rk::")
     if "rk::" in name:
         return name.split("(")[0].replace("void ", "")
     for key in ("multi_tensor_apply", "elementwise_kernel", "reduce_kernel", "Cijk_", "igemm", "naive_conv", "batched_transpose",
