@@ -41,7 +41,7 @@ template <> struct Cell4<__half> {
         return make_float4(lo.x, lo.y, hi.x, hi.y);
     }
     __device__ static __forceinline__ unsigned bits(float v) {
-        return (unsigned)__builtin_bit_cast(unsigned short, __float2half(v));
+        return (unsigned)__builtin_bit_cast(unsigned short, __float2half(materialise(v)));
     }
     __device__ static __forceinline__ uint2 narrow(float a, float b, float c, float d) {
         return make_uint2(bits(a) | (bits(b) << 16), bits(c) | (bits(d) << 16));

@@ -25,7 +25,11 @@ template <> __device__ __forceinline__ float ld<__hip_bfloat16>(const __hip_bflo
     return __bfloat162float(*p);
 }
 template <typename T> __device__ __forceinline__ void st(T* p, typename Compute<T>::type v) { *p = v; }
-template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half(v); }
+// (the empty asm keeps the fp32 value materialised: without it hipcc folds `(half)(a * b)` into v_fma_mixlo_f16, ONE
+// rounding from the exact product, which differs from "fp32 result rounded once" on double-rounding ties and made
+// the fused strided 2-D backward disagree with the d(x)-only kernel on 6 of 128 800 elements)
+__device__ __forceinline__ float materialise(float v) { asm volatile("" : "+v"(v)); return v; }
+template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half(materialise(v)); }
 template <> __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, float v) {
     *p = __float2bfloat16(v);
 }
