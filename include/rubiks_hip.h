@@ -174,6 +174,13 @@ RK_DECL_TAP(bf16, void, float)
 
 size_t rk_tshift3_backward_workspace_bytes(int NT, int n_segment, int C, int HW);
 
+/* The [C,3] half of AttentionShift (attention_shift.py:29-30): taps = softmax((weight / (std(weight, dim=1) + 1e-6)) / T)
+ * over the three taps of a channel (std unbiased), and its backward (gweight from gtaps).  fp32; T is the module's
+ * one-element device tensor (no host read); one launch each instead of ~15 + ~25 PyTorch kernels per layer. */
+int rk_soft_taps_forward_f32(const float* weight, const float* T, float* taps, int C, rk_stream_t stream);
+int rk_soft_taps_backward_f32(const float* weight, const float* T, const float* taps, const float* gtaps, float* gweight,
+                              int C, rk_stream_t stream);
+
 /* ---- BatchNorm2d (+ ReLU) of the backbone blocks -- widening row f3 of SURVEY 8(f) ----------------
  * Replaces the reference's nn.BatchNorm2d followed by nn.ReLU(inplace=True)
  * (rubiksnet/backbone.py:50-53 BN2d; :129 relu(bn1(x)), :131 relu(bn2(conv2(.))), :196 relu(bn_last(x))),

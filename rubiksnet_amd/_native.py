@@ -35,6 +35,8 @@ SIGNATURES = {
     "rk3d_backward_finalize_f32": (_i, [_p, _i, _i, _p, _i, ctypes.c_float, _p]),
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
     "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_soft_taps_forward_f32": (_i, [_p, _p, _p, _i, _p]),
+    "rk_soft_taps_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _p]),
     "rk_bn_workspace_bytes": (_sz, [_i, _i, _i]),
     "rk_pw_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_gemm_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -60,6 +60,29 @@ class _TemporalShift3Func(torch.autograd.Function):
         return gx, gtaps.to(ctx.taps_dtype), None
 
 
+class _SoftTapsFunc(torch.autograd.Function):
+    """softmax((w / (std(w, dim=1) + 1e-6)) / T, dim=1) of a [C, 3] fp32 weight on the device, one launch each way
+    (rk_soft_taps_*): the expression of attention_shift.py:29-30.  T stays a device tensor (no host read)."""
+
+    @staticmethod
+    def forward(ctx, weight, temperature):
+        w = weight.detach().contiguous()
+        t = temperature.detach().to(device=w.device, dtype=torch.float32).reshape(1)
+        taps = torch.empty_like(w)
+        _run("rk_soft_taps_forward_f32", w.device, w.data_ptr(), t.data_ptr(), taps.data_ptr(), w.shape[0])
+        ctx.save_for_backward(w, t, taps)
+        return taps
+
+    @staticmethod
+    def backward(ctx, gtaps):
+        w, t, taps = ctx.saved_tensors
+        gtaps = gtaps.contiguous().float()
+        gw = torch.empty_like(w)
+        _run("rk_soft_taps_backward_f32", w.device, w.data_ptr(), t.data_ptr(), taps.data_ptr(), gtaps.data_ptr(),
+             gw.data_ptr(), w.shape[0])
+        return gw, None
+
+
 def temporal_shift3(x, taps, n_segment):
     """Functional form: x [N*T, C, H, W], taps [C, 3] (already normalised)."""
     return _TemporalShift3Func.apply(x, taps, n_segment)
@@ -80,7 +103,10 @@ class AttentionShift(nn.Module):
 
     def soft_taps(self):
         """softmax((w / (std(w) + 1e-6)) / T) over the 3 taps (attention_shift.py:29-30)."""
-        weight = self.weight / (torch.std(self.weight, dim=1, keepdim=True) + 1e-6)
+        w = self.weight
+        if w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == 3:
+            return _SoftTapsFunc.apply(w, self.T)
+        weight = w / (torch.std(w, dim=1, keepdim=True) + 1e-6)      # host-side tensors: the same expression in PyTorch
         return F.softmax(weight / self.T, dim=1)
 
     def forward(self, x):

@@ -152,6 +152,55 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_finalize(const CT* __restric
         for (int k = 0; k < 3; ++k) gtaps[c * 3 + k] = (CT)s[k];
 }
 
+
+// ---- the [C,3] half of AttentionShift (attention_shift.py:29-30): taps = softmax((w / (std(w) + 1e-6)) / T) over the
+// three taps of a channel, std unbiased (torch.std default).  One thread per channel; in PyTorch this is ~15 tiny
+// kernels forward and ~25 backward per layer (2 000 launches per Large-AQ train step).
+__global__ __launch_bounds__(kBlock) void k_soft_taps_forward(const float* __restrict__ w, const float* __restrict__ Tp,
+                                                              float* __restrict__ taps, int C) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    const float T = Tp[0];
+    const float w0 = w[3 * c], w1 = w[3 * c + 1], w2 = w[3 * c + 2];
+    const float m = (w0 + w1 + w2) / 3.0f;
+    const float d0 = w0 - m, d1 = w1 - m, d2 = w2 - m;
+    const float sd = sqrtf((d0 * d0 + d1 * d1 + d2 * d2) / 2.0f);
+    const float den = sd + 1e-6f;
+    const float z0 = w0 / den / T, z1 = w1 / den / T, z2 = w2 / den / T;
+    const float zm = fmaxf(z0, fmaxf(z1, z2));
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm), e2 = expf(z2 - zm);
+    const float es = e0 + e1 + e2;
+    taps[3 * c] = e0 / es;
+    taps[3 * c + 1] = e1 / es;
+    taps[3 * c + 2] = e2 / es;
+}
+
+// d(w) from d(taps): softmax backward, then z_i = w_i a(w) with a = 1 / (T (std + eps)), d std / d w_k = (w_k - m) / (2 std)
+// (0 / 0 = NaN when the three weights are equal, as torch.std's backward)
+__global__ __launch_bounds__(kBlock) void k_soft_taps_backward(const float* __restrict__ w, const float* __restrict__ Tp,
+                                                               const float* __restrict__ taps,
+                                                               const float* __restrict__ gtaps, float* __restrict__ gw,
+                                                               int C) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    const float w0 = w[3 * c], w1 = w[3 * c + 1], w2 = w[3 * c + 2];
+    const float T = Tp[0];
+    const float p0 = taps[3 * c], p1 = taps[3 * c + 1], p2 = taps[3 * c + 2];
+    const float g0 = gtaps[3 * c], g1 = gtaps[3 * c + 1], g2 = gtaps[3 * c + 2];
+    const float dot = g0 * p0 + g1 * p1 + g2 * p2;
+    const float z0 = p0 * (g0 - dot), z1 = p1 * (g1 - dot), z2 = p2 * (g2 - dot);   // dL/dz
+    const float m = (w0 + w1 + w2) / 3.0f;
+    const float d0 = w0 - m, d1 = w1 - m, d2 = w2 - m;
+    const float sd = sqrtf((d0 * d0 + d1 * d1 + d2 * d2) / 2.0f);
+    const float den = sd + 1e-6f;
+    const float a = 1.0f / (T * den);
+    const float zw = z0 * w0 + z1 * w1 + z2 * w2;
+    const float k = -zw / (T * den * den) / (2.0f * sd);          // (sum_i dz_i w_i) * da/dstd / (2 std)
+    gw[3 * c] = a * z0 + k * d0;
+    gw[3 * c + 1] = a * z1 + k * d1;
+    gw[3 * c + 2] = a * z2 + k * d2;
+}
+
 int make_dimsT(DimsT& d, int NT, int S, int C, int HW, int vec) {
     if (NT <= 0 || S <= 0 || C <= 0 || HW <= 0 || NT % S != 0) return RK_ERR_BAD_DIMS;
     if ((long long)NT * C * HW > 0x7fffffffLL) return RK_ERR_BAD_DIMS;
@@ -253,5 +302,21 @@ RK_DEF_TAP(f64, double, double, double)
 RK_DEF_TAP(f16, __half, void, float)
 RK_DEF_TAP(bf16, __hip_bfloat16, void, float)
 #undef RK_DEF_TAP
+
+int rk_soft_taps_forward_f32(const float* weight, const float* T, float* taps, int C, rk_stream_t stream) {
+    if (!weight || !T || !taps) return RK_ERR_NULL_POINTER;
+    if (C <= 0) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_soft_taps_forward, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, weight, T,
+                       taps, C);
+    return launch_status();
+}
+int rk_soft_taps_backward_f32(const float* weight, const float* T, const float* taps, const float* gtaps, float* gweight,
+                              int C, rk_stream_t stream) {
+    if (!weight || !T || !taps || !gtaps || !gweight) return RK_ERR_NULL_POINTER;
+    if (C <= 0) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_soft_taps_backward, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, weight, T,
+                       taps, gtaps, gweight, C);
+    return launch_status();
+}
 
 }  // extern "C"
