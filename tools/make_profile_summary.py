@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    name = name.strip('"').replace("(anonymous namespace)::", "rk::")
+    name = name.strip('"')
+    if name.startswith("void (anonymous namespace)::"):
+        name = name.replace("(anonymous namespace)::", "rk::", 1)
     if "rk::" in name:
         return name.split("(")[0].replace("void ", "")
     if "distribution_elementwise" in name:

@@ -12,7 +12,9 @@ import sys
 
 
 def short(name):
-    name = name.strip('"').replace("(anonymous namespace)::", "rk::")
+    name = name.strip('"')
+    if name.startswith("void (anonymous namespace)::"):
+        name = name.replace("(anonymous namespace)::", "rk::", 1)
     if "rk::" in name:
         return name.split("(")[0].replace("void ", "")
     for key in ("multi_tensor_apply", "elementwise_kernel", "reduce_kernel", "Cijk_", "igemm", "naive_conv", "batched_transpose",
