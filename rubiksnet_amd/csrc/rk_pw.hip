@@ -443,10 +443,10 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
     const int steps = per / kNB;                                // same for every wave: barriers stay uniform
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
-        __syncthreads();                                        // previous tile fully consumed
+        // (no workgroup barrier: the two tiles are this wave's own, and LDS executes a wave's accesses in order --
+        // with barriers here the four waves marched in lock step, MFMA phases and load phases all at once)
         wg_deposit(ta, va);
         wg_deposit(tb, vb);
-        __syncthreads();
         cur.advance(d.P);
         wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);           // next tile, in flight during the MFMAs
         wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
