@@ -199,8 +199,9 @@ __device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slo
 // Finalizers are dispatched behind the producers (and would be harmless ahead of them: C one-wave blocks against
 // hundreds of producer slots; nothing waits on a finalizer).  The workspace is uninitialised memory: a stale
 // granule passes for this launch's only if its upper 32 bits equal the tag (per-process counter seeded from the
-// clock; p = 2^-32 per granule on memory these kernels never wrote).  A finalizer that has polled ~150 ms gives up
-// and the caller writes NaN: loud, never a hang.
+// clock; p = 2^-32 per granule on memory these kernels never wrote); a finalizer retires every granule it has
+// consumed (tag 0), so replaying a captured launch -- same tag -- is safe too.  A finalizer that has polled ~2 s gives
+// up and the caller writes NaN: loud, never a hang.
 // (The first fused version -- the last-ARRIVING producer finalizes, ticket by CAS -- cost +10 us: the store ->
 // vmcnt(0) -> CAS round trips sat on every producer's exit while it held its LDS slot.)
 struct Fin {
@@ -235,7 +236,7 @@ __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double
 #pragma unroll
         for (int k = 0; k < D; ++k)
             v[k] = act ? __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done;
-        for (int spin = 0; spin < 400000; ++spin) {
+        for (int spin = 0; spin < 8000000; ++spin) {                 // ~0.25 us per poll: gives up after ~2 s
             bool ready = true;
 #pragma unroll
             for (int k = 0; k < D; ++k) ready = ready && (unsigned)(v[k] >> 32) == fin.tag;
@@ -250,6 +251,10 @@ __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double
         for (int k = 0; k < D; ++k) {
             ok = ok && (unsigned)(v[k] >> 32) == fin.tag;
             s[k] += (double)__uint_as_float((unsigned)v[k]);
+            // consumed: retire the granule (tag 0 is never issued), so that a REPLAY of this launch with the same
+            // tag -- a captured hipGraph -- cannot take the previous replay's partials for its own
+            if (act) __hip_atomic_store(const_cast<unsigned long long*>(g) + (size_t)k * P + i, 0ull, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 #pragma unroll

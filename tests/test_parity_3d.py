@@ -340,3 +340,34 @@ def test_empty_batch_and_single_element(oracle):
     assert x.grad.shape == x.shape and torch.equal(shp.grad, torch.zeros_like(shp))
     x1 = np.full((1, 1, 2, 1, 1), 2.0, np.float32)        # T = H = W = 1: at most one tap is in range
     np.testing.assert_array_equal(to_np(rubiks_shift_3d_forward(to_dev(x1), sh, 1, 0)), oracle.rk3d_forward(x1, shn))
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 6, 56, 56), (2, 4, 8, 14, 14), (2, 3, 4, 56, 56)])
+def test_backward_replayed_from_a_graph(shape):
+    """The boundary allocates and synchronises nothing, so a call can be captured in a hipGraph.  A replay repeats the
+    launch WITH THE SAME granule tag: the in-launch row-sum must not take the previous replay's partials for its own
+    (rk_dma.hpp: consumed granules are retired)."""
+    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
+
+    stride = (1, 2, 2) if shape == (2, 3, 4, 56, 56) else 1
+    torch.manual_seed(5)
+    N, T, C, H, W = shape
+    x = torch.rand(shape, device="cuda:0") * 2 - 1
+    shift = torch.rand(3, C, device="cuda:0") * 2 - 1
+    Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if stride != 1 else (H, W)
+    gy = torch.rand(N, T, C, Ho, Wo, device="cuda:0") * 2 - 1
+    rubiks_shift_3d_backward(gy, x, shift, stride, 0, True)              # warm up outside the capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            gx_g, gs_g = rubiks_shift_3d_backward(gy, x, shift, stride, 0, True)
+    for it in range(4):
+        x.copy_(torch.rand_like(x) * 2 - 1)
+        gy.copy_(torch.rand_like(gy) * (it + 1))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        gx_e, gs_e = rubiks_shift_3d_backward(gy, x, shift, stride, 0, True)
+        assert torch.equal(gx_g, gx_e) and torch.equal(gs_g, gs_e), it
