@@ -235,6 +235,11 @@ int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* 
  *                   Y [F,Cout,Hin/2,Win/2]; Hin even, Win % 8 == 0, 9 Cin <= 64.                              */
 int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
                           rk_stream_t stream);
+/* d(weight) of that convolution: dW [Cout][Cin][3][3] (fp32) from dY [F, Cout, Hin/2, Win/2] and X [F, Cin, Hin, Win];
+ * workspace of rk_pw_wgrad_workspace_bytes(F, 9 * Cin, Cout, (Hin/2) * (Win/2)) bytes.  Replaces the d(weight) half of
+ * conv2d's backward for the stem (backbone.py:154); the stem needs no d(input). */
+int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                           void* workspace, size_t workspace_bytes, rk_stream_t stream);
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
                     size_t ws_bytes, rk_stream_t stream);

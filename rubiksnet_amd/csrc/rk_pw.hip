@@ -357,6 +357,7 @@ struct WgDims {
     int MB, KB;                          // 64-row blocks of dY / X
     int S;                               // pixel chunks
     int chunk;                           // pixels per chunk (multiple of kNB)
+    int Cin, Hin, Win, Wo;               // STEM mode only: X is the image [F, Cin, Hin, Win], K = 9 Cin, P = Ho * Wo
 };
 
 // this lane's position in the pixel stream: n = (f, p); advanced 32 pixels per tile without dividing
@@ -389,6 +390,28 @@ __device__ __forceinline__ void wg_fetch(const TT* __restrict__ T, int rows, int
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// STEM: the X tile is the im2col of a 3x3 / stride-2 / pad-1 convolution gathered on the fly (row k = (ci, kh, kw),
+// column = output pixel): the lane's 4 consecutive output pixels read 4 input pixels 2 apart (cf. k_pw_gemm's STEM)
+__device__ __forceinline__ void wg_fetch_stem(const float* __restrict__ X, const WgDims& d, const PixCursor& c,
+                                              long long nend, float4 (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    const bool nok = c.n < nend;
+    const int ho = c.p / d.Wo, wo = c.p - ho * d.Wo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * j + (lane >> 3);
+        const int ci = k / 9, r9 = k - 9 * ci, kh3 = r9 / 3, kw3 = r9 - 3 * kh3;
+        const int hi = 2 * ho - 1 + kh3, wi = 2 * wo - 1 + kw3;
+        const bool ok = nok && k < d.K && hi >= 0 && hi < d.Hin;
+        const float* row = X + (((size_t)(nok ? c.f : 0) * d.Cin + (ok ? ci : 0)) * d.Hin + (ok ? hi : 0)) * d.Win;
+        float4 t;
+        t.x = (ok && wi >= 0) ? row[wi >= 0 ? wi : 0] : 0.f;
+        t.y = ok ? row[wi + 2] : 0.f;
+        t.z = ok ? row[wi + 4] : 0.f;
+        t.w = ok ? row[wi + 6] : 0.f;
+        v[j] = t;
+    }
+}
 __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -399,7 +422,7 @@ __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     }
 }
 
-template <typename T>
+template <typename T, bool STEM = false>
 __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, const T* __restrict__ X,
                                                      float* __restrict__ ws, WgDims d) {
     __shared__ float tiles[4][2][64 * kNB];
@@ -439,7 +462,8 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
     PixCursor cur;
     cur.init(n0, d.P);
     wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);
-    wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
+    if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
+    else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
     const int steps = per / kNB;                                // same for every wave: barriers stay uniform
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
@@ -449,7 +473,8 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
         wg_deposit(tb, vb);
         cur.advance(d.P);
         wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);           // next tile, in flight during the MFMAs
-        wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
+        if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
+        else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
 #pragma unroll
         for (int s = 0; s < kNB / 2; ++s) {
             const float a0 = ta[tile_at(l31, 2 * s + kh)], a1 = ta[tile_at(32 + l31, 2 * s + kh)];
@@ -922,6 +947,33 @@ int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int C
     if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
     else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
     else hipLaunchKernelGGL((k_pw_gemm<float, 4, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
+    return launch_status();
+}
+// d(weight) of the same stem convolution: dW [Cout][Cin][3][3] = sum over frames and output pixels of dY x im2col(X);
+// dY [F, Cout, Ho, Wo], X [F, Cin, Hin, Win]; ws of rk_pw_wgrad_workspace_bytes(F, 9 Cin, Cout, Ho * Wo) bytes.
+int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                           void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || 9 * Cin > 64) return RK_ERR_BAD_DIMS;
+    if ((uintptr_t)dY & 15) return RK_ERR_BAD_DIMS;
+    const int K = 9 * Cin, M = Cout, P = (Hin / 2) * (Win / 2);
+    WgDims d;
+    if (int rc = make_wg(d, F, K, M, P)) return rc;
+    d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    if (!ws || ws_bytes < (size_t)(d.S + kRed) * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nmk = d.MB * d.KB, bpw = nmk < 4 ? nmk : 4, groups = (nmk + bpw - 1) / bpw;
+    float* part = (float*)ws;
+    float* part2 = part + (size_t)d.S * M * K;
+    const int MK = M * K;
+    const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_pw_wgrad<float, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    if (d.S > kRed) {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
+    } else {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
+    }
     return launch_status();
 }
 // Inference: Y[f] = epi(A pro(X[f])) (+ R[f]) with the per-channel affine (+ReLU) stages of PwFuse above; ka / kb

@@ -259,14 +259,30 @@ class _StemFunc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(
-            dy.contiguous(), x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
-            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        dy = dy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:                       # (never in the networks: the stem's input is the clip)
+            gx = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            # d(weight) on the same im2col-on-the-fly gather as the forward: MIOpen's pair of asm kernels takes
+            # 1.04 ms per step at [256,3,224,224] -> 54 channels
+            Fr, Cin, H, W = x.shape
+            Cout = weight.shape[0]
+            dev = x.device
+            L = _native.lib()
+            gw = torch.empty_like(weight)
+            with torch.cuda.device(dev):
+                nbytes = int(L.rk_pw_wgrad_workspace_bytes(Fr, 9 * Cin, Cout, (H // 2) * (W // 2)))
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                rc = L.rk_stem_wgrad3x3s2_f32(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), Fr, Cin, Cout, H, W,
+                                              ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(rc, "rk_stem_wgrad3x3s2_f32")
         return gx, gw
 
 
 def stem_conv(conv, x):
-    """`conv(x)` for the backbone's 3x3 / stride-2 / pad-1 first layer (forward on the HIP GEMM; backward on aten)."""
+    """`conv(x)` for the backbone's 3x3 / stride-2 / pad-1 first layer (forward and d(weight) on the HIP GEMM kernels)."""
     # under autocast the stock layer would produce a bf16 activation: leave it to autocast (an fp32 output here would
     # keep the next BatchNorm / shift in fp32 storage)
     ok = (pointwise_mode() != "0" and not torch.is_autocast_enabled()

@@ -132,7 +132,7 @@ def test_ineligible_layers_take_the_stock_path(monkeypatch):
 @pytest.mark.parametrize("shape", [(3, 3, 32, 40, 54), (2, 3, 224, 224, 72), (5, 2, 18, 16, 20), (2, 7, 8, 8, 150)])
 def test_stem_conv(shape):
     """The 3x3 / stride-2 / pad-1 first layer on the MFMA GEMM (im2col gathered on the fly) against F.conv2d in fp64;
-    d(weight) goes through aten."""
+    d(weight) on the d(weight) kernel with the same gather (rk_stem_wgrad3x3s2_f32)."""
     from rubiksnet_amd.pointwise import stem_conv
 
     Fr, Cin, H, W, Cout = shape
