@@ -310,6 +310,25 @@ MODEL_LEGS = {
 }
 
 
+def run_in(env, step, min_s=1.5, max_s=12.0):
+    times, t0 = [], time.perf_counter()
+    while True:
+        ts = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - ts)
+        elapsed = time.perf_counter() - t0
+        settled = False
+        if elapsed >= min_s and len(times) >= 12:
+            a, b = sum(times[-6:]) / 6, sum(times[-12:-6]) / 6
+            settled = abs(a - b) <= 0.03 * b
+        flags = torch.tensor([0.0 if settled else 1.0, 1.0 if elapsed > max_s else 0.0], device=env.device)
+        if env.distributed:
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX)
+        if flags[0].item() == 0.0 or flags[1].item() == 1.0:      # everyone settled, or someone ran out of time
+            return len(times)
+
+
 def model_bench(env, leg, per_gpu_batch, steps, warmup):
     from rubiksnet_amd import RubiksNet
 
@@ -338,12 +357,12 @@ def model_bench(env, leg, per_gpu_batch, steps, warmup):
                 dp.train_step(model, opt, clips, labels)
         desc = "train step (fwd+bwd+Adam%s), %s" % (", DDP all-reduce" if env.distributed else "",
                                                      "bf16 autocast" if amp is not None else "fp32")
-    # untimed run-in: a fresh process needs ~40 steps before a train step reaches its sustained time (Tiny: 35.6 ms
-    # averaged over steps 3-8, 30.9 over 3-22, 28.4 over 3-152: MIOpen / allocator warm-up, then the clock settle)
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 1.5:
-        step()
-        torch.cuda.synchronize()
+    # untimed run-in: a fresh process needs tens of steps before a train step reaches its sustained time (MIOpen /
+    # rocBLAS pick and compile their kernels, the allocator warms up, then the clocks settle: the FIRST model leg of a
+    # fresh box read 31-38 ms for Tiny with a fixed 1.5 s run-in, 26-28 ms in a second process).  Run until the step
+    # time has settled -- the last 6 steps within 3 % of the 6 before -- for at least 1.5 s and at most ~12 s.  The
+    # stop decision is taken collectively, so every rank runs the same number of steps (a DDP step is a collective).
+    run_in(env, step)
     for _ in range(warmup):
         step()
     dt = dp.timed_region(env, step, steps)

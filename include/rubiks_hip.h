@@ -240,6 +240,17 @@ int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int C
  * conv2d's backward for the stem (backbone.py:154); the stem needs no d(input). */
 int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
                            void* workspace, size_t workspace_bytes, rk_stream_t stream);
+/* 1x1 / stride-2 / no-bias convolution (the projecting shortcut of a downsampling block, backbone.py:98-104) on the
+ * same GEMM kernels: forward (the streamed operand read at stride 2), d(input) (results scattered to the even
+ * positions, zeros elsewhere: every element of dX is written) and d(weight).  W [Cout][Cin] fp32, X / dX
+ * [F, Cin, Hin, Win], Y / dY [F, Cout, Hin/2, Win/2]; Hin even, Win % 8 == 0, Cin and Cout even; the d(weight)
+ * workspace is rk_pw_wgrad_workspace_bytes(F, Cin, Cout, (Hin/2) * (Win/2)) bytes. */
+int rk_pw_s2_forward_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                         rk_stream_t stream);
+int rk_pw_s2_dgrad_f32(const float* W, const float* dY, float* dX, int F, int Cin, int Cout, int Hin, int Win,
+                       rk_stream_t stream);
+int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                       void* workspace, size_t workspace_bytes, rk_stream_t stream);
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
                     size_t ws_bytes, rk_stream_t stream);

@@ -96,7 +96,12 @@ struct AStage {
 // a [K, P] matrix (the backbone's first layer, backbone.py:154 Conv3x3(3, width, stride=2)): column = output
 // pixel, k = (ci, kh, kw); a lane's 4 output pixels read 4 input pixels 2 apart (the only out-of-range ones
 // are row -1 / Hin and column -1).
-template <typename T, int WM, int kKC, bool FUSE, bool STEM = false>
+// S2 = 1: the streamed operand is a [K, Hin, Win] frame read at stride 2 (1x1 / stride-2 convolution, the projecting
+// shortcuts, backbone.py:98-104): column = output pixel (ho, wo), a lane's 4 pixels read 4 input pixels 2 apart.
+// S2 = 2: d(input) of that convolution: the result block of output pixel (ho, wo..wo+3) is scattered to the input-
+// sized tensor at (2 ho, 2 wo ..) with zeros in between and in row 2 ho + 1 (four 16-byte stores, every element of
+// d(input) written once: no memset).
+template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
                                                     const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz) {
     using Raw = typename Px4<T>::Raw;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
 
-    const int s_ho = STEM ? p / d.Wo : 0, s_wo = STEM ? p - s_ho * d.Wo : 0;      // this lane's first output pixel
+    const int s_ho = (STEM || S2) ? p / d.Wo : 0, s_wo = (STEM || S2) ? p - s_ho * d.Wo : 0;   // this lane's first output pixel
     auto load_b = [&](int k) -> Raw {
         if constexpr (STEM && std::is_same<T, float>::value) {
             const int ci = k / 9, r9 = k - 9 * ci, kh3 = r9 / 3, kw3 = r9 - 3 * kh3;
@@ -133,6 +138,15 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             v.y = ok ? row[wi + 2] : 0.f;
             v.z = ok ? row[wi + 4] : 0.f;
             v.w = ok ? row[wi + 6] : 0.f;
+            return v;
+        } else if constexpr (S2 == 1 && std::is_same<T, float>::value) {
+            const bool ok = valid && k < d.K;
+            const float* row = X + (((size_t)f * d.K + (ok ? k : 0)) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
+            float4 v;
+            v.x = ok ? row[0] : 0.f;
+            v.y = ok ? row[2] : 0.f;
+            v.z = ok ? row[4] : 0.f;
+            v.w = ok ? row[6] : 0.f;
             return v;
         } else {
             return (valid && k < d.K) ? Px4<T>::load(xp + (size_t)k * d.P) : Px4<T>::zero();
@@ -195,7 +209,16 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
                         const float4 t = Px4<T>::widen(Px4<T>::load(R + (yp - Y) + (size_t)gm * d.P));
                         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
                     }
-                    Px4<T>::store(yp + (size_t)gm * d.P, o);
+                    if constexpr (S2 == 2 && std::is_same<T, float>::value) {
+                        float* q = Y + (((size_t)f * d.M + gm) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
+                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4*>(q) = make_float4(o.x, 0.f, o.y, 0.f);
+                        *reinterpret_cast<float4*>(q + 4) = make_float4(o.z, 0.f, o.w, 0.f);
+                        *reinterpret_cast<float4*>(q + d.Win) = z;
+                        *reinterpret_cast<float4*>(q + d.Win + 4) = z;
+                    } else {
+                        Px4<T>::store(yp + (size_t)gm * d.P, o);
+                    }
                 }
             }
     }
@@ -412,6 +435,20 @@ __device__ __forceinline__ void wg_fetch_stem(const float* __restrict__ X, const
         v[j] = t;
     }
 }
+// stride-2 1x1 convolution: X is [F, K, Hin, Win], column = output pixel (ho, wo) <- input pixel (2 ho, 2 wo)
+__device__ __forceinline__ void wg_fetch_s2(const float* __restrict__ X, const WgDims& d, int r0, const PixCursor& c,
+                                            long long nend, float4 (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    const bool nok = c.n < nend;
+    const int ho = c.p / d.Wo, wo = c.p - ho * d.Wo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 8 * j + (lane >> 3);
+        const bool ok = nok && r < d.K;
+        const float* row = X + (((size_t)(nok ? c.f : 0) * d.K + (ok ? r : 0)) * d.Hin + 2 * ho) * d.Win + 2 * wo;
+        v[j] = ok ? make_float4(row[0], row[2], row[4], row[6]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -422,7 +459,7 @@ __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     }
 }
 
-template <typename T, bool STEM = false>
+template <typename T, bool STEM = false, bool S2 = false>
 __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, const T* __restrict__ X,
                                                      float* __restrict__ ws, WgDims d) {
     __shared__ float tiles[4][2][64 * kNB];
@@ -463,6 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
     cur.init(n0, d.P);
     wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);
     if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
+    else if constexpr (S2 && std::is_same<T, float>::value) wg_fetch_s2(X, d, 64 * kb, cur, nend, vb);
     else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
     const int steps = per / kNB;                                // same for every wave: barriers stay uniform
 #pragma nounroll
@@ -474,6 +512,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
         cur.advance(d.P);
         wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);           // next tile, in flight during the MFMAs
         if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
+        else if constexpr (S2 && std::is_same<T, float>::value) wg_fetch_s2(X, d, 64 * kb, cur, nend, vb);
         else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
 #pragma unroll
         for (int s = 0; s < kNB / 2; ++s) {
@@ -968,6 +1007,63 @@ int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, in
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_pw_wgrad<float, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    if (d.S > kRed) {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
+    } else {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
+    }
+    return launch_status();
+}
+// 1x1 / stride-2 convolution, no bias (the projecting shortcuts): forward (mode 1: X [F,K,Hin,Win] -> Y [F,M,Ho,Wo]) and
+// d(input) (mode 2: X = dY [F,K=Cout,Ho,Wo] -> Y = dX [F,M=Cin,Hin,Win], every element written).  Hin, Win even,
+// Wo % 4 == 0, K even.
+static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, int Hin, int Win, int mode, int a_is_mk,
+                 rk_stream_t stream_) {
+    if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || K <= 0 || M <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || K % 2) return RK_ERR_BAD_DIMS;
+    if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
+    PwDims d;
+    d.F = F; d.K = K; d.M = M; d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    d.P = (Hin / 2) * d.Wo; d.ntot = (long long)F * d.P; d.a_is_mk = a_is_mk;
+    const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
+    d.WM = wm; d.WN = 4 / wm;
+    const int mt = 64 * wm;
+    const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
+    hipStream_t stream = (hipStream_t)stream_;
+    const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const float* R = nullptr;
+#define RK_S2_GO(WMV, MODE) hipLaunchKernelGGL((k_pw_gemm<float, WMV, 12, false, false, MODE>), grid, block, 0, stream, A, X, R, Y, d, fz)
+    if (mode == 1) { if (wm == 1) RK_S2_GO(1, 1); else RK_S2_GO(2, 1); }
+    else { if (wm == 1) RK_S2_GO(1, 2); else RK_S2_GO(2, 2); }
+#undef RK_S2_GO
+    return launch_status();
+}
+int rk_pw_s2_forward_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                         rk_stream_t stream) {
+    return pw_s2(W, X, Y, F, Cin, Cout, Hin, Win, 1, 1, stream);
+}
+int rk_pw_s2_dgrad_f32(const float* W, const float* dY, float* dX, int F, int Cin, int Cout, int Hin, int Win,
+                       rk_stream_t stream) {
+    return pw_s2(W, dY, dX, F, Cout, Cin, Hin, Win, 2, 0, stream);     // W read as [K=Cout][M=Cin]
+}
+int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* ws,
+                       size_t ws_bytes, rk_stream_t stream_) {
+    if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8) return RK_ERR_BAD_DIMS;
+    if ((uintptr_t)dY & 15) return RK_ERR_BAD_DIMS;
+    const int K = Cin, M = Cout, P = (Hin / 2) * (Win / 2);
+    WgDims d;
+    if (int rc = make_wg(d, F, K, M, P)) return rc;
+    d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    if (!ws || ws_bytes < (size_t)(d.S + kRed) * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nmk = d.MB * d.KB, bpw = nmk < 4 ? nmk : 4, groups = (nmk + bpw - 1) / bpw;
+    float* part = (float*)ws;
+    float* part2 = part + (size_t)d.S * M * K;
+    const int MK = M * K;
+    const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_pw_wgrad<float, false, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     if (d.S > kRed) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);

@@ -20,6 +20,7 @@ _BF16_CMAX = 128            # bf16-MFMA GEMM, H*W >= 784
 _F32_CMAX_56 = 128          # fp32, H*W >= 3136
 _F32_CMAX_28 = 160          # fp32, H*W >= 784: 108 ch ties MIOpen (77 vs 76 us), 144 ch wins (123 vs 215)
 _F32_CMAX_14 = 320          # fp32, H*W >= 196: a tie on its own (288 ch: 101 vs 106 us), a win with the residual add fused
+_S2_CMAX = 320              # 1x1 / stride-2 shortcuts (fp32)
 _FUSED_EVAL_CMAX = 320      # inference fusion: channel limit of rk_pw_gemm_fused_f32's register tile
 _FUSED_EVAL_PMIN = 196      # ... and smallest plane it pays for
 
@@ -136,6 +137,59 @@ def _eligible(conv, x, has_residual=False):
     return P >= 196 and K <= _F32_CMAX_14 and M <= _F32_CMAX_14
 
 
+class _ConvS2Func(torch.autograd.Function):
+    """1x1 / stride-2 convolution (the projecting shortcut of a downsampling block) on the HIP GEMM kernels:
+    forward reads the activation at stride 2, d(input) scatters into the even positions (zeros elsewhere, every
+    element written), d(weight) gathers like the forward.  MIOpen runs these as two asm kernels + an implicit-GEMM
+    d(weight) between layout transposes (1.3 ms + of a Tiny train step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_pw_s2_forward_f32(weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W,
+                                                    torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_pw_s2_forward_f32")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        L = _native.lib()
+        dx = dw = None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _native.check(L.rk_pw_s2_dgrad_f32(weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), Fr, Cin, Cout, H, W,
+                                                   stream), "rk_pw_s2_dgrad_f32")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                nbytes = int(L.rk_pw_wgrad_workspace_bytes(Fr, Cin, Cout, (H // 2) * (W // 2)))
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                _native.check(L.rk_pw_s2_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H, W,
+                                                   ws.data_ptr(), nbytes, stream), "rk_pw_s2_wgrad_f32")
+        return dx, dw
+
+
+def _eligible_s2(conv, x):
+    return (pointwise_mode() != "0" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
+            and not torch.is_autocast_enabled()
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
+            and max(conv.in_channels, conv.out_channels) <= _S2_CMAX
+            and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+
+
 def conv1x1(conv, x, residual=None):
     """`conv(x)` (`conv(x) + residual` when a residual is given) for a 1x1 nn.Conv2d module -- or an nn.Sequential
     ending in one (the -aq variant prepends its AttentionShift to conv2, models.py:_prepare_backbone)."""
@@ -143,6 +197,8 @@ def conv1x1(conv, x, residual=None):
         for m in list(conv)[:-1]:
             x = m(x)
         conv = conv[-1]
+    if residual is None and _eligible_s2(conv, x):
+        return _ConvS2Func.apply(x.contiguous(), conv.weight)
     hip_gemm = _eligible(conv, x, residual is not None)
     if hip_gemm is None or (residual is not None and not (residual.is_contiguous() and residual.dtype == x.dtype)):
         y = conv(x)

@@ -149,3 +149,35 @@ def test_stem_conv(shape):
     wr = conv.weight.detach().double().cpu().requires_grad_(True)
     F.conv2d(x.double(), wr, stride=2, padding=1).backward(dy.double())
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=1e-4 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(3, 6, 16, 24, 10), (2, 54, 112, 112, 54), (4, 54, 56, 56, 108), (5, 108, 28, 24, 216),
+                                   (2, 144, 28, 32, 288)])
+def test_strided_shortcut_conv(shape):
+    """1x1 / stride-2 convolution (projecting shortcut) on the GEMM kernels -- strided gather forward, scattered
+    d(input) with every element written, gathered d(weight) -- against F.conv2d in fp64."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    Fr, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(Fr, Cin, H, W, generator=g)
+    conv = nn.Conv2d(Cin, Cout, 1, stride=2, bias=False)
+    dy = torch.randn(Fr, Cout, H // 2, W // 2, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=2)
+    ref.backward(dy.double())
+    conv = conv.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = conv1x1(conv, xg)
+    assert "ConvS2Func" in type(y.grad_fn).__name__
+    tol = 3e-6 * Cin ** 0.5
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=tol * float(ref.abs().max()))
+    dx_poison = torch.full_like(xg, float("nan"))          # d(input) must be written everywhere (no memset relied on)
+    y.backward(dy.cuda())
+    del dx_poison
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=0,
+                               atol=3e-6 * Cout ** 0.5 * float(xr.grad.abs().max()))
+    assert float(xg.grad[:, :, 1::2, :].abs().max()) == 0.0 and float(xg.grad[:, :, :, 1::2].abs().max()) == 0.0
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0,
+                               atol=1e-4 * float(wr.grad.abs().max()))
