@@ -227,6 +227,12 @@ int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F
  *                   pro: x' = relu?(ka[k] x + kb[k]) per input channel  (relu(bn1(x)) feeding conv2, backbone.py:129-131)
  *                   epi: y  = relu?(ma[m] y + mb[m]) per output channel (relu(bn2(conv2(.))), BatchNorm in eval mode:
  *                   a = gamma / sqrt(running_var + eps), b = beta - running_mean * a).  NULL pairs switch a stage off. */
+/* SURVEY 8(f) f1 (inference): Y[f] = A RubiksShift3D(X)[f] (+ R[f]) -- the conv3 of a block (backbone.py:133) fed by its
+ * as3 shift (:132), the shift's gather done in the GEMM's operand load so that the shifted activation is never stored.
+ * X [NT, K, H, W] (NT = clips * T frames), shift [3][K] (rows T, H, W), stride 1 / pad 0, no quantize, W % 4 == 0;
+ * bit-identical to rk3d_forward_f32 followed by rk_pw_gemm_f32. */
+int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, const float* R, float* Y, int NT, int T,
+                           int K, int M, int H, int W, rk_stream_t stream);
 int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, const float* ma,
                          const float* mb, int relu_out, rk_stream_t stream);

@@ -3,6 +3,9 @@
     RK_FUSED_BN    1 | 0          relu(bn(x)) pairs through the fused HIP operator (fused_bn.py) / stock modules
     RK_PW          auto | 0 | all 1x1 convolutions on the HIP MFMA GEMM where it wins / never / wherever it can run
     RK_FUSED_EVAL  1 | 0          inference blocks with BN + residual folded into the two GEMMs / layer by layer
+    RK_F1          0 | 1          inference blocks: shift kernel, then the conv3 GEMM / the 3-D shift inside conv3's operand
+                                  load (gather form: bit-identical, never stores the shifted activation,
+                                  but 1.7x slower than the two kernels -- DESIGN 7 -- hence off)
 
 Everything else that used to be tunable from the environment (tile shapes, channel limits, prefetch depths)
 is a constant next to the code it tunes.  The native library has one switch of its own, RK_SHIFT_KERNELS
@@ -19,6 +22,7 @@ class Switches:
     fused_bn: bool = True
     pointwise: str = "auto"          # "auto" | "0" | "all"
     fused_eval: bool = True
+    fused_shift_gemm: bool = False
 
     @staticmethod
     def from_env(env=None):
@@ -27,7 +31,8 @@ class Switches:
         if pw not in ("auto", "0", "all"):
             raise ValueError("RK_PW must be auto, 0 or all (got %r)" % pw)
         return Switches(fused_bn=env.get("RK_FUSED_BN", "1") != "0", pointwise=pw,
-                        fused_eval=env.get("RK_FUSED_EVAL", "1") != "0")
+                        fused_eval=env.get("RK_FUSED_EVAL", "1") != "0",
+                        fused_shift_gemm=env.get("RK_F1", "0") == "1")
 
 
 _current = Switches.from_env()

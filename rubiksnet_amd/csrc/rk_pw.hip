@@ -17,6 +17,7 @@
 // (cdna_hip_programming.md, "FP32-input MFMA") -- same arithmetic class as the MIOpen / rocBLAS fp32 kernels.
 #include <type_traits>
 #include "rk_common.hpp"
+#include "rk3d_generic.hpp"
 
 namespace rk {
 namespace pw {
@@ -56,6 +57,8 @@ struct PwDims {
     int a_is_mk;            // A given as [M][K] row-major (the weight itself), else [K][M]
     int Cin, Hin, Win, Wo;  // STEM mode only: 3x3 / stride 2 / pad 1 convolution, K = 9 Cin, P = Ho * Wo
     int WM, WN;             // waves along M / along N (WM * WN = 4); workgroup tile = 64 WM rows x 128 WN columns
+    const float* shift;     // SHIFT mode only: RubiksShift3D table [3][K]; frames are (n, t), t < T; plane Hin x Win
+    int T;
 };
 
 
@@ -101,7 +104,12 @@ struct AStage {
 // S2 = 2: d(input) of that convolution: the result block of output pixel (ho, wo..wo+3) is scattered to the input-
 // sized tensor at (2 ho, 2 wo ..) with zeros in between and in row 2 ho + 1 (four 16-byte stores, every element of
 // d(input) written once: no memset).
-template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0>
+// SHIFT (inference): the streamed operand is RubiksShift3D(X) (stride 1 / pad 0, W % 4 == 0) computed
+// on the fly -- a lane's 4 consecutive pixels of channel k come from 2 planes x 2 rows x 5 columns of X through the
+// reference's trilinear tree (rk3d_generic.hpp trilerp, contraction off), so the B fragments are bit-identical to what
+// the shift kernels would have written and Y is bit-identical to "shift, then this GEMM"; the shifted activation is
+// never stored.
+template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0, bool SHIFT = false>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
                                                     const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz) {
     using Raw = typename Px4<T>::Raw;
@@ -127,6 +135,8 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
 
     const int s_ho = (STEM || S2) ? p / d.Wo : 0, s_wo = (STEM || S2) ? p - s_ho * d.Wo : 0;   // this lane's first output pixel
+    const int sh_h = SHIFT ? p / d.Win : 0, sh_w = SHIFT ? p - sh_h * d.Win : 0;              // SHIFT: (h, w) of pixel 0
+    const int sh_n = SHIFT ? f / d.T : 0, sh_t = SHIFT ? f - sh_n * d.T : 0;
     auto load_b = [&](int k) -> Raw {
         if constexpr (STEM && std::is_same<T, float>::value) {
             const int ci = k / 9, r9 = k - 9 * ci, kh3 = r9 / 3, kw3 = r9 - 3 * kh3;
@@ -139,6 +149,32 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             v.z = ok ? row[wi + 4] : 0.f;
             v.w = ok ? row[wi + 6] : 0.f;
             return v;
+        } else if constexpr (SHIFT && std::is_same<T, float>::value) {
+            if (!(valid && k < d.K)) return make_float4(0.f, 0.f, 0.f, 0.f);
+            const Frac<float> fT = split_shift(d.shift[k]), fH = split_shift(d.shift[d.K + k]),
+                              fW = split_shift(d.shift[2 * d.K + k]);
+            const int t0 = sh_t + fT.fl, h0 = sh_h + fH.fl, w0 = sh_w + fW.fl;
+            float v[2][2][5];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool vt = t0 + j >= 0 && t0 + j < d.T;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool vh = vt && h0 + i >= 0 && h0 + i < d.Hin;
+                    const float* row = X + (((size_t)(sh_n * d.T + (vt ? t0 + j : 0)) * d.K + k) * d.Hin + (vh ? h0 + i : 0)) * d.Win;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const int w = w0 + c;
+                        v[j][i][c] = (vh && w >= 0 && w < d.Win) ? row[w] : 0.f;
+                    }
+                }
+            }
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = trilerp(v[0][0][q], v[0][0][q + 1], v[0][1][q], v[0][1][q + 1], v[1][0][q], v[1][0][q + 1],
+                               v[1][1][q], v[1][1][q + 1], fT.r, fH.r, fW.r);
+            return make_float4(o[0], o[1], o[2], o[3]);
         } else if constexpr (S2 == 1 && std::is_same<T, float>::value) {
             const bool ok = valid && k < d.K;
             const float* row = X + (((size_t)f * d.K + (ok ? k : 0)) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
@@ -876,7 +912,7 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if (((uintptr_t)X & am) || ((uintptr_t)Y & am)) return RK_ERR_BAD_DIMS;
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
-    d.Cin = d.Hin = d.Win = d.Wo = 0;
+    d.Cin = d.Hin = d.Win = d.Wo = 0; d.shift = nullptr; d.T = 0;
     // rows per workgroup tile = 64 wm.  Above 128 rows 64-row tiles win although the streamed operand is then
     // re-read once per tile (L2 / Infinity Cache absorb it; 288 rows: 101 us against 141 / 179 us with 128 / 256-row
     // tiles, which also pad 288 to 384 / 512)
@@ -974,7 +1010,7 @@ int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int C
     if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || 9 * Cin > 64) return RK_ERR_BAD_DIMS;
     if ((uintptr_t)Y & 15) return RK_ERR_BAD_DIMS;
     PwDims d;
-    d.F = F; d.K = 9 * Cin; d.M = Cout; d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    d.F = F; d.K = 9 * Cin; d.M = Cout; d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0;
     d.P = (Hin / 2) * d.Wo; d.ntot = (long long)F * d.P; d.a_is_mk = 1;
     const int wm = Cout <= 64 ? 1 : (Cout <= 128 ? 2 : 4);
     d.WM = wm; d.WN = 4 / wm;
@@ -1024,7 +1060,7 @@ static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, 
     if (F <= 0 || K <= 0 || M <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || K % 2) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
     PwDims d;
-    d.F = F; d.K = K; d.M = M; d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    d.F = F; d.K = K; d.M = M; d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0;
     d.P = (Hin / 2) * d.Wo; d.ntot = (long long)F * d.P; d.a_is_mk = a_is_mk;
     const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
     d.WM = wm; d.WN = 4 / wm;
@@ -1070,6 +1106,30 @@ int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Ci
     } else {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
     }
+    return launch_status();
+}
+// SURVEY 8(f) f1, inference: Y[f] = A RubiksShift3D(X)[f] (+ R[f]) with the shift (stride 1 / pad 0, no quantize) applied
+// in the operand load -- the conv3 of a block fed by its as3 shift, plus the residual.  X [N*T, K, H, W], shift [3][K],
+// W % 4 == 0, K even; bit-identical to rk3d_forward_f32 followed by rk_pw_gemm_f32.
+int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, const float* R, float* Y, int NT, int T,
+                           int K, int M, int H, int W, rk_stream_t stream_) {
+    if (!A || !X || !shift || !Y) return RK_ERR_NULL_POINTER;
+    if (NT <= 0 || T <= 0 || NT % T || K <= 0 || M <= 0 || H <= 0 || W <= 0 || W % 4 || K % 2) return RK_ERR_BAD_DIMS;
+    if (((uintptr_t)Y & 15) || (R && ((uintptr_t)R & 15))) return RK_ERR_BAD_DIMS;
+    PwDims d;
+    d.F = NT; d.K = K; d.M = M; d.P = H * W; d.ntot = (long long)NT * d.P; d.a_is_mk = 1;
+    d.Cin = 0; d.Hin = H; d.Win = W; d.Wo = 0; d.shift = shift; d.T = T;
+    const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
+    d.WM = wm; d.WN = 4 / wm;
+    const int mt = 64 * wm;
+    const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
+    hipStream_t stream = (hipStream_t)stream_;
+    const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;       // the plain GEMM's choice: same k order
+#define RK_SH_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, false, false, 0, true>), grid, block, 0, stream, A, X, R, Y, d, fz)
+    if (wm == 1) { if (kc == 12) RK_SH_GO(1, 12); else RK_SH_GO(1, 16); }
+    else { if (kc == 12) RK_SH_GO(2, 12); else RK_SH_GO(2, 16); }
+#undef RK_SH_GO
     return launch_status();
 }
 // Inference: Y[f] = epi(A pro(X[f])) (+ R[f]) with the per-channel affine (+ReLU) stages of PwFuse above; ka / kb
