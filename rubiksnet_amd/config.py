@@ -1,7 +1,7 @@
 """Process-wide switches of the MI355X path, read ONCE (at import) into one frozen object.
 
     RK_FUSED_BN    1 | 0          relu(bn(x)) pairs through the fused HIP operator (fused_bn.py) / stock modules
-    RK_PW          auto | 0 | all 1x1 convolutions on the HIP MFMA GEMM where it wins / never / wherever it can run
+    RK_PW          auto | 0 | all 1x1 convolutions on the HIP MFMA GEMM wherever it can run / never / (same as auto)
     RK_FUSED_EVAL  1 | 0          inference blocks with BN + residual folded into the two GEMMs / layer by layer
     RK_F1          0 | 1          inference blocks: shift kernel, then the conv3 GEMM / the 3-D shift inside conv3's operand
                                   load (gather form: bit-identical, never stores the shifted activation,

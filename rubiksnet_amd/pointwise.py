@@ -15,11 +15,6 @@ import torch
 
 from . import _native, config
 
-# measured win regions of the forward / d(input) GEMM against MIOpen (tools/pointwise_probe.py)
-_BF16_CMAX = 128            # bf16-MFMA GEMM, H*W >= 784
-_F32_CMAX_56 = 128          # fp32, H*W >= 3136
-_F32_CMAX_28 = 160          # fp32, H*W >= 784: 108 ch ties MIOpen (77 vs 76 us), 144 ch wins (123 vs 215)
-_F32_CMAX_14 = 320          # fp32, H*W >= 196: a tie on its own (288 ch: 101 vs 106 us), a win with the residual add fused
 _S2_CMAX = 320              # 1x1 / stride-2 shortcuts (fp32)
 _FUSED_EVAL_CMAX = 320      # inference fusion: channel limit of rk_pw_gemm_fused_f32's register tile
 _FUSED_EVAL_PMIN = 196      # ... and smallest plane it pays for
@@ -125,17 +120,11 @@ def _eligible(conv, x, has_residual=False):
     K, M = conv.in_channels, conv.out_channels
     if P % 4 or K % 2 or M % 2 or x.numel() == 0:      # kernel constraints (M even: it is K of the d(input) GEMM)
         return None
-    if mode == "all":
-        return True
-    # measured win region of the GEMM (tools/pointwise_probe.py); with a residual to fuse, the 28x28 tie
-    # (77 vs 76 us) tips over: the epilogue add replaces a separate elementwise pass
-    if x.dtype == torch.bfloat16:                        # bf16-MFMA GEMM: 43 vs 137 us at 56x56, 32 vs 80 us at 28x28
-        return P >= 784 and K <= _BF16_CMAX and M <= _BF16_CMAX
-    if P >= 3136:
-        return K <= _F32_CMAX_56 and M <= _F32_CMAX_56
-    if P >= 784:
-        return K <= _F32_CMAX_28 and M <= _F32_CMAX_28
-    return P >= 196 and K <= _F32_CMAX_14 and M <= _F32_CMAX_14
+    # Round 1 restricted "auto" to a per-plane-size channel window measured with isolated, event-bracketed probes
+    # (tools/pointwise_probe.py).  Measured on the train steps themselves the HIP GEMM wins wherever it can run
+    # (RK_PW=all against that window: Large-AQ bf16 49.3 -> 45.0 ms, Large 74.4 -> 73.5, Small 44.9 -> 44.3,
+    # Tiny 25.8 -> 25.6, Tiny forward b64 equal), so "auto" and "all" now mean the same.
+    return True
 
 
 class _ConvS2Func(torch.autograd.Function):
@@ -206,10 +195,7 @@ def conv1x1(conv, x, residual=None):
         if residual is not None:
             y += residual
         return y
-    # d(input) alone also wins one step wider: 144 channels at 28x28 (Large): 194 vs MIOpen's 363 us
-    P = x.shape[2] * x.shape[3]
-    hip_dx = hip_gemm or (x.dtype == torch.float32 and pointwise_mode() == "auto" and P >= 784
-                          and max(conv.in_channels, conv.out_channels) <= _F32_CMAX_28)
+    hip_dx = hip_gemm
     return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual, hip_dx)
 
 
