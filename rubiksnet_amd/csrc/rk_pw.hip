@@ -916,6 +916,8 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     // rows per workgroup tile = 64 wm.  Above 128 rows 64-row tiles win although the streamed operand is then
     // re-read once per tile (L2 / Infinity Cache absorb it; 288 rows: 101 us against 141 / 179 us with 128 / 256-row
     // tiles, which also pad 288 to 384 / 512)
+    // (bf16, 288 rows, Large-AQ train step: 64-row tiles 45.1 ms, 128-row 47.1, 256-row 57.7: workgroup count and the
+    // per-chunk latency chain, not the re-read of the streamed operand, bound the bf16 kernel)
     const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
     d.WM = wm; d.WN = 4 / wm;
     const int mt = 64 * wm;
