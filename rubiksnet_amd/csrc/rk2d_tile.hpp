@@ -340,7 +340,9 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // Host side.  false / 0 = shape not handled here.
-constexpr int kTileFrames = 16;
+// frames per wave, [256,288,14,14] fwd / bwd us (steady state): bf16 1: 22 / 44, 2: 19 / 31, 4: 17 / 26, 8: 17 / 26,
+// 16: 19 / 28, 32: 26 / 40, 64: 45 / 62; fp32 1: 22 / 50, 2: 21 / 40, 4: 22.5 / 35, 8: 24 / 36, 16: 27 / 42, 32: 30 / 46
+constexpr int kTileFrames = 4;
 template <typename T, int H, int W> inline bool make_tdims(TDims2& t, const Dims2& d) {
     using G = Geo<T, H, W>;
     const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
