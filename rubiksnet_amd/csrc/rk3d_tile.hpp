@@ -5,10 +5,10 @@
 // small to be a workgroup's unit of streaming (tools/stream_pattern_probe.hip: row bands below ~6 KB collapse to
 // 1.4-3.4 TB/s), W % 4 != 0 rules out the float4 cells of rk3d_dma.hpp, and the column kernels of rk3d_column.hpp
 // (per-element global taps through L1/L2) sit at 2.1 TB/s.  But in [N,T,C,H,W] the planes of consecutive channels
-// of one (n,t) are contiguous, so here the unit is a TILE = GC consecutive channels x one plane (14x14: GC = 2,
-// 1568 B = 98 aligned 16-byte pieces), DMA'd straight into LDS (global_load_lds_dwordx4 nt, counted s_waitcnt
-// vmcnt) by the wave that owns it, and a 256-thread workgroup = 4 independent waves = 8 consecutive channels =
-// 6.3 KB of contiguous traffic per plane.  A wave reads only what it DMA'd itself, so there is NO workgroup
+// of one (n,t) are contiguous, so here the unit is a TILE = GC consecutive channels x one plane (14x14: GC = 1,
+// 784 B = 49 aligned 16-byte pieces; GC = 2 measured 3-18 % slower: twice the waves win), DMA'd straight into LDS
+// (global_load_lds_dwordx4 nt, counted s_waitcnt vmcnt) by the wave that owns it, and a 256-thread workgroup = 4
+// independent waves = 4 consecutive channels = 3.1 KB of contiguous traffic per plane.  A wave reads only what it DMA'd itself, so there is NO workgroup
 // barrier anywhere.
 //
 // Work of a wave: walk t over its tile column (T + 1 steps).  A "round" is 64 lanes over 64 consecutive elements
@@ -452,13 +452,13 @@ inline bool launch_interp_hw(const float* src, const float* shift, float* dst, c
                        stream, src, shift, dst, t);
     return true;
 }
-// forward / d(x)-only; false = not handled here.  14x14: 2 channels per wave (8 rounds, 106 VGPRs), ring of 3.
+// forward / d(x)-only; false = not handled here.  14x14: 1 channel per wave (4 rounds), ring of 3 (ring of 4: slower).
 // (7x7 planes were measured on this scheme too -- 16 or 8 channels per wave -- and came out level with the column
 // kernels, 74.6 vs 74.8 us fwd+bwd at [32,8,576,7,7]; they stay there.)
 template <bool NEGATE>
 inline bool launch_interp(const float* src, const float* shift, float* dst, const Dims3& d, hipStream_t stream) {
     if (!s1p0(d) || !aligned16(src) || !aligned16(dst)) return false;
-    return launch_interp_hw<14, 14, 2, 3, NEGATE>(src, shift, dst, d, stream);
+    return launch_interp_hw<14, 14, 1, 3, NEGATE>(src, shift, dst, d, stream);
 }
 
 template <int H, int W, int GCO, int RING>
@@ -488,7 +488,7 @@ inline int launch_bwd_hw(const float* x, const float* shift, const float* gy, fl
 inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
                       const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
     if (!s1p0(d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
-    return launch_bwd_hw<14, 14, 2, 3>(x, shift, gy, gx, gshift, ws, d, normalize, t_factor, stream);
+    return launch_bwd_hw<14, 14, 1, 3>(x, shift, gy, gx, gshift, ws, d, normalize, t_factor, stream);
 }
 
 }  // namespace tile3d
