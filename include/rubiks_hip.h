@@ -253,6 +253,9 @@ int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, in
  * workspace is rk_pw_wgrad_workspace_bytes(F, Cin, Cout, (Hin/2) * (Win/2)) bytes. */
 int rk_pw_s2_forward_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
                          rk_stream_t stream);
+int rk_pw_s2_forward_fused_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                               const float* ka, const float* kb, int relu_in, rk_stream_t stream);   /* inference: x' =
+                               relu?(ka[k] x + kb[k]) on the streamed operand, as rk_pw_gemm_fused_f32's prologue */
 int rk_pw_s2_dgrad_f32(const float* W, const float* dY, float* dX, int F, int Cin, int Cout, int Hin, int Win,
                        rk_stream_t stream);
 int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,

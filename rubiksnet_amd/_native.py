@@ -43,6 +43,7 @@ SIGNATURES = {
     "rk_stem_conv3x3s2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_stem_wgrad3x3s2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_pw_s2_forward_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rk_pw_s2_forward_fused_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "rk_pw_s2_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_s2_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_pw_gemm_shift3d_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

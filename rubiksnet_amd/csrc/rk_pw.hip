@@ -1057,7 +1057,7 @@ int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, in
 // d(input) (mode 2: X = dY [F,K=Cout,Ho,Wo] -> Y = dX [F,M=Cin,Hin,Win], every element written).  Hin, Win even,
 // Wo % 4 == 0, K even.
 static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, int Hin, int Win, int mode, int a_is_mk,
-                 rk_stream_t stream_) {
+                 rk_stream_t stream_, const PwFuse* fuse = nullptr) {
     if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
     if (F <= 0 || K <= 0 || M <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || K % 2) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
@@ -1069,13 +1069,22 @@ static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, 
     const int mt = 64 * wm;
     const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
     hipStream_t stream = (hipStream_t)stream_;
-    const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const PwFuse fz = fuse ? *fuse : PwFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
     const float* R = nullptr;
-#define RK_S2_GO(WMV, MODE) hipLaunchKernelGGL((k_pw_gemm<float, WMV, 12, false, false, MODE>), grid, block, 0, stream, A, X, R, Y, d, fz)
-    if (mode == 1) { if (wm == 1) RK_S2_GO(1, 1); else RK_S2_GO(2, 1); }
-    else { if (wm == 1) RK_S2_GO(1, 2); else RK_S2_GO(2, 2); }
+#define RK_S2_GO(WMV, MODE, FU) hipLaunchKernelGGL((k_pw_gemm<float, WMV, 12, FU, false, MODE>), grid, block, 0, stream, A, X, R, Y, d, fz)
+    if (mode == 1 && fuse) { if (wm == 1) RK_S2_GO(1, 1, true); else RK_S2_GO(2, 1, true); }
+    else if (mode == 1) { if (wm == 1) RK_S2_GO(1, 1, false); else RK_S2_GO(2, 1, false); }
+    else { if (wm == 1) RK_S2_GO(1, 2, false); else RK_S2_GO(2, 2, false); }
 #undef RK_S2_GO
     return launch_status();
+}
+// inference: the same forward with relu?(ka[k] x + kb[k]) (the block's eval-mode bn1 + ReLU) applied to the streamed
+// operand on the fly
+int rk_pw_s2_forward_fused_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                               const float* ka, const float* kb, int relu_in, rk_stream_t stream) {
+    if (!ka || !kb) return RK_ERR_NULL_POINTER;
+    const PwFuse fz{ka, kb, nullptr, nullptr, relu_in, 0};
+    return pw_s2(W, X, Y, F, Cin, Cout, Hin, Win, 1, 1, stream, &fz);
 }
 int rk_pw_s2_forward_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
                          rk_stream_t stream) {

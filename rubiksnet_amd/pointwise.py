@@ -268,6 +268,40 @@ def _gemm_shift3d(conv, x, as3, residual):
     return y
 
 
+def _strided_shortcut_ok(conv, x):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
+            and max(conv.in_channels, conv.out_channels) <= _S2_CMAX and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+
+
+def _as3_stride_2(as3):
+    """True when the only subsampling inside `as3` is one shift with spatial stride (2, 2) and temporal stride 1."""
+    strides = []
+    for m in as3.modules():
+        st = getattr(m, "stride", None)
+        if st is None:
+            continue
+        st = (st,) * 2 if isinstance(st, int) else tuple(int(v) for v in st)
+        if any(v != 1 for v in st):
+            strides.append(st)
+    return len(strides) == 1 and strides[0][-2:] == (2, 2) and all(v == 1 for v in strides[0][:-2])
+
+
+def _gemm_s2_fused(conv, x, pro):
+    Fr, Cin, H, W = x.shape
+    Cout = conv.out_channels
+    y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
+    dev = x.device
+    ka, kb = pro
+    with torch.cuda.device(dev):
+        rc = _native.lib().rk_pw_s2_forward_fused_f32(conv.weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W,
+                                                      ka.data_ptr(), kb.data_ptr(), 1,
+                                                      torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "rk_pw_s2_forward_fused_f32")
+    return y
+
+
 def _stride_one(as3):
     """True when no shift inside `as3` (RubiksShift2D, the 3-D wrapper, the attention + 2-D pair) subsamples."""
     for m in as3.modules():
@@ -295,14 +329,27 @@ def fused_eval_block(block, x):
         return None
     P = x.shape[2] * x.shape[3]
     identity = isinstance(block.shortcut, torch.nn.Identity)
+    strided = not _stride_one(block.as3)
     if (P % 4 or P < _FUSED_EVAL_PMIN
             or not (_plain_1x1(block.conv2, x) and _plain_1x1(block.conv3, x))
-            or not (_eval_bn(block.bn1) and _eval_bn(block.bn2)) or not (identity or _plain_1x1(block.shortcut, x))
-            or not _stride_one(block.as3)):
+            or not (_eval_bn(block.bn1) and _eval_bn(block.bn2))):
+        return None
+    if strided:
+        # a downsampling block: as3 subsamples by (2, 2), so does the projecting shortcut (1x1 / stride 2); both GEMMs
+        # that read x still take bn1 + ReLU in their operand load
+        if (identity or not _strided_shortcut_ok(block.shortcut, x) or not _as3_stride_2(block.as3)
+                or (P // 4) % 4 or P // 4 < _FUSED_EVAL_PMIN):
+            return None
+    elif not (identity or _plain_1x1(block.shortcut, x)):
         return None
     x = x.contiguous()
     pro = _bn_affine(block.bn1)
-    shortcut = x if identity else _gemm_fused(block.shortcut, x, pro=pro)
+    if identity:
+        shortcut = x
+    elif strided:
+        shortcut = _gemm_s2_fused(block.shortcut, x, pro)
+    else:
+        shortcut = _gemm_fused(block.shortcut, x, pro=pro)
     mid = _gemm_fused(block.conv2, x, pro=pro, epi=_bn_affine(block.bn2))
     fused = _gemm_shift3d(block.conv3, mid, block.as3, shortcut)      # f1: the shift inside conv3's operand load
     if fused is not None:
