@@ -233,6 +233,10 @@ int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F
  * bit-identical to rk3d_forward_f32 followed by rk_pw_gemm_f32. */
 int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, const float* R, float* Y, int NT, int T,
                            int K, int M, int H, int W, rk_stream_t stream);
+/* eval-mode BatchNorm2d folded to y = a x + b per channel (a = gamma / sqrt(running_var + eps), b = beta -
+ * running_mean a): the (ka, kb) / (ma, mb) arrays of the fused entry points below, in one launch. */
+int rk_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                   float* a, float* b, int C, rk_stream_t stream);
 int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, const float* ma,
                          const float* mb, int relu_out, rk_stream_t stream);

@@ -66,6 +66,18 @@ struct PwDims {
 //   prologue on the streamed operand, per input channel k:   x' = relu?(ka[k] x + kb[k])   (relu(bn1(x)) -> conv2)
 //   epilogue on the result, per output channel m:             y  = relu?(ma[m] y + mb[m])   (relu(bn2(conv2(.))))
 // NULL pointers switch a stage off.
+// eval-mode BatchNorm as a per-channel affine map: a = gamma / sqrt(var + eps), b = beta - mean a (one launch instead of
+// the five elementwise PyTorch kernels per BatchNorm and forward)
+__global__ __launch_bounds__(kBlock) void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                                    float eps, float* __restrict__ a, float* __restrict__ b, int C) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] * (1.0f / sqrtf(var[c] + eps));       // = rk_bn.hip's affine(): the unfused eval path
+    a[c] = s;
+    b[c] = fmaf(-mean[c], s, beta[c]);
+}
+
 struct PwFuse {
     const float* ka; const float* kb; const float* ma; const float* mb;
     int relu_in, relu_out;
@@ -1141,6 +1153,14 @@ int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, c
     if (wm == 1) { if (kc == 12) RK_SH_GO(1, 12); else RK_SH_GO(1, 16); }
     else { if (kc == 12) RK_SH_GO(2, 12); else RK_SH_GO(2, 16); }
 #undef RK_SH_GO
+    return launch_status();
+}
+int rk_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                   float* a, float* b, int C, rk_stream_t stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !a || !b) return RK_ERR_NULL_POINTER;
+    if (C <= 0) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_bn_fold, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, a, b, C);
     return launch_status();
 }
 // Inference: Y[f] = epi(A pro(X[f])) (+ R[f]) with the per-channel affine (+ReLU) stages of PwFuse above; ka / kb

@@ -205,12 +205,22 @@ def conv1x1(conv, x, residual=None):
 # residual add on the conv3 GEMM: per block two GEMMs and the shift touch memory, nothing else.
 
 def _bn_affine(bn):
-    """(a, b) with bn(x) = a x + b in eval mode.  Recomputed on every call -- two [C]-sized ops -- because no cache
-    key sees in-place edits made through `.data` (EMA updates, checkpoint surgery; the reference itself initialises
-    with `fc.weight.data.normal_`)."""
+    """(a, b) with bn(x) = a x + b in eval mode.  Recomputed on every call -- ONE launch on [C] elements
+    (rk_bn_fold_f32) -- because no cache key sees in-place edits made through `.data` (EMA updates, checkpoint
+    surgery; the reference itself initialises with `fc.weight.data.normal_`)."""
+    w, bias, mean, var = bn.weight, bn.bias, bn.running_mean, bn.running_var
+    if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (w, bias, mean, var)):
+        ab = torch.empty(2, w.shape[0], dtype=torch.float32, device=w.device)
+        a, b = ab[0], ab[1]
+        with torch.cuda.device(w.device):
+            rc = _native.lib().rk_bn_fold_f32(w.data_ptr(), bias.data_ptr(), mean.data_ptr(), var.data_ptr(), float(bn.eps),
+                                              a.data_ptr(), b.data_ptr(), w.shape[0],
+                                              torch.cuda.current_stream(w.device).cuda_stream)
+        _native.check(rc, "rk_bn_fold_f32")
+        return a, b
     with torch.no_grad():
-        a = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
-        b = (bn.bias.float() - bn.running_mean.float() * a).contiguous()
+        a = (w.float() * torch.rsqrt(var.float() + bn.eps)).contiguous()
+        b = (bias.float() - mean.float() * a).contiguous()
     return a, b
 
 
