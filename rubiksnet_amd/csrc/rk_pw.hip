@@ -874,14 +874,16 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_bf16(const __hip_bfloat16* 
 }
 
 // out[part][i] = sum of in[c][i] over the chunks c of this part (c = part, part + parts, ...): coalesced in i,
-// fixed order.  Launched twice: S chunks -> kRed parts -> 1.
+// fixed order.  One launch (parts = 1) up to kRedDirect chunks; beyond, twice: S chunks -> kRed parts -> 1.
 constexpr int kRed = 32;
+constexpr int kRedDirect = 128;           // up to this many chunks one launch sums them (two launches: +8 us per d(weight))
 __global__ __launch_bounds__(kBlock) void k_pw_wgrad_reduce(const float* __restrict__ in, float* __restrict__ out,
                                                             int MK, int S, int parts) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int part = blockIdx.y;
     if (i >= MK) return;
     float s = 0.f;
+#pragma unroll 8
     for (int c = part; c < S; c += parts) s += in[(size_t)c * MK + i];
     out[(size_t)part * MK + i] = s;
 }
@@ -987,7 +989,7 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
     } else {
         hipLaunchKernelGGL((k_pw_wgrad<T>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     }
-    if (d.S > kRed) {
+    if (d.S > kRedDirect) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
     } else {
@@ -1057,7 +1059,7 @@ int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, in
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_pw_wgrad<float, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
-    if (d.S > kRed) {
+    if (d.S > kRedDirect) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
     } else {
@@ -1123,7 +1125,7 @@ int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Ci
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_pw_wgrad<float, false, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
-    if (d.S > kRed) {
+    if (d.S > kRedDirect) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
     } else {
