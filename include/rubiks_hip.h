@@ -201,6 +201,13 @@ size_t rk_bn_workspace_bytes(int F, int C, int P);
                                  float* running_var, float* save_mean, float* save_invstd, CTYPE* y, int F,      \
                                  int C, int P, float eps, float momentum, int relu, int training, void* ws,     \
                                  size_t ws_bytes, rk_stream_t stream);                                           \
+    /* training forward that also does nn.BatchNorm2d's `num_batches_tracked += 1` (int64 device scalar, may be   \
+     * NULL) inside the launch instead of a kernel of its own */                                                  \
+    int rk_bn_relu_forward_counted_##SFX(const CTYPE* x, const float* gamma, const float* beta,                  \
+                                         float* running_mean, float* running_var, float* save_mean,              \
+                                         float* save_invstd, CTYPE* y, int F, int C, int P, float eps,           \
+                                         float momentum, int relu, long long* num_batches_tracked, void* ws,    \
+                                         size_t ws_bytes, rk_stream_t stream);                                   \
     int rk_bn_relu_backward_##SFX(const CTYPE* dy, const CTYPE* x, const float* gamma, const float* beta,        \
                                   const float* save_mean, const float* save_invstd, const CTYPE* dskip,          \
                                   CTYPE* dx, float* dgamma, float* dbeta, int F, int C, int P, int relu,         \

@@ -60,6 +60,8 @@ for _sfx in ("f32", "bf16"):
     SIGNATURES["rk_se_scale_backward_" + _sfx] = (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p])
     SIGNATURES["rk_bn_relu_forward_" + _sfx] = (
         _i, [_p] * 8 + [_i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _i, _p, _sz, _p])
+    SIGNATURES["rk_bn_relu_forward_counted_" + _sfx] = (
+        _i, [_p] * 8 + [_i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _p, _p, _sz, _p])
     SIGNATURES["rk_bn_relu_backward_" + _sfx] = (_i, [_p] * 10 + [_i, _i, _i, _i, _p, _sz, _p])
 for _sfx in ("f32", "f64", "f16", "bf16"):
     SIGNATURES["rk2d_forward_" + _sfx] = (_i, [_p, _p, _p] + _DIMS2 + [_i, _p])

@@ -128,9 +128,12 @@ __global__ __launch_bounds__(kBlock) void k_bn_apply(const T* __restrict__ x, co
                                                      const float* __restrict__ beta, const float* __restrict__ part,
                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                     T* __restrict__ y, BnDims d, float eps, float momentum) {
+                                                     T* __restrict__ y, BnDims d, float eps, float momentum,
+                                                     long long* __restrict__ num_batches_tracked) {
     __shared__ double sm[1][2];
     const Where w = where_am_i(d);
+    // nn.BatchNorm2d's `num_batches_tracked += 1` rides on this launch (one thread), instead of a kernel of its own
+    if (TRAIN && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     float mean, invstd;
     if (TRAIN) {
         double S[2];
@@ -258,7 +261,7 @@ template <typename T> bool vec4_ok(const BnDims& d, const void* a, const void* b
 template <typename T>
 int bn_forward(const void* x_, const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* save_mean, float* save_invstd, void* y_, int F, int C, int P, float eps, float momentum,
-               int relu, int training, void* ws, size_t ws_bytes, rk_stream_t stream_) {
+               int relu, int training, void* ws, size_t ws_bytes, rk_stream_t stream_, long long* nbt) {
     const T* x = (const T*)x_; T* y = (T*)y_;
     if (!x || !y || !gamma || !beta) return RK_ERR_NULL_POINTER;
     if (training ? (!save_mean || !save_invstd) : (!running_mean || !running_var)) return RK_ERR_NULL_POINTER;
@@ -272,7 +275,7 @@ int bn_forward(const void* x_, const float* gamma, const float* beta, float* run
     const bool v4 = vec4_ok<T>(d, x, y);
 #define RK_BN_APPLY(VEC, RELU, TRAIN)                                                                              \
     hipLaunchKernelGGL((k_bn_apply<T, VEC, RELU, TRAIN>), grid, block, 0, stream, x, gamma, beta, (const float*)part, \
-                       running_mean, running_var, save_mean, save_invstd, y, d, eps, momentum)
+                       running_mean, running_var, save_mean, save_invstd, y, d, eps, momentum, nbt)
     if (training) {
         if (v4) hipLaunchKernelGGL((k_bn_stats<T, 4>), grid, block, 0, stream, x, part, d);
         else hipLaunchKernelGGL((k_bn_stats<T, 1>), grid, block, 0, stream, x, part, d);
@@ -332,7 +335,15 @@ size_t rk_bn_workspace_bytes(int F, int C, int P) {
                                  int C, int P, float eps, float momentum, int relu, int training, void* ws,      \
                                  size_t ws_bytes, rk_stream_t stream) {                                           \
         return bn_forward<TYPE>(x, gamma, beta, running_mean, running_var, save_mean, save_invstd, y, F, C, P,    \
-                                eps, momentum, relu, training, ws, ws_bytes, stream);                             \
+                                eps, momentum, relu, training, ws, ws_bytes, stream, nullptr);                    \
+    }                                                                                                             \
+    int rk_bn_relu_forward_counted_##SFX(const CTYPE* x, const float* gamma, const float* beta,                   \
+                                         float* running_mean, float* running_var, float* save_mean,               \
+                                         float* save_invstd, CTYPE* y, int F, int C, int P, float eps,            \
+                                         float momentum, int relu, long long* num_batches_tracked, void* ws,     \
+                                         size_t ws_bytes, rk_stream_t stream) {                                   \
+        return bn_forward<TYPE>(x, gamma, beta, running_mean, running_var, save_mean, save_invstd, y, F, C, P,    \
+                                eps, momentum, relu, 1, ws, ws_bytes, stream, num_batches_tracked);               \
     }                                                                                                             \
     int rk_bn_relu_backward_##SFX(const CTYPE* dy, const CTYPE* x, const float* gamma, const float* beta,         \
                                   const float* save_mean, const float* save_invstd, const CTYPE* dskip,           \

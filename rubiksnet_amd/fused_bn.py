@@ -36,7 +36,7 @@ class _BNReLUTrain(torch.autograd.Function):
     """y = relu?(batch_norm(x)) with batch statistics; updates running_mean / running_var in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, with_skip=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, with_skip=False, counter_ptr=None):
         L = _native.lib()
         Fr, C, H, W = x.shape
         P = H * W
@@ -46,10 +46,11 @@ class _BNReLUTrain(torch.autograd.Function):
         save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws, nbytes = _ws(L, Fr, C, P, dev)
-            rc = getattr(L, "rk_bn_relu_forward_" + _SFX[x.dtype])(
+            # counter_ptr: address of the module's num_batches_tracked (int64 device scalar), incremented in the launch
+            rc = getattr(L, "rk_bn_relu_forward_counted_" + _SFX[x.dtype])(
                 x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var),
                 save_mean.data_ptr(), save_invstd.data_ptr(), y.data_ptr(), Fr, C, P, float(eps), float(momentum),
-                int(relu), 1, ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
+                int(relu), counter_ptr, ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "rk_bn_relu_forward")
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.relu = relu
@@ -85,7 +86,7 @@ class _BNReLUTrain(torch.autograd.Function):
                 save_invstd.data_ptr(), _ptr(dskip), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, P,
                 int(ctx.relu), ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "rk_bn_relu_backward")
-        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None, None, None
 
 
 def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):
@@ -112,6 +113,24 @@ def _fusable(bn, x):
     )
 
 
+def _count_batch(bn):
+    """nn.BatchNorm2d.forward's bookkeeping (torch/nn/modules/batchnorm.py): (momentum, counter).  `counter` is the
+    num_batches_tracked tensor for the kernel to increment, or None when it was already incremented here (momentum=None:
+    the cumulative average needs the new count on the host) or is not tracked."""
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    counter = None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        nbt = bn.num_batches_tracked
+        if bn.momentum is None:
+            nbt.add_(1)
+            momentum = 1.0 / float(nbt)
+        elif nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1:
+            counter = nbt
+        else:
+            nbt.add_(1)
+    return momentum, counter
+
+
 def bn_relu_skip(bn, x):
     """(`relu(bn(x))`, x) for a block whose input also feeds an identity shortcut.  On the fused training path the
     second element is an autograd alias of x whose gradient is added inside the BN d(x) kernel (one elementwise pass
@@ -119,14 +138,10 @@ def bn_relu_skip(bn, x):
     if (_fusable(bn, x) and (bn.training or (bn.running_mean is None and bn.running_var is None))
             and torch.is_grad_enabled() and x.requires_grad):
         x = x.contiguous()
-        momentum = 0.0 if bn.momentum is None else bn.momentum
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-            if bn.momentum is None:
-                momentum = 1.0 / float(bn.num_batches_tracked)
+        momentum, counter = _count_batch(bn)
         rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
         rv = bn.running_var if (bn.training and bn.track_running_stats) else None
-        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, True, True)
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, True, True, _ptr(counter))
     return bn_relu(bn, x), x
 
 
@@ -138,15 +153,10 @@ def bn_relu(bn, x, relu=True):
     use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
     x = x.contiguous()
     if use_batch_stats:
-        # nn.BatchNorm2d.forward's bookkeeping (torch/nn/modules/batchnorm.py): count the batch, pick the factor
-        momentum = 0.0 if bn.momentum is None else bn.momentum
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-            if bn.momentum is None:
-                momentum = 1.0 / float(bn.num_batches_tracked)
+        momentum, counter = _count_batch(bn)
         rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
         rv = bn.running_var if (bn.training and bn.track_running_stats) else None
-        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu)
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, False, _ptr(counter))
     if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
         y = bn(x)                                  # frozen-statistics fine-tuning: stock kernels
         return F.relu(y, inplace=True) if relu else y

@@ -18,7 +18,7 @@ def declared_symbols():
     names = {n for n in names if not n.endswith("_")}
     for macro, templ in (("RK_DECL_2D", ["rk2d_forward_%s", "rk2d_backward_%s"]),
                          ("RK_DECL_TAP", ["rk_tshift3_forward_%s", "rk_tshift3_backward_%s"]),
-                         ("RK_DECL_BN", ["rk_bn_relu_forward_%s", "rk_bn_relu_backward_%s"]),
+                         ("RK_DECL_BN", ["rk_bn_relu_forward_%s", "rk_bn_relu_forward_counted_%s", "rk_bn_relu_backward_%s"]),
                          ("RK_DECL_SE", ["rk_se_squeeze_%s", "rk_se_scale_%s", "rk_se_scale_backward_%s"])):
         for sfx in re.findall(macro + r"\((\w+)[,)]", text):
             if sfx != "SFX":
