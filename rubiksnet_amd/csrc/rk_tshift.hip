@@ -9,7 +9,9 @@
 // lane per access when H*W allows.  Backward does the same walk over (gy, x) producing gx
 // and the [C,3] tap gradients through wave-shuffle -> LDS -> per-(n,c) partial -> fixed-order
 // fp64 finalize (no atomics).
+#include <type_traits>
 #include "rk_common.hpp"
+#include "rk_dma.hpp"
 
 using namespace rk;
 
@@ -81,14 +83,28 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
     }
 }
 
-// partials part[c][3][P], P = n_batch
-template <typename T, int VEC>
+// partials part[c][3][P], P = n_batch.  FUSED (fp32 partials): they are published as {value, tag} granules and the C
+// extra blocks at the end of the grid sum them into gtaps (rk_dma.hpp: the row-sum inside the launch).
+template <typename T, int VEC, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const typename Compute<T>::type* __restrict__ taps,
                                                              T* __restrict__ gx,
-                                                             typename Compute<T>::type* __restrict__ part, DimsT d) {
+                                                             typename Compute<T>::type* __restrict__ part, DimsT d,
+                                                             dma::Fin fin, typename Compute<T>::type* __restrict__ gtaps) {
     using CT = typename Compute<T>::type;
     __shared__ CT red[3][kBlock / kWave];
+    if constexpr (FUSED) {
+        if ((int)blockIdx.x >= fin.producers) {
+            if (threadIdx.x < kWave) {
+                const int cf = (int)blockIdx.x - fin.producers;
+                double s[3];
+                const bool ok = dma::fin_collect<3>(fin, cf, d.NB, s);
+                if (threadIdx.x == 0)
+                    for (int k = 0; k < 3; ++k) gtaps[cf * 3 + k] = ok ? (CT)s[k] : (CT)__uint_as_float(0x7fc00000u);
+            }
+            return;
+        }
+    }
     int n, c, e;
     const bool valid = my_column(d, n, c, e);
     CT a0 = 0, a1 = 0, a2 = 0;
@@ -131,10 +147,16 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
     a1 = group_sum(a1, d.E, red[1]);
     a2 = group_sum(a2, d.E, red[2]);
     if (valid && e == 0) {
-        CT* o = part + (size_t)c * 3 * d.NB + n;
-        o[0] = a0;
-        o[d.NB] = a1;
-        o[2 * d.NB] = a2;
+        const size_t at = (size_t)c * 3 * d.NB + n;
+        if constexpr (FUSED) {
+            dma::fin_publish(fin, at, (float)a0);
+            dma::fin_publish(fin, at + d.NB, (float)a1);
+            dma::fin_publish(fin, at + 2 * d.NB, (float)a2);
+        } else {
+            part[at] = a0;
+            part[at + d.NB] = a1;
+            part[at + 2 * d.NB] = a2;
+        }
     }
 }
 
@@ -241,9 +263,19 @@ int bwd_launch(const T* gy, const T* x, const typename Compute<T>::type* taps, T
     using CT = typename Compute<T>::type;
     DimsT d;
     if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
-    hipLaunchKernelGGL((k_tshift3_backward<T, VEC>), dim3(gridT(d)), dim3(kBlock), 0, stream, gy, x, taps, gx,
-                       (CT*)ws, d);
-    hipLaunchKernelGGL((k_tshift3_finalize<CT>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gtaps, d.NB);
+    if constexpr (std::is_same<CT, float>::value) {
+        dma::Fin fin;
+        fin.gran = reinterpret_cast<unsigned long long*>(ws);
+        fin.tag = dma::next_launch_tag();
+        fin.producers = (int)gridT(d);
+        hipLaunchKernelGGL((k_tshift3_backward<T, VEC, true>), dim3(gridT(d) + C), dim3(kBlock), 0, stream, gy, x, taps, gx,
+                           (CT*)ws, d, fin, gtaps);
+    } else {
+        dma::Fin fin{nullptr, 0u, 0};
+        hipLaunchKernelGGL((k_tshift3_backward<T, VEC, false>), dim3(gridT(d)), dim3(kBlock), 0, stream, gy, x, taps, gx,
+                           (CT*)ws, d, fin, gtaps);
+        hipLaunchKernelGGL((k_tshift3_finalize<CT>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gtaps, d.NB);
+    }
     return launch_status();
 }
 
