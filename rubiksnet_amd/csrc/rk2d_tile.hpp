@@ -1,8 +1,8 @@
 // rk2d_tile.hpp -- RubiksShift2D on 14x14 planes (stride 1 / pad 0; fp32, f16, bf16): the 35 layer-3 blocks of the
 // -aq networks ([256,288,14,14] per GPU for Large-AQ), which the column kernels of rk2d_column.hpp
 // run at 0.8-1.8 TB/s.  Same idea as rk3d_tile.hpp: the planes of consecutive channels of one frame are contiguous,
-// so the unit is a TILE = 2 consecutive channels x one plane (fp32: 2 x 784 B = 98 aligned 16-byte pieces, 16-bit:
-// 2 x 392 B = 49), LDS-DMA'd RAW (global_load_lds_dwordx4 nt, counted vmcnt) by the WAVE that owns it; a
+// so the unit is a TILE = one plane of one channel in fp32 (784 B = 49 aligned 16-byte pieces) and of 2 consecutive
+// channels for the 16-bit types (2 x 392 B = 49 pieces), LDS-DMA'd RAW (global_load_lds_dwordx4 nt, counted vmcnt) by the WAVE that owns it; a
 // workgroup is 4 independent waves and there is no workgroup barrier.  A wave owns (channel group, group of FG
 // frames) and walks its frames through a ring of R slots; the shift is per channel, so all tap addresses are
 // computed ONCE per wave, relative to a slot, a tap outside the plane pointing at the slot's zero word.
@@ -27,7 +27,7 @@ using g2d::Dims2;
 template <typename T, int H_, int W_> struct Geo {
     static constexpr int H = H_, W = W_, HW = H_ * W_;
     static constexpr int ES = (int)sizeof(T);
-    static constexpr int GC = 2;                                  // channels per tile (4 for the 16-bit types: 236 VGPRs)
+    static constexpr int GC = ES == 4 ? 1 : 2;                    // channels per tile (16-bit: 2 x 392 B is the smallest whole number of 16-byte pieces)
     static constexpr int PAIRS = HW / 2;
     static constexpr int RC = (PAIRS + kWave - 1) / kWave;        // rounds per channel
     static constexpr int ROUNDS = GC * RC;
