@@ -366,12 +366,12 @@ __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // Host side.
 // false = shape not handled here (stride / padding / W % 4 / RK_SHIFT_KERNELS)
-inline bool make_fdims(FDims& f, const Dims2& d, int frames_per_group) {
+inline bool make_fdims(FDims& f, const Dims2& d, int frames_per_group, bool backward = false) {
     const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
     if (!s1p0 || d.W % 4 != 0 || d.W < 4 || !streaming_kernels_on()) return false;
     BDims& b = f.b;
     b.N = 1; b.T = d.N; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
-    if (!choose_bands(b)) return false;
+    if (!choose_bands(b, backward)) return false;      // (backward: two-round bands, rk_dma.hpp)
     f.frames = d.N;
     f.FG = frames_per_group < d.N ? frames_per_group : d.N;
     f.ngroups = (d.N + f.FG - 1) / f.FG;
@@ -402,7 +402,7 @@ inline bool launch_interp2(const float* src, const float* shift, float* dst, con
 // partials per channel the fused backward writes for this shape (0 = shape not handled here)
 inline int backward2_partials(const Dims2& d, int frames_per_group) {
     FDims f;
-    return make_fdims(f, d, frames_per_group) ? f.ngroups * f.b.nbands : 0;
+    return make_fdims(f, d, frames_per_group, true) ? f.ngroups * f.b.nbands : 0;
 }
 
 // d(x) + d(shift) (row-sum + K9 inside the launch: ws holds granules [C][2][P]); false = not handled here
@@ -410,7 +410,7 @@ inline bool launch_backward2(const float* gy, const float* x, const float* shift
                              int normalize, const Dims2& d, hipStream_t stream) {
     constexpr int DG = 1, DX = 1;
     FDims f;
-    if (!make_fdims(f, d, kFramesF32) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
+    if (!make_fdims(f, d, kFramesF32, true) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
     const size_t lds = bwd_ring_bytes(f.b, DG, DX);
     if (lds > 64 * 1024) return false;
     Fin2<float> fin;

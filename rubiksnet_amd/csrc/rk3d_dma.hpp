@@ -418,11 +418,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 // ---------------------------------------------------------------------------------------------
 // Host side: launchers.
 // false = shape not handled by the DMA kernels
-inline bool make_bdims(BDims& b, const Dims3& d) {
+inline bool make_bdims(BDims& b, const Dims3& d, bool backward = false) {
     const bool s1p0 = d.sT == 1 && d.sH == 1 && d.sW == 1 && d.pT == 0 && d.pH == 0 && d.pW == 0;
     if (!s1p0 || d.W % 4 != 0 || d.W < 4 || !streaming_kernels_on()) return false;
     b.N = d.N; b.T = d.T; b.C = d.C; b.H = d.H; b.W = d.W; b.W4 = d.W / 4;
-    return choose_bands(b);
+    return choose_bands(b, backward);
 }
 
 template <bool NEGATE, int D>
@@ -468,7 +468,7 @@ inline void launch_bwd_d(const float* x, const float* shift, const float* gy, fl
 inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
                       const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
     BDims b;
-    if (!make_bdims(b, d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
+    if (!make_bdims(b, d, true) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
     if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return 0;
     Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);

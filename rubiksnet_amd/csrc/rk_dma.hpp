@@ -268,7 +268,21 @@ inline int rounds_for(int cells) { return (cells + kBlock - 1) / kBlock; }
 
 // Equal bands with (BH + 1) * W4 <= 1024 cells and the same number of rounds on the tap side and on the
 // output side (so rounds 0..ROUNDS-2 are full).  Needs b.H and b.W4; false = no such banding.
-inline bool choose_bands(BDims& b) {
+// two_rounds: prefer the fewest bands of at most 2 rounds (512 cells) that are still >= 6 KB of a plane -- for the
+// fused backward kernels, whose 4-round form holds 168 VGPRs (3 workgroups per CU): 56x56 in two 28-row bands is
+// 116 VGPRs, 4 workgroups per CU and twice the workgroups, 115.0 -> 112.3 us on [32,8,64,56,56] although each band
+// re-reads one halo row of gy (+1.2 % bytes); the forward kernels are faster on whole planes (68 vs 76 us).
+inline bool choose_bands(BDims& b, bool two_rounds = false) {
+    if (two_rounds) {
+        for (int nb = 1; nb <= b.H; ++nb) {
+            if (b.H % nb) continue;
+            const int bh = b.H / nb, co = bh * b.W4, ci = (bh + 1) * b.W4;
+            if (co * 16 < 6144) break;                               // bands below ~6 KB collapse (pattern probe)
+            if (ci > 2 * kBlock || rounds_for(co) != rounds_for(ci)) continue;
+            b.nbands = nb; b.BH = bh;
+            return true;
+        }
+    }
     for (int nb = 1; nb <= b.H; ++nb) {
         if (b.H % nb) continue;
         const int bh = b.H / nb, co = bh * b.W4, ci = (bh + 1) * b.W4;
