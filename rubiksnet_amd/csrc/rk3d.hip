@@ -91,6 +91,10 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
     if constexpr (std::is_same<T, float>::value) {
         // quantize: d(x) is a plane translation; d(shift) does not depend on quantize (K2 takes the fractional
         // shift, rubiks.cpp:324-358), so it comes from the streaming backward without its d(x) half
+        if (quantize && gx && gshift && !P_out) {                       // both gradients, one launch (rk3d_dma.hpp QUANT)
+            if (dma3d::launch_bwd(x, shift, gy, gx, gshift, (float*)ws, d, normalize_grad, t_factor, stream, true))
+                return launch_status();
+        }
         if (quantize && gx && xlate3d::launch<true>(gy, shift, gx, d, stream)) {
             if (!gshift) return launch_status();
             gx = nullptr;

@@ -176,7 +176,11 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
 // channel instead of the per-element path on one workgroup per column.  The walk loop sits INSIDE each tap-offset
 // copy: around the switch over the copies the compiler hoists the set-up of all four out of it (256 VGPRs).
 
-template <int ROUNDS, bool WRITE_GX, int DG, int DX, int OFF>
+// QUANT (quantize = True): d(x) is the single nearest tap -- plane fl'T or fl'T + 1, row a or b, column m or m + 1 by
+// "remainder >= 0.5" (rubiks3d_kernels.cu:819 ff. with the rounding of :76-93) -- which the walk already has at hand
+// (the tap cells of the current plane, the previous plane's choice in Qprev); d(shift) is unchanged (K2 takes the
+// fractional shift whatever quantize says).
+template <int ROUNDS, bool WRITE_GX, int DG, int DX, int OFF, bool QUANT = false>
 __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
                                                   float* __restrict__ op, float4* ring, const BDims& d,
                                                   const Band& b, const Frac<float>& fT, const Frac<float>& fH,
@@ -194,6 +198,7 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
 
     const float rT = fT.r, rH = fH.r, rW = fW.r;
     const float uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
+    const bool selT = !(rT < 0.5f), selH = !(rH < 0.5f), selW = !(rW < 0.5f);     // QUANT: wave-uniform
     const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(gring));
     const unsigned xaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(xring));
     const unsigned gslot_bytes = (unsigned)gslot_f4 * 16u, xslot_bytes = (unsigned)xslot_f4 * 16u;
@@ -274,15 +279,28 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
             sW = fmaf(col[m] - col[m + 1], mx, sW);
         }
         if (WRITE_GX) {
+            float nv[4];                                          // QUANT: the nearest tap of THIS plane
+            if (QUANT) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float va = selW ? tap<OFF>(qa0, qa1, m + 1) : tap<OFF>(qa0, qa1, m);
+                    const float vb = selW ? tap<OFF>(qb0, qb1, m + 1) : tap<OFF>(qb0, qb1, m);
+                    nv[m] = selH ? vb : va;
+                }
+            }
             if (store) {
                 float4 o;
-                o.x = uT * Qprev[i].x + rT * q[0];
-                o.y = uT * Qprev[i].y + rT * q[1];
-                o.z = uT * Qprev[i].z + rT * q[2];
-                o.w = uT * Qprev[i].w + rT * q[3];
+                if (QUANT) {
+                    o = selT ? make_float4(nv[0], nv[1], nv[2], nv[3]) : Qprev[i];
+                } else {
+                    o.x = uT * Qprev[i].x + rT * q[0];
+                    o.y = uT * Qprev[i].y + rT * q[1];
+                    o.z = uT * Qprev[i].z + rT * q[2];
+                    o.w = uT * Qprev[i].w + rT * q[3];
+                }
                 stream_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off0 + 4096 * i), o);
             }
-            Qprev[i] = make_float4(q[0], q[1], q[2], q[3]);
+            Qprev[i] = QUANT ? make_float4(nv[0], nv[1], nv[2], nv[3]) : make_float4(q[0], q[1], q[2], q[3]);
         }
     };
 
@@ -353,7 +371,7 @@ __device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, in
 }
 
 // (forcing <= 128 VGPRs with __launch_bounds__(256, 4) on an earlier version spilled and ran 13% slower)
-template <int ROUNDS, bool WRITE_GX, int DG, int DX, bool FUSED>
+template <int ROUNDS, bool WRITE_GX, int DG, int DX, bool FUSED, bool QUANT = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k3d_dma_backward(const float* __restrict__ x,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gy,
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         if (band == 0) {
             if (WRITE_GX)
                 for (int t = 0; t < d.T; ++t)
-                    backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+                    backward_input_plane<float, QUANT>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
             for (int to = 0; to < d.T; ++to)
                 shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
         }
@@ -390,10 +408,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         const Band b = make_band(d, band, fH.fl);
         const int off = ((fW.fl % 4) + 4) % 4;
         switch (off) {   // wave-uniform; one specialised copy of the loop per tap offset
-            case 0: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 0>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
-            case 1: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 1>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
-            case 2: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 2>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
-            default: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 3>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 0: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 0, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 1: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 1, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 2: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 2, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            default: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 3, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
         }
     }
 
@@ -448,16 +466,16 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
     return true;
 }
 
-template <bool WRITE_GX, int DG, int DX, bool FUSED>
+template <bool WRITE_GX, int DG, int DX, bool FUSED, bool QUANT = false>
 inline void launch_bwd_d(const float* x, const float* shift, const float* gy, float* gx, float* ws, const BDims& b,
                          const Dims3& d, const Fin3& fin, hipStream_t stream) {
     const size_t lds = bwd_ring_bytes(b, DG, DX);
     const dim3 grid((unsigned)(b.N * b.C * b.nbands + (FUSED ? b.C : 0))), block(kBlock);
     switch (rounds_of(b)) {
-        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
-        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
-        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
-        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX, FUSED>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
     }
 }
 
@@ -465,8 +483,9 @@ inline void launch_bwd_d(const float* x, const float* shift, const float* gy, fl
 // memory system, not latency, bounds it).  gshift != nullptr: row-sum + K5 fused into the launch (ws holds 8-byte
 // granules [C][3][P]); gshift == nullptr: plain float partials ws[C][3][P] for a separate finalize (two-phase API).
 // Returns P (0 = not handled here).
+// quant: quantize = True (only the fused one-call form with both gradients is built for it)
 inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
-                      const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
+                      const Dims3& d, int normalize, float t_factor, hipStream_t stream, bool quant = false) {
     BDims b;
     if (!make_bdims(b, d, true) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
     if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return 0;
@@ -477,7 +496,10 @@ inline int launch_bwd(const float* x, const float* shift, const float* gy, float
     fin.gshift = gshift;
     fin.normalize = normalize;
     fin.t_factor = t_factor;
-    if (gshift) {
+    if (quant) {
+        if (!(gshift && gx)) return 0;
+        launch_bwd_d<true, 1, 1, true, true>(x, shift, gy, gx, ws, b, d, fin, stream);
+    } else if (gshift) {
         if (gx) launch_bwd_d<true, 1, 1, true>(x, shift, gy, gx, ws, b, d, fin, stream);
         else launch_bwd_d<false, 1, 1, true>(x, shift, gy, gx, ws, b, d, fin, stream);
     } else {

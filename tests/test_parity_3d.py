@@ -92,8 +92,8 @@ def test_shift_grad_matches_fp64_oracle(oracle, cfg, kind, dtype):
 @pytest.mark.parametrize("kind", ["generic", "wide", "half"])
 def test_quantize_backward_both_halves(oracle, cfg, kind):
     """quantize=True backward: d(x) is the nearest-position translation (bit-exact), d(shift) is K2 on the fractional
-    shift (the reference's K2 takes no quantize flag).  On the streaming shapes the two halves come from different
-    kernels (rk3d_translate.hpp + the d(shift)-only streaming backward)."""
+    shift (the reference's K2 takes no quantize flag).  On the streaming shapes both come from one launch (the QUANT
+    walk of rk3d_dma.hpp); d(x) alone is rk3d_translate.hpp, d(shift) alone the shift-only streaming backward."""
     N, T, C, H, W, s, p = cfg
     rng = np.random.default_rng(seed_of(cfg, kind, "q"))
     x = rand(rng, (N, T, C, H, W), np.float32)
@@ -324,6 +324,16 @@ def test_tsm_init_integer_temporal_shifts(oracle, hw, wide):
     from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward
     _, gs_only = rubiks_shift_3d_backward(to_dev(gy), to_dev(x), to_dev(shift), 1, 0, False, need_x_grad=False)
     np.testing.assert_allclose(to_np(gs_only), raw_ref, rtol=0, atol=1e-5 * scale)
+    # quantize=True on the same shifts (one launch for both gradients: the QUANT walk of rk3d_dma.hpp), plus
+    # remainders of exactly 0.5 -- the rounding boundary of the nearest tap
+    shift[1, ::3] = np.floor(shift[1, ::3]) + 0.5
+    shift[2, 1::4] = np.floor(shift[2, 1::4]) + 0.5
+    gxq_ref, _ = oracle.rk3d_backward(gy, x, shift, 1, 0, quantize=True)
+    _, _, rawq_ref = oracle.rk3d_backward(gy.astype(np.float64), x.astype(np.float64), shift.astype(np.float64),
+                                          normalize_grad=False, quantize=True, return_raw=True)
+    gxq, gsq = _run_bwd(gy, x, shift, 1, 0, True, normalize=False)
+    np.testing.assert_array_equal(gxq, gxq_ref)
+    np.testing.assert_allclose(gsq, rawq_ref, rtol=0, atol=1e-5 * max(1.0, float(np.abs(rawq_ref).max())))
 
 
 def test_empty_batch_and_single_element(oracle):
