@@ -430,6 +430,259 @@ __global__ __launch_bounds__(kBlock) void k3d_tile_backward(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// 14x14, one channel per wave, ring of 3 with the step loop unrolled by the ring: the slot of a step is a compile-time
+// constant, so a tap is ONE ds_read_b32 with the slot in its immediate offset (no per-tap address add), the counted
+// waits are literals (VMEM order of a step: [fetch of plane k+2][4 stores]; "plane k has landed" leaves the 4 + 4
+// stores of steps k-2, k-1 and the fetch of plane k+1 outstanding) and the ring bookkeeping (modulo, fifo of issue
+// counts, the 33-way s_waitcnt switch) is gone: ~75 instead of ~140 instructions per step and wave.
+namespace t14 {
+constexpr int kHW = 196, kTileB = 784, kStride = 800, kZ = 784, kRC = 4, kPieces = 49;
+template <int I> struct IC { static constexpr int value = I; };
+
+__device__ __forceinline__ float uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <int OFFB> __device__ __forceinline__ float lds_at(unsigned a) {
+    return *(__attribute__((address_space(3))) const float*)(size_t)(a + (unsigned)OFFB);
+}
+// absolute LDS byte addresses (slot 0) of the 4 taps of element p = lane + 64 * rc; outside the plane -> the zero word
+__device__ __forceinline__ void taps(unsigned (&rel)[4], unsigned slot0, int flH, int flW, int lane, int rc) {
+    const int p = lane + kWave * rc;
+    const bool live = p < kHW;
+    const int pc = live ? p : 0;
+    const int h = pc / 14, w = pc - h * 14;
+    const int h0 = h + flH, w0 = w + flW;
+    const bool mh0 = (unsigned)h0 < 14u, mh1 = (unsigned)(h0 + 1) < 14u;
+    const bool mw0 = (unsigned)w0 < 14u, mw1 = (unsigned)(w0 + 1) < 14u;
+    const unsigned a = slot0 + (unsigned)((h0 * 14 + w0) * 4), Z = slot0 + kZ;
+    rel[0] = live && mh0 && mw0 ? a : Z;
+    rel[1] = live && mh0 && mw1 ? a + 4u : Z;
+    rel[2] = live && mh1 && mw0 ? a + 56u : Z;
+    rel[3] = live && mh1 && mw1 ? a + 60u : Z;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NEGATE>
+__global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restrict__ src, const float* __restrict__ shift,
+                                                            float* __restrict__ dst, TDims d) {
+    constexpr int R = 3;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (kWave - 1);
+    const long long id = (long long)blockIdx.x * (kBlock / kWave) + wave;
+    if (id >= (long long)d.N * d.C) return;                          // whole wave; no barriers in this kernel
+    const int n = (int)(id / d.C), c = (int)(id - (long long)n * d.C);
+    char* ring = lds_raw + wave * (R * kStride);
+    if (lane < R) *reinterpret_cast<float4*>(ring + lane * kStride + kZ) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
+    if (NEGATE) { s0 = -s0; s1 = -s1; s2 = -s2; }
+    const Frac<float> fT = split_shift(s0), fH = split_shift(s1), fW = split_shift(s2);
+    const float rT = uni(fT.r), rH = uni(fH.r), rW = uni(fW.r), uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
+    const int f0 = __builtin_amdgcn_readfirstlane(fT.fl);
+    const int flH = __builtin_amdgcn_readfirstlane(fH.fl), flW = __builtin_amdgcn_readfirstlane(fW.fl);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
+    const long long tstride = (long long)d.C * kHW;
+    const float* col = src + ((size_t)n * d.T * d.C + c) * kHW;       // plane t = 0 of my column
+    float* optr = dst + ((size_t)n * d.T * d.C + c) * kHW + lane;     // my element of the next output plane
+
+    unsigned rel[kRC][4];
+#pragma unroll
+    for (int rc = 0; rc < kRC; ++rc) taps(rel[rc], ring_addr, flH, flW, lane, rc);
+
+    int tf = f0;                                                     // next source plane to fetch ...
+    const float* pf = col + (long long)f0 * tstride;                 // ... and where it lives (never dereferenced out of range)
+    auto fetch = [&](int slot) {
+        if ((unsigned)tf < (unsigned)d.T) {
+            if (lane < kPieces) dma16s<true>(pf, lane * 16, ring_addr + slot * kStride);
+        } else if (lane < kPieces) {
+            *reinterpret_cast<float4*>(ring + slot * kStride + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        ++tf; pf += tstride;
+    };
+    const f32x2 uW2 = {uW, uW}, rW2 = {rW, rW}, uH2 = {uH, uH}, rH2 = {rH, rH}, uT2 = {uT, uT}, rT2 = {rT, rT};
+    f32x2 Bprev[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // VMEM order of a step j: [fetch of plane j+2][4 stores, j >= 1]; "plane k has landed" leaves outstanding the fetch of
+    // plane k+1 (when it was in range: tf - 1 now) and the stores of steps k-2, k-1 (LATE: k >= 3).
+    auto step = [&](auto SC, auto LATE, bool store) {
+        constexpr int S = decltype(SC)::value;
+        constexpr int W0 = decltype(LATE)::value ? 8 : 0;
+        if ((unsigned)(tf - 1) < (unsigned)d.T) wait_vmcnt(W0 + 1); else wait_vmcnt(W0);
+        fetch((S + 2) % 3);                                          // into the slot of plane k-1
+        f32x2 q[2][4];                                               // rounds (0,1) and (2,3) as packed pairs
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q[h][j].x = lds_at<S * kStride>(rel[2 * h][j]);
+                q[h][j].y = lds_at<S * kStride>(rel[2 * h + 1][j]);
+            }
+        // all 16 reads in flight before the first multiply (the scheduler otherwise serialises them round by round)
+        asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[1][0]), "+v"(q[1][1]),
+                          "+v"(q[1][2]), "+v"(q[1][3]));
+        f32x2 Bnew[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            Bnew[h] = uH2 * (q[h][0] * uW2 + q[h][1] * rW2) + rH2 * (q[h][2] * uW2 + q[h][3] * rW2);
+        if (store) {
+            const f32x2 o0 = uT2 * Bprev[0] + rT2 * Bnew[0], o1 = uT2 * Bprev[1] + rT2 * Bnew[1];
+            __builtin_nontemporal_store(o0.x, optr);
+            __builtin_nontemporal_store(o0.y, optr + 64);
+            __builtin_nontemporal_store(o1.x, optr + 128);
+            if (lane < kHW - 192) __builtin_nontemporal_store(o1.y, optr + 192);
+            optr += tstride;
+        }
+        Bprev[0] = Bnew[0]; Bprev[1] = Bnew[1];
+    };
+    fetch(0);
+    fetch(1);
+    int k = 0;
+    do {                                                             // steps 0..2: nothing but fetches outstanding
+        step(IC<0>{}, IC<0>{}, false); if (++k > d.T) break;
+        step(IC<1>{}, IC<0>{}, true); if (++k > d.T) break;
+        step(IC<2>{}, IC<0>{}, true); if (++k > d.T) break;
+        for (;;) {
+            step(IC<0>{}, IC<1>{}, true); if (++k > d.T) break;
+            step(IC<1>{}, IC<1>{}, true); if (++k > d.T) break;
+            step(IC<2>{}, IC<1>{}, true); if (++k > d.T) break;
+        }
+    } while (false);
+}
+
+// Backward of the same shape: d(x) (WRITE_GX) + the d(shift) partial of (n, c), adjoint form (rk3d_dma.hpp) -- gy taps
+// with the negated shift from a ring of 3, my own x elements from a second ring of 3 (x[k-1] stays in registers).
+// VMEM order of a step j: [gy plane j+2][x plane j+2][4 stores, j >= 1 with WRITE_GX].
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <bool WRITE_GX, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __restrict__ x, const float* __restrict__ shift,
+                                                              const float* __restrict__ gy, float* __restrict__ gx,
+                                                              float* __restrict__ part, TDims d, Dims3 gd, dma3d::Fin3 fin) {
+    if (FUSED && (int)blockIdx.x >= fin.f.producers) {                // row-sum + K5 inside the launch (rk_dma.hpp)
+        if (threadIdx.x < kWave) dma3d::finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (kWave - 1);
+    const long long id = (long long)blockIdx.x * (kBlock / kWave) + wave;
+    if (id >= (long long)d.N * d.C) return;
+    const int n = (int)(id / d.C), c = (int)(id - (long long)n * d.C);
+    const size_t at = (size_t)c * 3 * d.N + n;
+    auto publish = [&](float a, float b, float w) {
+        if (lane == 0) {
+            if (FUSED) { fin_publish(fin.f, at, a); fin_publish(fin.f, at + d.N, b); fin_publish(fin.f, at + 2 * d.N, w); }
+            else { part[at] = a; part[at + d.N] = b; part[at + 2 * d.N] = w; }
+        }
+    };
+    const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
+    const bool integer = split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0;
+    if (__builtin_amdgcn_readfirstlane((int)integer)) {
+        // exactly-integer component: the reference's per-element formulation (lowered-index quirk :290-298)
+        float aT = 0.f, aH = 0.f, aW = 0.f;
+        for (int t = 0; t < d.T; ++t) {
+            if (WRITE_GX) backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, lane, kWave);
+            shift_grad_plane<float>(x, shift, gy, gd, n, t, c, lane, kWave, aT, aH, aW);
+        }
+        publish(wave_sum(aT), wave_sum(aH), wave_sum(aW));
+        return;
+    }
+    char* ring = lds_raw + wave * (6 * kStride);                      // slots 0..2: gy, 3..5: x
+    if (lane < 6) *reinterpret_cast<float4*>(ring + lane * kStride + kZ) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r' of the negated shift
+    const float rT = uni(fT.r), rH = uni(fH.r), rW = uni(fW.r), uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
+    const int f0 = __builtin_amdgcn_readfirstlane(fT.fl);
+    const int flH = __builtin_amdgcn_readfirstlane(fH.fl), flW = __builtin_amdgcn_readfirstlane(fW.fl);
+    const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring)), xaddr = gaddr + 3 * kStride;
+    const long long tstride = (long long)d.C * kHW;
+    const size_t col0 = ((size_t)n * d.T * d.C + c) * kHW;
+    float* optr = WRITE_GX ? gx + col0 + lane : nullptr;
+
+    unsigned rel[kRC][4], xoff[kRC];
+#pragma unroll
+    for (int rc = 0; rc < kRC; ++rc) {
+        taps(rel[rc], gaddr, flH, flW, lane, rc);
+        const int p = lane + kWave * rc;
+        xoff[rc] = xaddr + (p < kHW ? (unsigned)(p * 4) : (unsigned)kZ);
+    }
+    int tg = f0, tx = 0;                                             // next gy / x planes to fetch
+    const float* pg = gy + col0 + (long long)f0 * tstride;           // (never dereferenced out of range)
+    const float* px = x + col0;
+    auto fetch1 = [&](const float* p, int t, unsigned base, int slot) {
+        if ((unsigned)t < (unsigned)d.T) {
+            if (lane < kPieces) dma16s<true>(p, lane * 16, base + slot * kStride);
+        } else if (lane < kPieces) {
+            *reinterpret_cast<float4*>(ring + (base - gaddr) + slot * kStride + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto fetch = [&](int slot) {
+        fetch1(pg, tg, gaddr, slot); ++tg; pg += tstride;
+        fetch1(px, tx, xaddr, slot); ++tx; px += tstride;
+    };
+    const f32x2 uW2 = {uW, uW}, rW2 = {rW, rW}, uH2 = {uH, uH}, rH2 = {rH, rH}, uT2 = {uT, uT}, rT2 = {rT, rT};
+    f32x2 Qprev[2] = {{0.f, 0.f}, {0.f, 0.f}}, xa[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    f32x2 aT = {0.f, 0.f}, aH = {0.f, 0.f}, aW = {0.f, 0.f};
+    auto step = [&](auto SC, auto LATE, bool store) {
+        constexpr int S = decltype(SC)::value;
+        constexpr int W0 = (decltype(LATE)::value && WRITE_GX) ? 8 : 0;
+        // outstanding behind "gy plane k and x plane k have landed": the fetches of step k-1 that were VMEM ops
+        // (planes tg - 1, tx - 1 now) and the stores of steps k-2, k-1 (LATE: k >= 3)
+        const int more = ((unsigned)(tg - 1) < (unsigned)d.T ? 1 : 0) + ((unsigned)(tx - 1) < (unsigned)d.T ? 1 : 0);
+        if (more == 2) wait_vmcnt(W0 + 2); else if (more == 1) wait_vmcnt(W0 + 1); else wait_vmcnt(W0);
+        f32x2 q[2][4], xb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xb[h].x = lds_at<S * kStride>(xoff[2 * h]);
+            xb[h].y = lds_at<S * kStride>(xoff[2 * h + 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q[h][j].x = lds_at<S * kStride>(rel[2 * h][j]);
+                q[h][j].y = lds_at<S * kStride>(rel[2 * h + 1][j]);
+            }
+        }
+        fetch((S + 2) % 3);                                          // into the slots of planes k-1 (their reads are done)
+        asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[1][0]), "+v"(q[1][1]),
+                          "+v"(q[1][2]), "+v"(q[1][3]), "+v"(xb[0]), "+v"(xb[1]));
+        f32x2 Qnew[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 la = q[h][0] * uW2 + q[h][1] * rW2, lb = q[h][2] * uW2 + q[h][3] * rW2;
+            Qnew[h] = uH2 * la + rH2 * lb;                           // the reference's tree, contraction off
+            const f32x2 c0 = fma2(uH2, q[h][0], rH2 * q[h][2]), c1 = fma2(uH2, q[h][1], rH2 * q[h][3]);
+            const f32x2 dx = xb[h] - xa[h], mx = fma2(uT2, xb[h], rT2 * xa[h]);
+            aT = fma2(Qnew[h], dx, aT);
+            aH = fma2(la - lb, mx, aH);
+            aW = fma2(c0 - c1, mx, aW);
+            xa[h] = xb[h];
+        }
+        if (WRITE_GX) {
+            if (store) {
+                const f32x2 o0 = uT2 * Qprev[0] + rT2 * Qnew[0], o1 = uT2 * Qprev[1] + rT2 * Qnew[1];
+                __builtin_nontemporal_store(o0.x, optr);
+                __builtin_nontemporal_store(o0.y, optr + 64);
+                __builtin_nontemporal_store(o1.x, optr + 128);
+                if (lane < kHW - 192) __builtin_nontemporal_store(o1.y, optr + 192);
+                optr += tstride;
+            }
+            Qprev[0] = Qnew[0]; Qprev[1] = Qnew[1];
+        }
+    };
+    fetch(0);
+    fetch(1);
+    int k = 0;
+    do {
+        step(IC<0>{}, IC<0>{}, false); if (++k > d.T) break;
+        step(IC<1>{}, IC<0>{}, true); if (++k > d.T) break;
+        step(IC<2>{}, IC<0>{}, true); if (++k > d.T) break;
+        for (;;) {
+            step(IC<0>{}, IC<1>{}, true); if (++k > d.T) break;
+            step(IC<1>{}, IC<1>{}, true); if (++k > d.T) break;
+            step(IC<2>{}, IC<1>{}, true); if (++k > d.T) break;
+        }
+    } while (false);
+    publish(wave_sum(aT.x + aT.y), wave_sum(aH.x + aH.y), wave_sum(aW.x + aW.y));
+}
+}  // namespace t14
+
+// ---------------------------------------------------------------------------------------------
 // Host side.
 template <typename G> inline bool tile_dims(TDims& t, const Dims3& d) {
     if (d.H != G::H || d.W != G::W) return false;
@@ -458,7 +711,12 @@ inline bool launch_interp_hw(const float* src, const float* shift, float* dst, c
 template <bool NEGATE>
 inline bool launch_interp(const float* src, const float* shift, float* dst, const Dims3& d, hipStream_t stream) {
     if (!s1p0(d) || !aligned16(src) || !aligned16(dst)) return false;
-    return launch_interp_hw<14, 14, 1, 3, NEGATE>(src, shift, dst, d, stream);
+    if (d.H != 14 || d.W != 14) return false;
+    TDims t{d.N, d.T, d.C, d.C};
+    const unsigned grid = (unsigned)(((long long)d.N * d.C + 3) / 4);
+    hipLaunchKernelGGL((t14::k3d_tile14_interp<NEGATE>), dim3(grid), dim3(kBlock), 4 * 3 * t14::kStride, stream, src, shift,
+                       dst, t);
+    return true;
 }
 
 template <int H, int W, int GCO, int RING>
@@ -488,7 +746,23 @@ inline int launch_bwd_hw(const float* x, const float* shift, const float* gy, fl
 inline int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
                       const Dims3& d, int normalize, float t_factor, hipStream_t stream) {
     if (!s1p0(d) || !aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
-    return launch_bwd_hw<14, 14, 1, 3>(x, shift, gy, gx, gshift, ws, d, normalize, t_factor, stream);
+    if (d.H != 14 || d.W != 14) return 0;
+    TDims t{d.N, d.T, d.C, d.C};
+    const unsigned producers = (unsigned)(((long long)d.N * d.C + 3) / 4);
+    const size_t lds = 4 * 6 * t14::kStride;
+    dma3d::Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = (int)producers;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+#define RK_T14_BWD(GX, FU) hipLaunchKernelGGL((t14::k3d_tile14_backward<GX, FU>), dim3(producers + (FU ? d.C : 0)), \
+                                              dim3(kBlock), lds, stream, x, shift, gy, gx, ws, t, d, fin)
+    if (gshift) { if (gx) RK_T14_BWD(true, true); else RK_T14_BWD(false, true); }
+    else { if (gx) RK_T14_BWD(true, false); else RK_T14_BWD(false, false); }
+#undef RK_T14_BWD
+    return d.N;
 }
 
 }  // namespace tile3d
