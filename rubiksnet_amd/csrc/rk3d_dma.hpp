@@ -383,7 +383,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[3][kBlock / kWave];
-    const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
+    // Two bands per plane: workgroups b and b + 8 (same XCD under the round-robin dispatch, launched together) take the two
+    // bands of one plane, so the halo row of gy they share is an L2 hit for the second one instead of a second HBM read.
+    int bid = (int)blockIdx.x;
+    const int nprod = FUSED ? fin.f.producers : (int)gridDim.x;
+    if (d.nbands == 2 && (bid | 15) < nprod) bid = (bid & ~15) + ((bid & 7) << 1) + ((bid >> 3) & 1);
+    const int band = bid % d.nbands, col = bid / d.nbands;
     const int c = col % d.C, n = col / d.C;
     const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
     float accT = 0.f, accH = 0.f, accW = 0.f;
