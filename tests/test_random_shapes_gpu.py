@@ -6,6 +6,8 @@ counts and ragged last rounds of the LDS-DMA kernels, W % 8 for the raw 16-bit p
 channel-group counts, stride-2 band splits, integer temporal shifts -- with the same bars: y and d(x) bit-exact,
 d(shift) within 1e-5 * scale of the fp64 oracle (16-bit storage: the fp32 oracle on the widened inputs, rounded once).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -39,7 +41,7 @@ def _draw3(rng):
     return N, T, C, H, W, s, p
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RK_SWEEP_3D", "120"))))   # RK_SWEEP_3D=2000: soak run
 def test_random_3d(oracle, seed):
     from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_backward, rubiks_shift_3d_forward
 
