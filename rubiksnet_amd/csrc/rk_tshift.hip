@@ -38,6 +38,18 @@ __device__ __forceinline__ void store_pack(T* p, const typename Compute<T>::type
     *reinterpret_cast<Pack<T, VEC>*>(p) = q;
 }
 
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_raw(const T* p) { return *reinterpret_cast<const Pack<T, VEC>*>(p); }
+template <typename T, int VEC>
+__device__ __forceinline__ void unpack(const Pack<T, VEC>& q, typename Compute<T>::type (&o)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = ld(&q.v[k]);
+}
+// n_segment = 8 (every network of the reference): the whole column of a thread -- 8 packs per tensor -- is requested
+// before the first one is used.  With one plane of look-ahead a wave had 0.5-1 KB in flight and the kernels sat at
+// 3-4 TB/s, latency-bound; the arithmetic (and its order) is that of the generic walk below.
+constexpr int kSeg = 8;
+
 __device__ __forceinline__ bool my_column(const DimsT& d, int& n, int& c, int& e) {
     const int sub = threadIdx.x >> d.logE;
     e = threadIdx.x & (d.E - 1);
@@ -65,6 +77,28 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
         CT prev[VEC], cur[VEC], nxt[VEC], out[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) prev[k] = 0;
+        if (d.S == kSeg) {
+            Pack<T, VEC> raw[kSeg];
+#pragma unroll
+            for (int t = 0; t < kSeg; ++t) raw[t] = load_raw<T, VEC>(xp + (size_t)t * tstride);
+            unpack<T, VEC>(raw[0], cur);
+#pragma unroll
+            for (int t = 0; t < kSeg; ++t) {
+                if (t + 1 < kSeg) unpack<T, VEC>(raw[t + 1 < kSeg ? t + 1 : 0], nxt);
+                else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) nxt[k] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    out[k] = s0 * prev[k] + s1 * cur[k] + s2 * nxt[k];
+                    prev[k] = cur[k];
+                    cur[k] = nxt[k];
+                }
+                store_pack<T, VEC>(yp + (size_t)t * tstride, out);
+            }
+            continue;
+        }
         load_pack<T, VEC>(xp, cur);
         for (int t = 0; t < d.S; ++t) {
             if (t + 1 < d.S) load_pack<T, VEC>(xp + (size_t)(t + 1) * tstride, nxt);
@@ -119,6 +153,37 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
             CT xprev[VEC], xcur[VEC], xnxt[VEC], gprev[VEC], gcur[VEC], gnxt[VEC], out[VEC];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { xprev[k] = 0; gprev[k] = 0; }
+            if (d.S == kSeg) {
+                Pack<T, VEC> xr[kSeg], gr[kSeg];
+#pragma unroll
+                for (int t = 0; t < kSeg; ++t) {
+                    gr[t] = load_raw<T, VEC>(gp + (size_t)t * tstride);
+                    xr[t] = load_raw<T, VEC>(xp + (size_t)t * tstride);
+                }
+                unpack<T, VEC>(xr[0], xcur);
+                unpack<T, VEC>(gr[0], gcur);
+#pragma unroll
+                for (int t = 0; t < kSeg; ++t) {
+                    if (t + 1 < kSeg) {
+                        unpack<T, VEC>(xr[t + 1 < kSeg ? t + 1 : 0], xnxt);
+                        unpack<T, VEC>(gr[t + 1 < kSeg ? t + 1 : 0], gnxt);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) { xnxt[k] = 0; gnxt[k] = 0; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        out[k] = s0 * gnxt[k] + s1 * gcur[k] + s2 * gprev[k];
+                        a0 += gcur[k] * xprev[k];
+                        a1 += gcur[k] * xcur[k];
+                        a2 += gcur[k] * xnxt[k];
+                        xprev[k] = xcur[k]; xcur[k] = xnxt[k];
+                        gprev[k] = gcur[k]; gcur[k] = gnxt[k];
+                    }
+                    store_pack<T, VEC>(op + (size_t)t * tstride, out);
+                }
+                continue;
+            }
             load_pack<T, VEC>(xp, xcur);
             load_pack<T, VEC>(gp, gcur);
             for (int t = 0; t < d.S; ++t) {
