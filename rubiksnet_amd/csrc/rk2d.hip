@@ -75,7 +75,9 @@ int forward2(const void* x_, const void* shift_, void* y_, int N, int C, int H, 
     }
     // small planes only: on larger ones the per-plane kernel below is the faster forward (stride-2 56x56 ->
     // 28x28: 85 vs 102 us); the column BACKWARD wins everywhere (fused, single-tap)
-    if (col2d::supported(quantize) && d.Ho * d.Wo <= kBlock) {
+    // (16-bit strided layers: the column kernel with 8-byte stores also wins on the large planes, 108 -> 84 us at
+    // [256,108,56,56] bf16; in fp32 it loses there, 84 -> 97 us)
+    if (col2d::supported(quantize) && (d.Ho * d.Wo <= kBlock || (sizeof(T) == 2 && (d.sH > 1 || d.sW > 1)))) {
         col2d::launch_forward<T>(x, shift, y, d, stream);
         return launch_status();
     }

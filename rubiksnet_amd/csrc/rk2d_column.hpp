@@ -48,8 +48,12 @@ __device__ __forceinline__ Col2Id my_column2(const C2Dims& cd, int& e) {
     return r;
 }
 
+template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
+
 // ------------------------------------------------------------------------------------ forward
-template <typename T, int kM>
+// VEC (kM == 4, output planes of a multiple of 4 elements, aligned y): a thread owns 4 CONSECUTIVE outputs and stores
+// them as one 8- / 16-byte access; frames are taken in batches, every tap of a batch requested before the first is used.
+template <typename T, int kM, bool VEC = false>
 __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict__ x, const T* __restrict__ shift,
                                                              T* __restrict__ y, C2Dims cd) {
     using CT = typename Compute<T>::type;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
     unsigned mask[kM];
 #pragma unroll
     for (int m = 0; m < kM; ++m) {
-        const int i = id.chunk * cd.E * kM + m * cd.E + e;
+        const int i = VEC ? id.chunk * cd.E * kM + e * kM + m : id.chunk * cd.E * kM + m * cd.E + e;
         oidx[m] = i < HWo ? i : -1;
         const int ii = i < HWo ? i : 0;
         const int ho = ii / d.Wo, wo = ii - ho * d.Wo;
@@ -81,24 +85,60 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
         mask[m] = (i < HWo) ? ((mh0 && mw0 ? 1u : 0u) | (mh0 && mw1 ? 2u : 0u) | (mh1 && mw0 ? 4u : 0u) |
                                (mh1 && mw1 ? 8u : 0u)) : 0u;
     }
-    for (int k = 0; k < nf; ++k) {
+    struct Frame { CT q[kM][4]; };
+    auto load_frame = [&](int k, Frame& f) {                              // addresses clamped into the plane, masked at use
         const T* p = xc + (size_t)k * fsi;
-        T* out = yc + (size_t)k * fso;
 #pragma unroll
         for (int m = 0; m < kM; ++m) {
-            CT p00 = 0, p01 = 0, p10 = 0, p11 = 0;
             const unsigned mk = mask[m];
-            if (mk & 1u) p00 = ld(p + o00[m]);
-            if (mk & 2u) p01 = ld(p + o00[m] + 1);
-            if (mk & 4u) p10 = ld(p + o00[m] + d.W);
-            if (mk & 8u) p11 = ld(p + o00[m] + d.W + 1);
-            if (oidx[m] >= 0) st(out + oidx[m], interp2d(p00, p01, p10, p11, rH, rW));
+            f.q[m][0] = ld(p + ((mk & 1u) ? o00[m] : 0));
+            f.q[m][1] = ld(p + ((mk & 2u) ? o00[m] + 1 : 0));
+            f.q[m][2] = ld(p + ((mk & 4u) ? o00[m] + d.W : 0));
+            f.q[m][3] = ld(p + ((mk & 8u) ? o00[m] + d.W + 1 : 0));
         }
+    };
+    auto use_frame = [&](int k, const Frame& f) {
+        T* out = yc + (size_t)k * fso;
+        Quad<T> oq;
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+            const unsigned mk = mask[m];
+            const CT p00 = (mk & 1u) ? f.q[m][0] : (CT)0, p01 = (mk & 2u) ? f.q[m][1] : (CT)0;
+            const CT p10 = (mk & 4u) ? f.q[m][2] : (CT)0, p11 = (mk & 8u) ? f.q[m][3] : (CT)0;
+            const CT v = interp2d(p00, p01, p10, p11, rH, rW);
+            if constexpr (VEC) st(&oq.v[m & 3], v);
+            else if (oidx[m] >= 0) st(out + oidx[m], v);
+        }
+        if constexpr (VEC) {
+            if (oidx[0] >= 0) *reinterpret_cast<Quad<T>*>(out + oidx[0]) = oq;
+        }
+    };
+    constexpr int kRegsPerFrame = kM * 4 * (int)(sizeof(CT) / 4);
+    constexpr int kBatch = kRegsPerFrame * 4 <= 40 ? 4 : (kRegsPerFrame * 2 <= 32 ? 2 : 1);
+    int k = 0;
+    if constexpr (kBatch > 1) {
+        for (; k + kBatch - 1 < nf; k += kBatch) {
+            Frame fr[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) load_frame(k + j, fr[j]);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) use_frame(k + j, fr[j]);
+        }
+    }
+    for (; k < nf; ++k) {
+        Frame f;
+        load_frame(k, f);
+        use_frame(k, f);
     }
 }
 
 // ----------------------------------------------------------------------------------- backward
-template <typename T, int kM, bool SINGLE>
+// VEC (kM == 4, input planes of a multiple of 4 elements, 16-byte aligned tensors): a thread owns 4 CONSECUTIVE input
+// elements, so x and gx -- the two big streams of a strided layer's backward -- move as one 8-byte (16-bit types) or
+// 16-byte (fp32) access per thread and frame instead of four 2- / 4-byte ones; the gy taps stay scalar (L1-served).
+// Frames are taken four at a time, every load of the four requested before the first is used.  Same arithmetic per
+// element, bit-identical.
+template <typename T, int kM, bool SINGLE, bool VEC = false>
 __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restrict__ gy, const T* __restrict__ x,
                                                               const T* __restrict__ shift, T* __restrict__ gx,
                                                               typename Compute<T>::type* __restrict__ part,
@@ -134,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
             CT wj[kM], wk[kM], sj[kM], sk[kM];                                 // SINGLE: the tap's weights and signs
 #pragma unroll
             for (int m = 0; m < kM; ++m) {
-                const int i = id.chunk * cd.E * kM + m * cd.E + e;
+                const int i = VEC ? id.chunk * cd.E * kM + e * kM + m : id.chunk * cd.E * kM + m * cd.E + e;
                 const bool live = i < HW;
                 iidx[m] = live ? i : -1;
                 const int ii = live ? i : 0;
@@ -154,35 +194,72 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                 }
             }
             CT sH = 0, sW = 0;
-            for (int k = 0; k < nf; ++k) {
+            constexpr int NTAP = SINGLE ? 1 : 4;
+            struct Frame { CT xv[kM]; CT q[kM][NTAP]; };
+            auto load_frame = [&](int k, Frame& f) {                          // addresses clamped into the plane, values masked at use
                 const T* p = gc + (size_t)k * fso;
                 const T* xp = xc + (size_t)k * fsi;
+                if constexpr (VEC) {
+                    const Quad<T> xq = *reinterpret_cast<const Quad<T>*>(xp + (iidx[0] >= 0 ? iidx[0] : 0));
+#pragma unroll
+                    for (int m = 0; m < kM; ++m) f.xv[m] = ld(&xq.v[m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < kM; ++m) f.xv[m] = ld(xp + (iidx[m] >= 0 ? iidx[m] : 0));
+                }
+#pragma unroll
+                for (int m = 0; m < kM; ++m)
+#pragma unroll
+                    for (int j = 0; j < NTAP; ++j) f.q[m][j] = ld(p + (tap[m][j] >= 0 ? tap[m][j] : 0));
+            };
+            auto use_frame = [&](int k, const Frame& f) {
                 T* out = oc + (size_t)k * fsi;
+                Quad<T> oq;
 #pragma unroll
                 for (int m = 0; m < kM; ++m) {
-                    const CT xv = iidx[m] >= 0 ? ld(xp + iidx[m]) : (CT)0;
+                    const CT xv = iidx[m] >= 0 ? f.xv[m] : (CT)0;
                     CT Q, QH, QW;
                     if (SINGLE) {
-                        CT v = 0;
-                        if (tap[m][0] >= 0) v = ld(p + tap[m][0]);
+                        const CT v = tap[m][0] >= 0 ? f.q[m][0] : (CT)0;
                         const CT vj = v * wj[m];
                         Q = vj * wk[m];                                      // = K8's interp2d with three zero taps
                         QH = sj[m] * (v * wk[m]);
                         QW = sk[m] * vj;
                     } else {
-                        CT q00 = 0, q01 = 0, q10 = 0, q11 = 0;
-                        if (tap[m][0] >= 0) q00 = ld(p + tap[m][0]);
-                        if (tap[m][SINGLE ? 0 : 1] >= 0) q01 = ld(p + tap[m][SINGLE ? 0 : 1]);
-                        if (tap[m][SINGLE ? 0 : 2] >= 0) q10 = ld(p + tap[m][SINGLE ? 0 : 2]);
-                        if (tap[m][SINGLE ? 0 : 3] >= 0) q11 = ld(p + tap[m][SINGLE ? 0 : 3]);
+                        const CT q00 = tap[m][0] >= 0 ? f.q[m][0] : (CT)0;
+                        const CT q01 = tap[m][NTAP > 1 ? 1 : 0] >= 0 ? f.q[m][NTAP > 1 ? 1 : 0] : (CT)0;
+                        const CT q10 = tap[m][NTAP > 1 ? 2 : 0] >= 0 ? f.q[m][NTAP > 1 ? 2 : 0] : (CT)0;
+                        const CT q11 = tap[m][NTAP > 1 ? 3 : 0] >= 0 ? f.q[m][NTAP > 1 ? 3 : 0] : (CT)0;
                         Q = interp2d(q00, q01, q10, q11, rH, rW);            // K8's tree, contraction off
                         QH = (q00 * (1 - rW) + q01 * rW) - (q10 * (1 - rW) + q11 * rW);
                         QW = ((1 - rH) * q00 + rH * q10) - ((1 - rH) * q01 + rH * q11);
                     }
                     sH += QH * xv;
                     sW += QW * xv;
-                    if (iidx[m] >= 0) st(out + iidx[m], Q);
+                    if constexpr (VEC) st(&oq.v[m & 3], Q);
+                    else if (iidx[m] >= 0) st(out + iidx[m], Q);
                 }
+                if constexpr (VEC) {
+                    if (iidx[0] >= 0) *reinterpret_cast<Quad<T>*>(out + iidx[0]) = oq;
+                }
+            };
+            // frames in flight at once: as many (<= 4) as fit ~40 registers of loaded values
+            constexpr int kRegsPerFrame = kM * (1 + NTAP) * (int)(sizeof(CT) / 4);
+            constexpr int kBatch = kRegsPerFrame * 4 <= 40 ? 4 : (kRegsPerFrame * 2 <= 32 ? 2 : 1);
+            int k = 0;
+            if constexpr (kBatch > 1) {
+                for (; k + kBatch - 1 < nf; k += kBatch) {
+                    Frame fr[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) load_frame(k + j, fr[j]);
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) use_frame(k + j, fr[j]);
+                }
+            }
+            for (; k < nf; ++k) {
+                Frame f;
+                load_frame(k, f);
+                use_frame(k, f);
             }
             accH = sH; accW = sW;
         }
@@ -227,8 +304,11 @@ inline unsigned grid_of(const C2Dims& cd) {
 template <typename T>
 inline void launch_forward(const T* x, const T* shift, T* y, const Dims2& d, hipStream_t stream) {
     const C2Dims cd = make_c2dims(d, d.Ho * d.Wo);
+    const bool vec = cd.M == 4 && (d.Ho * d.Wo) % 4 == 0 && ((uintptr_t)y & 15) == 0;
     if (cd.M == 1)
         hipLaunchKernelGGL((k2d_forward_column<T, 1>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+    else if (vec)
+        hipLaunchKernelGGL((k2d_forward_column<T, 4, true>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
     else
         hipLaunchKernelGGL((k2d_forward_column<T, 4>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
 }
@@ -244,10 +324,12 @@ inline int launch_backward(const T* gy, const T* x, const T* shift, T* gx, typen
                            const Dims2& d, hipStream_t stream) {
     const C2Dims cd = make_c2dims(d, d.H * d.W);
     const bool single = d.sH >= 2 && d.sW >= 2;
-#define RK_C2_BWD(MM, SG) hipLaunchKernelGGL((k2d_backward_column<T, MM, SG>), dim3(grid_of(cd)), dim3(kBlock), 0, \
-                                             stream, gy, x, shift, gx, ws, cd)
-    if (cd.M == 1) { if (single) RK_C2_BWD(1, true); else RK_C2_BWD(1, false); }
-    else { if (single) RK_C2_BWD(4, true); else RK_C2_BWD(4, false); }
+    const bool vec = cd.M == 4 && (d.H * d.W) % 4 == 0 && (((uintptr_t)x | (uintptr_t)gx) & 15) == 0;
+#define RK_C2_BWD(MM, SG, VC) hipLaunchKernelGGL((k2d_backward_column<T, MM, SG, VC>), dim3(grid_of(cd)), dim3(kBlock), 0, \
+                                                 stream, gy, x, shift, gx, ws, cd)
+    if (cd.M == 1) { if (single) RK_C2_BWD(1, true, false); else RK_C2_BWD(1, false, false); }
+    else if (vec) { if (single) RK_C2_BWD(4, true, true); else RK_C2_BWD(4, false, true); }
+    else { if (single) RK_C2_BWD(4, true, false); else RK_C2_BWD(4, false, false); }
 #undef RK_C2_BWD
     return cd.ngroups * cd.nchunks;
 }
