@@ -158,6 +158,41 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
     const T* col = src + ((size_t)it.f0 * d.C + it.c0) * G::HW;
     char* ocol = reinterpret_cast<char*>(dst + ((size_t)it.f0 * d.C + it.c0) * G::HW);
 
+    if (it.nf == R) {
+        // A full group (the usual case): frame k lives in slot k, so the ring needs no bookkeeping -- all R frames are
+        // requested up front, the slot is an immediate offset of the LDS reads and the counted waits are literals (VMEM
+        // order: R fetches, then ROUNDS stores per step).  The kernels are bound by instructions issued per step
+        // (rk3d_tile.hpp), and this path drops the per-tap address add and the runtime s_waitcnt switch.
+#pragma unroll
+        for (int r = 0; r < G::ROUNDS; ++r)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) rel[r][j] += ring_addr;
+#pragma unroll
+        for (int k = 0; k < R; ++k) dma_tile<G>(col + (size_t)k * fstride, ring_addr + k * G::STRIDE, lane);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            wait_vmcnt((R - 1 - k) * G::PIECE_ROUNDS + k * G::ROUNDS);
+            char* out = ocol + (size_t)k * fstride * G::ES;
+            float o0[G::ROUNDS], o1[G::ROUNDS];
+#pragma unroll
+            for (int g = 0; g < G::GC; ++g)
+#pragma unroll
+                for (int rc = 0; rc < G::RC; ++rc) {
+                    const int r = g * G::RC + rc;
+                    const unsigned sb = (unsigned)(k * G::STRIDE);
+                    const float a0 = LdsElem<T>::get(rel[r][0] + sb), a1 = LdsElem<T>::get(rel[r][1] + sb),
+                                a2 = LdsElem<T>::get(rel[r][2] + sb);
+                    const float b0 = LdsElem<T>::get(rel[r][3] + sb), b1 = LdsElem<T>::get(rel[r][4] + sb),
+                                b2 = LdsElem<T>::get(rel[r][5] + sb);
+                    o0[r] = a0 * uH[g] * uW[g] + a1 * uH[g] * rW[g] + b0 * rH[g] * uW[g] + b1 * rH[g] * rW[g];   // interp2d
+                    o1[r] = a1 * uH[g] * uW[g] + a2 * uH[g] * rW[g] + b1 * rH[g] * uW[g] + b2 * rH[g] * rW[g];
+                }
+#pragma unroll
+            for (int r = 0; r < G::ROUNDS; ++r)
+                if (ooff[r] >= 0) store_pair<T>(out + ooff[r], o0[r], o1[r]);
+        }
+        return;
+    }
     int issued = 0;
     auto fetch = [&](int k) {                                        // frame k -> slot k % R
         if (k < it.nf) issued += dma_tile<G>(col + (size_t)k * fstride, ring_addr + (k % R) * G::STRIDE, lane);
@@ -373,7 +408,7 @@ inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d,
 template <typename T>
 inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* gshift, void* ws, int normalize,
                              const Dims2& d, hipStream_t stream) {
-    constexpr int R = 3;
+    constexpr int R = 3;       // (the forward's static full-group schedule was tried here too: 245 VGPRs, 26 -> 31 us)
     using G = Geo<T, 14, 14>;
     TDims2 t;
     if (!make_tdims<T, 14, 14>(t, d) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
