@@ -213,28 +213,29 @@ class RubiksNetBackbone(nn.Module):
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))
 
-    # parameter-group rules: (group name, module types, which of the module's parameters, lr_mult key, decay_mult)
-    _POLICY = (
-        ("weight", (nn.Conv2d, nn.Conv3d, nn.Linear), "weight", 1),
-        ("bias", (nn.Conv2d, nn.Conv3d, nn.Linear), "bias", 0),
-        ("bn", (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d), None, 0),
-        ("shift", (RubiksShift2D, RubiksShiftBase), None, 0),
+    # module family -> {group name: which of the module's own parameters}; the first matching family wins
+    _FAMILIES = (
+        ((nn.Conv2d, nn.Conv3d, nn.Linear), {"weight": "weight", "bias": "bias"}),
+        ((nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d), {"bn": None}),
+        ((RubiksShift2D, RubiksShiftBase), {"shift": None}),
     )
+    _DECAY = {"weight": 1, "bias": 0, "bn": 0, "shift": 0}
 
     def get_optim_policy(self, shift_lr_mult=0.01):
         """Optimizer parameter groups `weight` / `bias` / `bn` / `shift` with `lr_mult` and `decay_mult` entries
         (same groups, order and multipliers as the reference, backbone.py:202-235): only weights decay, shifts
-        train at `shift_lr_mult` of the base rate.  A parameter-owning leaf module of an unknown type is an error."""
-        groups = {name: [] for name, *_ in self._POLICY}
+        train at `shift_lr_mult` of the base rate.  A module belongs to the FIRST family it matches (so no
+        parameter can land in two groups); a parameter-owning LEAF module of an unknown type is an error, a
+        container of an unknown type is walked through, exactly as the reference does."""
+        groups = {name: [] for name in self._DECAY}
         for module in self.modules():
-            own = dict(module.named_parameters(recurse=False))
-            if not own:
+            family = next((rule for types, rule in self._FAMILIES if isinstance(module, types)), None)
+            if family is None:
+                if not module._modules and next(module.parameters(), None) is not None:
+                    raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(module)))
                 continue
-            rules = [r for r in self._POLICY if isinstance(module, r[1])]
-            if not rules:
-                raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(module)))
-            for name, _, attr, _ in rules:
-                groups[name] += [p for k, p in own.items() if attr is None or k == attr]
-        lr_mult = {"shift": shift_lr_mult}
-        return [{"params": groups[name], "lr_mult": lr_mult.get(name, 1), "decay_mult": decay, "name": name}
-                for name, _, _, decay in self._POLICY]
+            own = dict(module.named_parameters(recurse=False))
+            for group, attr in family.items():
+                groups[group] += [p for k, p in own.items() if attr is None or k == attr]
+        return [{"params": groups[name], "lr_mult": shift_lr_mult if name == "shift" else 1, "decay_mult": decay,
+                 "name": name} for name, decay in self._DECAY.items()]

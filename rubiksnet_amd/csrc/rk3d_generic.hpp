@@ -2,7 +2,7 @@
 //
 // These cover every case the reference's K1-K5 cover (cuda_src/rubiks3d_kernels.cu:15-960):
 // arbitrary stride / padding, quantize, exactly-integer shifts (the d(shift) lowering
-// quirk), fp32 and fp64.  The LDS-tiled streaming kernels in rk3d_stream.hpp take over
+// quirk), fp32 and fp64.  The LDS-fed streaming kernels (rk3d_plane / rk3d_dma / rk3d_tile / rk3d_stride2 .hpp) take over
 // for the shapes that dominate the networks; these stay as the complete fallback and as
 // the per-channel slow path for integer shifts.
 //

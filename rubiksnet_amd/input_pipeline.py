@@ -20,6 +20,22 @@ __all__ = ["stacked_u8_to_clips", "SyntheticClipLoader", "IMAGENET_MEAN", "IMAGE
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # RubiksNet.input_mean / input_std (models.py:106-107)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
+_MEAN_STD = {}      # (device, mean, std) -> fp32 [2, 3] on the device
+
+
+def _mean_std_on(dev, mean, std):
+    """The [2, 3] fp32 table (mean row, std row) on `dev`, built ONCE per (device, mean, std).
+
+    `torch.tensor(..., device=dev)` is a blocking copy from pageable host memory: the host waits for the current
+    stream to drain.  Done per call it serialised the loader's side stream behind the compute stream (round-2
+    advisor finding); cached, only the first call with a given table pays for it."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
+           tuple(float(v) for v in mean), tuple(float(v) for v in std))
+    table = _MEAN_STD.get(key)
+    if table is None:
+        table = torch.tensor([key[2], key[3]], dtype=torch.float32, device=dev)    # fp32(mean), fp32(std) as sub_/div_ use
+        _MEAN_STD[key] = table
+    return table
 
 
 def stacked_u8_to_clips(stacked, n_frames, mean=IMAGENET_MEAN, std=IMAGENET_STD, dtype=torch.float32, out=None):
@@ -37,7 +53,7 @@ def stacked_u8_to_clips(stacked, n_frames, mean=IMAGENET_MEAN, std=IMAGENET_STD,
         out = torch.empty(B, CS, H, W, dtype=dtype, device=dev)
     elif tuple(out.shape) not in ((B, CS, H, W), (B, n_frames, 3, H, W)) or out.dtype != dtype or not out.is_contiguous():
         raise RuntimeError("out must be a contiguous %s tensor [B, 3T, H, W]" % dtype)
-    ms = torch.tensor([list(mean), list(std)], dtype=torch.float32, device=dev)    # fp32(mean), fp32(std) as sub_/div_ use
+    ms = _mean_std_on(dev, mean, std)
     if B:
         with torch.cuda.device(dev):
             rc = getattr(_native.lib(), "rk_clip_u8_to_chw_" + _SFX[dtype])(
@@ -70,6 +86,7 @@ class SyntheticClipLoader:
         self._ready = [torch.cuda.Event() for _ in range(depth)]
         self._consumed = [torch.cuda.Event() for _ in range(depth)]
         self._stream = torch.cuda.Stream(self.device)
+        _mean_std_on(self.device, IMAGENET_MEAN, IMAGENET_STD)      # the one blocking upload happens here, not per batch
         self._i = 0
         for slot in range(depth):
             self._consumed[slot].record(torch.cuda.current_stream(self.device))

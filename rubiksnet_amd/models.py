@@ -91,21 +91,27 @@ class RubiksNet(nn.Module):
         return self.input_size * 256 // 224
 
 
+def _temporal_config(spatial, fill):
+    """(H, W) setting of a 2-D shift -> (T, H, W) with `fill` on the time axis."""
+    return (fill, *make_tuple(spatial, 2))
+
+
 class _Rubiks3DWrap(nn.Module):
-    """[N*T, C, H, W] <-> [N, T, C, H, W] views around a RubiksShift3D (models.py:128-145)."""
+    """Frame-batched adapter: the backbone works on [N*T, C, H, W]; the 3-D shift wants clips
+    [N, T, C, H, W].  Both are views of the same memory (models.py:128-145).  Takes the place of a
+    block's 2-D shift `as3`, with that layer's channel count and spatial stride / padding, never
+    striding or padding time; the 3-D shifts start from their own U(-1, 1) draw.  State-dict key:
+    `as3.rubiks3d.shift`."""
 
     def __init__(self, rubiks2d, n_segment=8):
         super().__init__()
-        assert isinstance(rubiks2d, RubiksShift2D)
-        self.rubiks3d = RubiksShift3D(
-            rubiks2d.num_channels,
-            stride=(1, *make_tuple(rubiks2d.stride, 2)),
-            padding=(0, *make_tuple(rubiks2d.padding, 2)),
-        )
+        if not isinstance(rubiks2d, RubiksShift2D):
+            raise AssertionError("expected the block's RubiksShift2D, got %s" % type(rubiks2d).__name__)
         self.n_segment = n_segment
+        self.rubiks3d = RubiksShift3D(rubiks2d.num_channels,
+                                      stride=_temporal_config(rubiks2d.stride, 1),
+                                      padding=_temporal_config(rubiks2d.padding, 0))
 
     def forward(self, x):
-        nt, c, h, w = x.size()
-        out = self.rubiks3d(x.view(nt // self.n_segment, self.n_segment, c, h, w))
-        n, t, c, h, w = out.size()
-        return out.view(n * t, c, h, w)
+        clips = x.unflatten(0, (-1, self.n_segment))          # [N*T, C, H, W] -> [N, T, C, H, W], no copy
+        return self.rubiks3d(clips).flatten(0, 1)

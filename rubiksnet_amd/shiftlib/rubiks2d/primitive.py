@@ -13,7 +13,7 @@ x is [N, C, H, W], shift is [2, C] with rows (H, W); float32 / float64 / float16
 """
 import torch
 
-from rubiksnet_amd import rubiksnet_cuda
+from rubiksnet_amd import _native, rubiksnet_cuda
 from rubiksnet_amd.utils import allocate_output, make_tuple
 
 __all__ = ["rubiks2d", "rubiks2d_forward", "rubiks2d_backward"]
@@ -21,17 +21,14 @@ __all__ = ["rubiks2d", "rubiks2d_forward", "rubiks2d_backward"]
 _DIM = 2
 
 
-def _get_output_dim(orig, stride, padding):
-    return (orig + 2 * padding - 1) // stride + 1      # cuda_src/rubiks.cpp:18
-
-
 def compute_output_shape(x, stride, padding, shift_dim=_DIM):
-    batch, C_in, H_in, W_in = x.size()
-    assert shift_dim == 2, "only the 2-D shift is defined here (rubiks2d/primitive.py:15-27)"
-    strides = make_tuple(stride, shift_dim)
-    paddings = make_tuple(padding, shift_dim)
-    return (batch, C_in, int(_get_output_dim(H_in, strides[0], paddings[0])),
-            int(_get_output_dim(W_in, strides[1], paddings[1])))
+    """[N, C, H, W] -> [N, C, Ho, Wo] with the library's own length rule (`rk_out_len`,
+    cuda_src/rubiks.cpp:18): `(L + 2*pad - 1) // stride + 1`, not the convolution formula."""
+    assert shift_dim == _DIM, "only the 2-D shift is defined here (rubiks2d/primitive.py:15-27)"
+    out_len = _native.lib().rk_out_len
+    moved = [int(out_len(int(length), s, p)) for length, s, p in
+             zip(x.shape[2:], make_tuple(stride, _DIM), make_tuple(padding, _DIM))]
+    return (int(x.shape[0]), int(x.shape[1]), *moved)
 
 
 def rubiks2d_forward(x, shift, stride=1, padding=0, quantize=False, output=None):

@@ -14,8 +14,8 @@ x is [N, T, C, H, W] (NOT NCTHW), shift is [3, C] with rows (T, H, W).
 """
 import torch
 
-from rubiksnet_amd import rubiksnet_cuda
-from rubiksnet_amd.utils import allocate_output
+from rubiksnet_amd import _native, rubiksnet_cuda
+from rubiksnet_amd.utils import allocate_output, make_tuple
 
 __all__ = [
     "rubiks_shift_3d_forward",
@@ -26,36 +26,28 @@ __all__ = [
 _DIM = 3
 
 
-def _make_tuple(elem, repeats):
-    if isinstance(elem, int):
-        return [elem] * repeats
-    assert len(elem) == repeats
-    return [int(x) for x in elem]
-
-
-def _get_output_dim(orig, stride, padding):
-    # cuda_src/rubiks.cpp:166; integer form of rubiks3d/primitive.py:25-26 (float divide + int())
-    return (orig + 2 * padding - 1) // stride + 1
+def _per_axis(value, naxes=_DIM):
+    """One integer per moving axis: a bare int applies to all of them."""
+    return make_tuple(value, naxes)
 
 
 def compute_output_shape(x, stride, padding, shift_dim=_DIM):
-    """Output size of the shift (rubiks3d/primitive.py:29-48); 1D/2D/3D select which dims move."""
-    batch, T_in, C_in, H_in, W_in = x.size()
-    T_out, H_out, W_out = T_in, H_in, W_in
-    strides = _make_tuple(stride, shift_dim)
-    paddings = _make_tuple(padding, shift_dim)
-    if shift_dim == 1:
-        T_out = _get_output_dim(T_in, strides[0], paddings[0])
-    elif shift_dim == 2:
-        H_out = _get_output_dim(H_in, strides[0], paddings[0])
-        W_out = _get_output_dim(W_in, strides[1], paddings[1])
-    elif shift_dim == 3:
-        T_out = _get_output_dim(T_in, strides[0], paddings[0])
-        H_out = _get_output_dim(H_in, strides[1], paddings[1])
-        W_out = _get_output_dim(W_in, strides[2], paddings[2])
-    else:
+    """Shape of the shifted tensor for x [N, T, C, H, W].
+
+    The last `shift_dim` of the three (T, H, W) axes move -- 3: all of them, 2: (H, W), 1: T alone,
+    which is how the reference numbers them (rubiks3d/primitive.py:29-48).  A moving axis of length L
+    comes out `(L + 2*pad - 1) // stride + 1` long: that is `rk_out_len`, the library's own rule
+    (cuda_src/rubiks.cpp:166), so Python and the kernels cannot disagree.
+    """
+    if shift_dim not in (1, 2, 3):
         raise NotImplementedError("only 1D, 2D, 3D shifts supported")
-    return batch, int(T_out), C_in, int(H_out), int(W_out)
+    n, t, c, h, w = (int(v) for v in x.size())
+    lengths = {"t": t, "h": h, "w": w}
+    moving = {1: "t", 2: "hw", 3: "thw"}[shift_dim]
+    out_len = _native.lib().rk_out_len
+    for axis, s, p in zip(moving, _per_axis(stride, shift_dim), _per_axis(padding, shift_dim)):
+        lengths[axis] = int(out_len(lengths[axis], s, p))
+    return n, lengths["t"], c, lengths["h"], lengths["w"]
 
 
 def _pick(x, f32, f64):
@@ -68,8 +60,8 @@ def _pick(x, f32, f64):
 
 def rubiks_shift_3d_forward(x, shift, stride, padding, quantize=False, output=None):
     """Pure forward primitive, no autograd (rubiks3d/primitive.py:54-80)."""
-    strides = _make_tuple(stride, _DIM)
-    paddings = _make_tuple(padding, _DIM)
+    strides = _per_axis(stride)
+    paddings = _per_axis(padding)
     assert x.is_cuda, "rubiks shift only works on CUDA tensors"
     assert x.size(2) == shift.size(1), "x tensor channel dim[2] must match shift channel dim[1]"
     assert x.dtype == shift.dtype, "x and shift must have the same dtype"
@@ -101,8 +93,8 @@ def rubiks_shift_3d_backward(
     `need_x_grad` / `need_shift_grad` are additions: the reference always computes both;
     a skipped half comes back as None.
     """
-    strides = _make_tuple(stride, _DIM)
-    paddings = _make_tuple(padding, _DIM)
+    strides = _per_axis(stride)
+    paddings = _per_axis(padding)
     assert x.is_cuda and upstream_grad.is_cuda, "rubiks shift only works on CUDA tensors"
     func = _pick(x, rubiksnet_cuda.rubiks_shift_3d_backward_float, rubiksnet_cuda.rubiks_shift_3d_backward_double)
     x_grad = allocate_output(x_grad_output, x, x.size(), zero=False) if need_x_grad else None

@@ -210,3 +210,36 @@ def test_switches_are_read_once_into_a_frozen_object(monkeypatch):
     import inspect
     for mod in (fused_bn, pointwise):
         assert "os.environ" not in inspect.getsource(mod)
+
+
+def test_optim_policy_groups_follow_the_reference_rules():
+    """backbone.py:202-235: first matching family wins, only parameter-owning LEAF modules of an unknown type raise."""
+    import torch.nn as nn
+
+    net = RubiksNet("tiny", num_classes=5, num_frames=8, verbose=False).backbone
+    groups = {g["name"]: g for g in net.get_optim_policy(shift_lr_mult=0.02)}
+    assert list(groups) == ["weight", "bias", "bn", "shift"]
+    assert [groups[k]["decay_mult"] for k in groups] == [1, 0, 0, 0]
+    assert groups["shift"]["lr_mult"] == 0.02 and groups["weight"]["lr_mult"] == 1
+    ids = [id(p) for g in groups.values() for p in g["params"]]
+    assert len(ids) == len(set(ids)) == len(list(net.parameters()))          # every parameter exactly once
+    assert all(p.dim() == 2 and p.shape[0] == 3 for p in groups["shift"]["params"])
+
+    class Container(nn.Module):                                              # unknown type, owns a parameter, NOT a leaf
+        def __init__(self):
+            super().__init__()
+            self.scale = nn.Parameter(torch.ones(1))
+            self.inner = nn.Linear(2, 2)
+
+    net.extra = Container()
+    names = {g["name"]: len(g["params"]) for g in net.get_optim_policy()}
+    assert names["weight"] == len(groups["weight"]["params"]) + 1            # walked through; `scale` is ignored
+
+    class Leaf(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.scale = nn.Parameter(torch.ones(1))
+
+    net.extra = Leaf()
+    with pytest.raises(ValueError, match="New atomic module type"):
+        net.get_optim_policy()
