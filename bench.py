@@ -492,14 +492,17 @@ def main():
     except Exception as exc:
         feeder = {"error": repr(exc)}
 
-    cpu = None
-    if env.is_main and not args.no_cpu:      # after every timed GPU leg; the other ranks wait at the final barrier
-        cpu = cpu_baseline()
-    dp.barrier(env)
-
+    # Rank-0-only legs run BEFORE the final barrier: every rank then reaches destroy_process_group() together.  (Round 2
+    # ran the 2-D / secondary legs on rank 0 after the last barrier while ranks 1..N-1 were already tearing the RCCL
+    # communicator down -- untested on RCCL, flagged by the round-2 review.)  The other ranks idle at the barrier.
     traffic, traffic_src = pmc_traffic("backward")
-    rk2d = op2d_bench(env) if env.is_main else None
-    secondary = secondary_points(env) if env.is_main else None
+    rk2d = secondary = tshift = cpu = None
+    if env.is_main:
+        rk2d = op2d_bench(env)
+        secondary = secondary_points(env)
+        if not args.no_cpu:                  # after every timed GPU leg
+            cpu = cpu_baseline()
+    dp.barrier(env)
 
     if env.is_main:
         out = {

@@ -59,6 +59,9 @@ int rk_version(void);                 /* 1000*major + minor */
 const char* rk_error_string(int code);
 int rk_out_len(int in, int stride, int pad); /* rubiks.cpp:14-30, :161-178 */
 int rk_device_count(void);            /* hipGetDeviceCount, 0 when none */
+/* test hook (no reference counterpart): the tag the next backward launch with an in-launch row-sum will stamp its
+ * workspace granules with; lets the parity tests pre-fill a workspace with adversarial near-miss patterns */
+unsigned rk_debug_peek_launch_tag(void);
 
 /* ------------------------------------------------------------------------- 3D
  * Replaces rubiks_shift_3d_forward<T>  (cuda_src/rubiks.cpp:181-253) + functor
@@ -144,6 +147,26 @@ RK_DECL_2D(f64, double)
 RK_DECL_2D(f16, void)
 RK_DECL_2D(bf16, void)
 #undef RK_DECL_2D
+
+/* 16-bit activations next to an fp32 shift table (what torch.autocast hands the operator: bf16 / f16 activations,
+ * fp32 nn.Parameter).  The reference instantiates K6-K9 at ONE scalar type (rubiks2d_kernels.cu:113-114 reads the
+ * shift in the tensor's type), so an autocast caller of it must round the parameter to 16 bits first; these entry
+ * points keep the shift, everything derived from it (floor / remainder, the 1e-7 integer test of :189, the quantize
+ * positions of :117-118) and d(shift) in fp32, exactly as rk2d_*_f32 evaluate them.  Same workspace as rk2d_backward_*. */
+#define RK_DECL_2D_SF32(SFX)                                                                \
+    int rk2d_forward_##SFX##_sf32(const void* x, const float* shift, void* y,              \
+                                  int N, int C, int H, int W,                              \
+                                  int stride_H, int stride_W, int pad_H, int pad_W,        \
+                                  int quantize, rk_stream_t stream);                       \
+    int rk2d_backward_##SFX##_sf32(const void* gy, const void* x, const float* shift,      \
+                                   void* gx, float* gshift,                                \
+                                   int N, int C, int H, int W,                             \
+                                   int stride_H, int stride_W, int pad_H, int pad_W,       \
+                                   int normalize_grad, int enable_shift_grad, int quantize, \
+                                   void* workspace, size_t workspace_bytes, rk_stream_t stream);
+RK_DECL_2D_SF32(f16)
+RK_DECL_2D_SF32(bf16)
+#undef RK_DECL_2D_SF32
 
 size_t rk2d_backward_workspace_bytes(int N, int C, int H, int W,
                                      int stride_H, int stride_W, int pad_H, int pad_W,

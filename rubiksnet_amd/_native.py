@@ -26,6 +26,7 @@ SIGNATURES = {
     "rk_error_string": (ctypes.c_char_p, [_i]),
     "rk_out_len": (_i, [_i, _i, _i]),
     "rk_device_count": (_i, []),
+    "rk_debug_peek_launch_tag": (ctypes.c_uint, []),
     "rk3d_forward_f32": (_i, [_p, _p, _p] + _DIMS3 + [_i, _p]),
     "rk3d_forward_f64": (_i, [_p, _p, _p] + _DIMS3 + [_i, _p]),
     "rk3d_backward_workspace_bytes": (_sz, _DIMS3 + [_i]),
@@ -66,6 +67,9 @@ for _sfx in ("f32", "bf16"):
 for _sfx in ("f32", "f64", "f16", "bf16"):
     SIGNATURES["rk2d_forward_" + _sfx] = (_i, [_p, _p, _p] + _DIMS2 + [_i, _p])
     SIGNATURES["rk2d_backward_" + _sfx] = (_i, [_p] * 5 + _DIMS2 + [_i, _i, _i, _p, _sz, _p])
+    if _sfx in ("f16", "bf16"):          # 16-bit activations, fp32 shift table / d(shift)
+        SIGNATURES["rk2d_forward_%s_sf32" % _sfx] = SIGNATURES["rk2d_forward_" + _sfx]
+        SIGNATURES["rk2d_backward_%s_sf32" % _sfx] = SIGNATURES["rk2d_backward_" + _sfx]
     SIGNATURES["rk_tshift3_forward_" + _sfx] = (_i, [_p, _p, _p, _i, _i, _i, _i, _p])
     SIGNATURES["rk_tshift3_backward_" + _sfx] = (_i, [_p] * 5 + [_i, _i, _i, _i, _p, _sz, _p])
 

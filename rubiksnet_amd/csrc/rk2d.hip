@@ -47,8 +47,8 @@ size_t workspace2(const Dims2& d, size_t elem) {
     P = P > Pr ? P : Pr;
     const int Pt = tile2d::backward2_partials<float>(d);             // (the same count for every storage type)
     P = P > Pt ? P : Pt;
-    // the streaming backwards keep their fp32 partials as 8-byte {value, tag} granules (rk_dma.hpp)
-    return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * (elem < 8 ? 8 : elem);
+    // the streaming backwards keep their fp32 partials as 16-byte granule pairs (rk_dma.hpp: fin_publish)
+    return (size_t)d.C * 2 * (size_t)(P > d.N ? P : d.N) * 16;
 }
 
 unsigned grid2(const Dims2& d) {
@@ -56,10 +56,13 @@ unsigned grid2(const Dims2& d) {
     return (unsigned)(((long long)d.N * d.C + per_block - 1) / per_block);
 }
 
-template <typename T>
+// T: storage type of the activations; S: storage type of the shift table and of d(shift).  S == T is the
+// reference's instantiation (the whole kernel at one scalar type, rubiks2d_kernels.cu:422); S = float next to
+// 16-bit activations keeps the fp32 parameter of an autocast network un-rounded (and returns d(shift) in fp32).
+template <typename T, typename S>
 int forward2(const void* x_, const void* shift_, void* y_, int N, int C, int H, int W, int sH, int sW, int pH,
              int pW, int quantize, rk_stream_t stream_) {
-    const T* x = (const T*)x_; const T* shift = (const T*)shift_; T* y = (T*)y_;
+    const T* x = (const T*)x_; const S* shift = (const S*)shift_; T* y = (T*)y_;
     if (!x || !shift || !y) return RK_ERR_NULL_POINTER;
     Dims2 d;
     if (int rc = make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return rc;
@@ -83,19 +86,19 @@ int forward2(const void* x_, const void* shift_, void* y_, int N, int C, int H, 
     }
     set_group2(d, d.Ho * d.Wo);
     if (quantize)
-        hipLaunchKernelGGL((k2d_forward<T, true>), dim3(grid2(d)), dim3(kBlock), 0, stream, x, shift, y, d);
+        hipLaunchKernelGGL((k2d_forward<T, S, true>), dim3(grid2(d)), dim3(kBlock), 0, stream, x, shift, y, d);
     else
-        hipLaunchKernelGGL((k2d_forward<T, false>), dim3(grid2(d)), dim3(kBlock), 0, stream, x, shift, y, d);
+        hipLaunchKernelGGL((k2d_forward<T, S, false>), dim3(grid2(d)), dim3(kBlock), 0, stream, x, shift, y, d);
     return launch_status();
 }
 
-template <typename T>
+template <typename T, typename S>
 int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, void* gshift_, int N, int C, int H,
               int W, int sH, int sW, int pH, int pW, int normalize_grad, int enable_shift_grad, int quantize,
               void* ws, size_t ws_bytes, rk_stream_t stream_) {
     using CT = typename Compute<T>::type;
-    const T* gy = (const T*)gy_; const T* x = (const T*)x_; const T* shift = (const T*)shift_;
-    T* gx = (T*)gx_; T* gshift = (T*)gshift_;
+    const T* gy = (const T*)gy_; const T* x = (const T*)x_; const S* shift = (const S*)shift_;
+    T* gx = (T*)gx_; S* gshift = (S*)gshift_;
     if (!gy || !shift || !gx) return RK_ERR_NULL_POINTER;
     if (enable_shift_grad && (!x || !gshift)) return RK_ERR_NULL_POINTER;
     Dims2 d;
@@ -134,22 +137,22 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
     }
     if (enable_shift_grad && col2d::supported(quantize)) {                // fused d(x) + d(shift), any stride / H x W
         const int P = col2d::launch_backward<T>(gy, x, shift, gx, (CT*)ws, d, stream);
-        hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(P)), 0, stream, (const CT*)ws, gshift, C, P,
+        hipLaunchKernelGGL((k2d_finalize<T, S>), dim3(C), dim3(finalize_block(P)), 0, stream, (const CT*)ws, gshift, C, P,
                            normalize_grad);
         return launch_status();
     }
     if (enable_shift_grad) {                                              // rubiks.cpp:126-149
         CT* part = (CT*)ws;
         set_group2(d, d.Ho * d.Wo);
-        hipLaunchKernelGGL((k2d_backward_shift<T>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, x, shift, part, d);
-        hipLaunchKernelGGL((k2d_finalize<T>), dim3(C), dim3(finalize_block(N)), 0, stream, (const CT*)part, gshift, C, N,
+        hipLaunchKernelGGL((k2d_backward_shift<T, S>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, x, shift, part, d);
+        hipLaunchKernelGGL((k2d_finalize<T, S>), dim3(C), dim3(finalize_block(N)), 0, stream, (const CT*)part, gshift, C, N,
                            normalize_grad);
     }
     set_group2(d, d.H * d.W);                                             // rubiks.cpp:151-153
     if (quantize)
-        hipLaunchKernelGGL((k2d_backward_input<T, true>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, shift, gx, d);
+        hipLaunchKernelGGL((k2d_backward_input<T, S, true>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, shift, gx, d);
     else
-        hipLaunchKernelGGL((k2d_backward_input<T, false>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, shift, gx, d);
+        hipLaunchKernelGGL((k2d_backward_input<T, S, false>), dim3(grid2(d)), dim3(kBlock), 0, stream, gy, shift, gx, d);
     return launch_status();
 }
 
@@ -166,12 +169,12 @@ size_t rk2d_backward_workspace_bytes(int N, int C, int H, int W, int sH, int sW,
 #define RK_DEF_2D(SFX, TYPE, CTYPE)                                                                              \
     int rk2d_forward_##SFX(const CTYPE* x, const CTYPE* shift, CTYPE* y, int N, int C, int H, int W, int sH,     \
                            int sW, int pH, int pW, int quantize, rk_stream_t stream) {                           \
-        return forward2<TYPE>(x, shift, y, N, C, H, W, sH, sW, pH, pW, quantize, stream);                        \
+        return forward2<TYPE, TYPE>(x, shift, y, N, C, H, W, sH, sW, pH, pW, quantize, stream);                      \
     }                                                                                                            \
     int rk2d_backward_##SFX(const CTYPE* gy, const CTYPE* x, const CTYPE* shift, CTYPE* gx, CTYPE* gshift,       \
                             int N, int C, int H, int W, int sH, int sW, int pH, int pW, int normalize_grad,     \
                             int enable_shift_grad, int quantize, void* ws, size_t ws_bytes, rk_stream_t stream) { \
-        return backward2<TYPE>(gy, x, shift, gx, gshift, N, C, H, W, sH, sW, pH, pW, normalize_grad,             \
+        return backward2<TYPE, TYPE>(gy, x, shift, gx, gshift, N, C, H, W, sH, sW, pH, pW, normalize_grad,             \
                                enable_shift_grad, quantize, ws, ws_bytes, stream);                               \
     }
 RK_DEF_2D(f32, float, float)
@@ -179,5 +182,24 @@ RK_DEF_2D(f64, double, double)
 RK_DEF_2D(f16, __half, void)
 RK_DEF_2D(bf16, __hip_bfloat16, void)
 #undef RK_DEF_2D
+
+// 16-bit activations with the shift table / d(shift) in fp32 (what autocast hands the operator: bf16 activations next
+// to an fp32 nn.Parameter).  Everything that depends on the shift -- floor / remainder, the 1e-7 integer test, the
+// quantize position arithmetic -- is then evaluated in fp32 exactly as by rk2d_*_f32.
+#define RK_DEF_2D_MIXED(SFX, TYPE)                                                                               \
+    int rk2d_forward_##SFX##_sf32(const void* x, const float* shift, void* y, int N, int C, int H, int W, int sH, \
+                                  int sW, int pH, int pW, int quantize, rk_stream_t stream) {                    \
+        return forward2<TYPE, float>(x, shift, y, N, C, H, W, sH, sW, pH, pW, quantize, stream);                 \
+    }                                                                                                            \
+    int rk2d_backward_##SFX##_sf32(const void* gy, const void* x, const float* shift, void* gx, float* gshift,   \
+                                   int N, int C, int H, int W, int sH, int sW, int pH, int pW,                   \
+                                   int normalize_grad, int enable_shift_grad, int quantize, void* ws,            \
+                                   size_t ws_bytes, rk_stream_t stream) {                                        \
+        return backward2<TYPE, float>(gy, x, shift, gx, gshift, N, C, H, W, sH, sW, pH, pW, normalize_grad,      \
+                                      enable_shift_grad, quantize, ws, ws_bytes, stream);                        \
+    }
+RK_DEF_2D_MIXED(f16, __half)
+RK_DEF_2D_MIXED(bf16, __hip_bfloat16)
+#undef RK_DEF_2D_MIXED
 
 }  // extern "C"

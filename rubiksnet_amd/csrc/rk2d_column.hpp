@@ -53,8 +53,8 @@ template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
 // ------------------------------------------------------------------------------------ forward
 // VEC (kM == 4, output planes of a multiple of 4 elements, aligned y): a thread owns 4 CONSECUTIVE outputs and stores
 // them as one 8- / 16-byte access; frames are taken in batches, every tap of a batch requested before the first is used.
-template <typename T, int kM, bool VEC = false>
-__global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict__ x, const T* __restrict__ shift,
+template <typename T, typename S, int kM, bool VEC = false>
+__global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict__ x, const S* __restrict__ shift,
                                                              T* __restrict__ y, C2Dims cd) {
     using CT = typename Compute<T>::type;
     const Dims2& d = cd.d;
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
 // 16-byte (fp32) access per thread and frame instead of four 2- / 4-byte ones; the gy taps stay scalar (L1-served).
 // Frames are taken four at a time, every load of the four requested before the first is used.  Same arithmetic per
 // element, bit-identical.
-template <typename T, int kM, bool SINGLE, bool VEC = false>
+template <typename T, typename S, int kM, bool SINGLE, bool VEC = false>
 __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restrict__ gy, const T* __restrict__ x,
-                                                              const T* __restrict__ shift, T* __restrict__ gx,
+                                                              const S* __restrict__ shift, T* __restrict__ gx,
                                                               typename Compute<T>::type* __restrict__ part,
                                                               C2Dims cd) {
     using CT = typename Compute<T>::type;
@@ -301,16 +301,16 @@ inline unsigned grid_of(const C2Dims& cd) {
     return (unsigned)((groups + per_block - 1) / per_block);
 }
 
-template <typename T>
-inline void launch_forward(const T* x, const T* shift, T* y, const Dims2& d, hipStream_t stream) {
+template <typename T, typename S>
+inline void launch_forward(const T* x, const S* shift, T* y, const Dims2& d, hipStream_t stream) {
     const C2Dims cd = make_c2dims(d, d.Ho * d.Wo);
     const bool vec = cd.M == 4 && (d.Ho * d.Wo) % 4 == 0 && ((uintptr_t)y & 15) == 0;
     if (cd.M == 1)
-        hipLaunchKernelGGL((k2d_forward_column<T, 1>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+        hipLaunchKernelGGL((k2d_forward_column<T, S, 1>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
     else if (vec)
-        hipLaunchKernelGGL((k2d_forward_column<T, 4, true>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+        hipLaunchKernelGGL((k2d_forward_column<T, S, 4, true>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
     else
-        hipLaunchKernelGGL((k2d_forward_column<T, 4>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
+        hipLaunchKernelGGL((k2d_forward_column<T, S, 4>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
 }
 
 inline int backward_partials(const Dims2& d) {
@@ -319,13 +319,13 @@ inline int backward_partials(const Dims2& d) {
 }
 
 // d(x) + d(shift) partials into ws[C][2][P]; returns P
-template <typename T>
-inline int launch_backward(const T* gy, const T* x, const T* shift, T* gx, typename Compute<T>::type* ws,
+template <typename T, typename S>
+inline int launch_backward(const T* gy, const T* x, const S* shift, T* gx, typename Compute<T>::type* ws,
                            const Dims2& d, hipStream_t stream) {
     const C2Dims cd = make_c2dims(d, d.H * d.W);
     const bool single = d.sH >= 2 && d.sW >= 2;
     const bool vec = cd.M == 4 && (d.H * d.W) % 4 == 0 && (((uintptr_t)x | (uintptr_t)gx) & 15) == 0;
-#define RK_C2_BWD(MM, SG, VC) hipLaunchKernelGGL((k2d_backward_column<T, MM, SG, VC>), dim3(grid_of(cd)), dim3(kBlock), 0, \
+#define RK_C2_BWD(MM, SG, VC) hipLaunchKernelGGL((k2d_backward_column<T, S, MM, SG, VC>), dim3(grid_of(cd)), dim3(kBlock), 0, \
                                                  stream, gy, x, shift, gx, ws, cd)
     if (cd.M == 1) { if (single) RK_C2_BWD(1, true, false); else RK_C2_BWD(1, false, false); }
     else if (vec) { if (single) RK_C2_BWD(4, true, true); else RK_C2_BWD(4, false, true); }

@@ -46,6 +46,11 @@ template <> struct QuantPos<__hip_bfloat16> {
     }
 };
 
+// the type the quantize position arithmetic runs in: the tensor's own (the reference), unless the shift table is wider
+template <typename T, typename S> struct PosType { using type = T; };
+template <> struct PosType<__half, float> { using type = float; };
+template <> struct PosType<__hip_bfloat16, float> { using type = float; };
+
 // rubiks2d_kernels.cu:60-66
 template <typename CT> __device__ __forceinline__ CT interp2d(CT p00, CT p01, CT p10, CT p11, CT rH, CT rW) {
     return p00 * (1 - rH) * (1 - rW) + p01 * (1 - rH) * rW + p10 * rH * (1 - rW) + p11 * rH * rW;
@@ -72,8 +77,8 @@ __device__ __forceinline__ int unmap2(int p, int s, int lim) {
 }
 
 // ------------------------------------------------------------------------------ K6
-template <typename T, bool QUANT>
-__global__ __launch_bounds__(kBlock) void k2d_forward(const T* __restrict__ x, const T* __restrict__ shift,
+template <typename T, typename S, bool QUANT>
+__global__ __launch_bounds__(kBlock) void k2d_forward(const T* __restrict__ x, const S* __restrict__ shift,
                                                       T* __restrict__ y, Dims2 d) {
     using CT = typename Compute<T>::type;
     int n, c, e;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void k2d_forward(const T* __restrict__ x, c
     for (int i = e; i < HWo; i += d.E) {
         const int bH = ho * d.sH - d.pH, bW = wo * d.sW - d.pW;
         if (QUANT) {  // out-of-range source: y is left untouched (rubiks2d_kernels.cu:116-121)
-            const int th = QuantPos<T>::nearest(bH, offH), tw = QuantPos<T>::nearest(bW, offW);
+            const int th = QuantPos<typename PosType<T, S>::type>::nearest(bH, offH), tw = QuantPos<typename PosType<T, S>::type>::nearest(bW, offW);
             if (th >= 0 && th < d.H && tw >= 0 && tw < d.W) yp[i] = xp[th * d.W + tw];
         } else {
             const int h0 = bH + iH, w0 = bW + iW;
@@ -110,9 +115,9 @@ __global__ __launch_bounds__(kBlock) void k2d_forward(const T* __restrict__ x, c
 
 // ------------------------------------------------------------------------------ K7
 // this thread's share of the d(shift) terms of one (n, c) plane (E cooperating threads)
-template <typename T>
+template <typename T, typename S>
 __device__ __forceinline__ void shift_grad_plane2(const T* __restrict__ gy, const T* __restrict__ x,
-                                                  const T* __restrict__ shift, const Dims2& d, int n, int c, int e,
+                                                  const S* __restrict__ shift, const Dims2& d, int n, int c, int e,
                                                   int E, typename Compute<T>::type& aH,
                                                   typename Compute<T>::type& aW) {
     using CT = typename Compute<T>::type;
@@ -153,9 +158,9 @@ __device__ __forceinline__ void shift_grad_plane2(const T* __restrict__ gy, cons
 }
 
 // partials part[c][2][P], P = N, p = n
-template <typename T>
+template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k2d_backward_shift(const T* __restrict__ gy, const T* __restrict__ x,
-                                                             const T* __restrict__ shift,
+                                                             const S* __restrict__ shift,
                                                              typename Compute<T>::type* __restrict__ part, Dims2 d) {
     using CT = typename Compute<T>::type;
     __shared__ CT red[2][kBlock / kWave];
@@ -173,9 +178,9 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_shift(const T* __restrict
 }
 
 // row-sum (rubiks.cpp:140-143) + K9 (rubiks2d_kernels.cu:381-397), one workgroup per channel
-template <typename T>
+template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k2d_finalize(const typename Compute<T>::type* __restrict__ part,
-                                                       T* __restrict__ gshift, int C, int P, int normalize) {
+                                                       S* __restrict__ gshift, int C, int P, int normalize) {
     using CT = typename Compute<T>::type;
     __shared__ double red[2][kBlock / kWave];
     const int c = blockIdx.x;
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(kBlock) void k2d_finalize(const typename Compute<T>
 
 // ------------------------------------------------------------------------------ K8
 // one (n, c) plane of d(x), computed by the E threads that call it
-template <typename T, bool QUANT>
-__device__ __forceinline__ void backward_input_plane2(const T* __restrict__ gy, const T* __restrict__ shift,
+template <typename T, bool QUANT, typename S>
+__device__ __forceinline__ void backward_input_plane2(const T* __restrict__ gy, const S* __restrict__ shift,
                                                       T* __restrict__ gx, const Dims2& d, int n, int c, int e, int E) {
     using CT = typename Compute<T>::type;
     const CT nH = -ld(shift + c), nW = -ld(shift + d.C + c);
@@ -217,8 +222,8 @@ __device__ __forceinline__ void backward_input_plane2(const T* __restrict__ gy, 
     for (int i = e; i < HW; i += E) {
         const int oH = h + d.pH, oW = w + d.pW;
         if (QUANT) {   // skipped positions leave gx untouched (rubiks2d_kernels.cu:294-309)
-            const int a = unmap2(QuantPos<T>::nearest(oH, nH), d.sH, d.Ho);
-            const int b = unmap2(QuantPos<T>::nearest(oW, nW), d.sW, d.Wo);
+            const int a = unmap2(QuantPos<typename PosType<T, S>::type>::nearest(oH, nH), d.sH, d.Ho);
+            const int b = unmap2(QuantPos<typename PosType<T, S>::type>::nearest(oW, nW), d.sW, d.Wo);
             if (a >= 0 && b >= 0) xp[i] = gp[a * d.Wo + b];
         } else if (zero) {
             st(xp + i, gat(oH, oW));
@@ -231,8 +236,8 @@ __device__ __forceinline__ void backward_input_plane2(const T* __restrict__ gy, 
     }
 }
 
-template <typename T, bool QUANT>
-__global__ __launch_bounds__(kBlock) void k2d_backward_input(const T* __restrict__ gy, const T* __restrict__ shift,
+template <typename T, typename S, bool QUANT>
+__global__ __launch_bounds__(kBlock) void k2d_backward_input(const T* __restrict__ gy, const S* __restrict__ shift,
                                                              T* __restrict__ gx, Dims2 d) {
     int n, c, e;
     if (!my_plane2(d, n, c, e)) return;

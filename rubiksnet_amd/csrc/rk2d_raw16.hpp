@@ -136,8 +136,8 @@ __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __rest
     }
 __device__ __forceinline__ int off8(int fl) { return ((fl % 8) + 8) % 8; }
 
-template <typename T, bool NEGATE, int ROUNDS, int D>
-__global__ __launch_bounds__(kBlock) void k2d_raw16_interp(const T* __restrict__ src, const T* __restrict__ shift,
+template <typename T, typename S, bool NEGATE, int ROUNDS, int D>
+__global__ __launch_bounds__(kBlock) void k2d_raw16_interp(const T* __restrict__ src, const S* __restrict__ shift,
                                                            T* __restrict__ dst, FDims fd) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     const BDims& d = fd.b;
@@ -260,10 +260,10 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
     accH = sH; accW = sW;
 }
 
-template <typename T, int ROUNDS>
+template <typename T, typename S, int ROUNDS>
 __global__ __launch_bounds__(kBlock) void k2d_raw16_backward(const T* __restrict__ gy, const T* __restrict__ x,
-                                                             const T* __restrict__ shift, T* __restrict__ gx,
-                                                             FDims fd, Fin2<T> fin) {
+                                                             const S* __restrict__ shift, T* __restrict__ gx,
+                                                             FDims fd, Fin2<S> fin) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     __shared__ float red[2][kBlock / kWave];
     const BDims& d = fd.b;
@@ -350,8 +350,8 @@ inline int backward2_partials(const Dims2& d) {
     return make_fdims8(f, d, kFramesRaw16) ? f.ngroups * f.b.nbands : 0;
 }
 
-template <typename T, bool NEGATE>
-inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d, hipStream_t stream) {
+template <typename T, bool NEGATE, typename S>
+inline bool launch_interp2(const T* src, const S* shift, T* dst, const Dims2& d, hipStream_t stream) {
     constexpr int D = 2;
     FDims f;
     if (!make_fdims8(f, d, kFramesRaw16) || !aligned16(src) || !aligned16(dst)) return false;
@@ -359,23 +359,23 @@ inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d,
     if (lds > 64 * 1024) return false;
     const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
     switch (rounds_of(f.b)) {
-        case 1: hipLaunchKernelGGL((k2d_raw16_interp<T, NEGATE, 1, D>), grid, block, lds, stream, src, shift, dst, f); break;
-        case 2: hipLaunchKernelGGL((k2d_raw16_interp<T, NEGATE, 2, D>), grid, block, lds, stream, src, shift, dst, f); break;
-        case 3: hipLaunchKernelGGL((k2d_raw16_interp<T, NEGATE, 3, D>), grid, block, lds, stream, src, shift, dst, f); break;
-        default: hipLaunchKernelGGL((k2d_raw16_interp<T, NEGATE, 4, D>), grid, block, lds, stream, src, shift, dst, f); break;
+        case 1: hipLaunchKernelGGL((k2d_raw16_interp<T, S, NEGATE, 1, D>), grid, block, lds, stream, src, shift, dst, f); break;
+        case 2: hipLaunchKernelGGL((k2d_raw16_interp<T, S, NEGATE, 2, D>), grid, block, lds, stream, src, shift, dst, f); break;
+        case 3: hipLaunchKernelGGL((k2d_raw16_interp<T, S, NEGATE, 3, D>), grid, block, lds, stream, src, shift, dst, f); break;
+        default: hipLaunchKernelGGL((k2d_raw16_interp<T, S, NEGATE, 4, D>), grid, block, lds, stream, src, shift, dst, f); break;
     }
     return true;
 }
 
 // d(x) + d(shift) (row-sum + K9 inside the launch: ws holds granules [C][2][P]); false = not handled here
-template <typename T>
-inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* gshift, void* ws, int normalize,
+template <typename T, typename S>
+inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* gshift, void* ws, int normalize,
                              const Dims2& d, hipStream_t stream) {
     FDims f;
     if (!make_fdims8(f, d, kFramesRaw16) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
     const size_t lds = bwd_ring_bytes(f.b, 1, 1);
     if (lds > 64 * 1024) return false;
-    Fin2<T> fin;
+    Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
     fin.f.tag = next_launch_tag();
     fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
@@ -383,10 +383,10 @@ inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* 
     fin.normalize = normalize;
     const dim3 grid((unsigned)(fin.f.producers + f.b.C)), block(kBlock);
     switch (rounds_of(f.b)) {
-        case 1: hipLaunchKernelGGL((k2d_raw16_backward<T, 1>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
-        case 2: hipLaunchKernelGGL((k2d_raw16_backward<T, 2>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
-        case 3: hipLaunchKernelGGL((k2d_raw16_backward<T, 3>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
-        default: hipLaunchKernelGGL((k2d_raw16_backward<T, 4>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
+        case 1: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 1>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
+        case 2: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 2>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
+        case 3: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 3>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
+        default: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 4>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
     }
     return true;
 }

@@ -127,8 +127,8 @@ template <typename G> __device__ __forceinline__ Item my_item(const TDims2& d, i
 
 // ---------------------------------------------------------------------------------------------
 // Forward (NEGATE = false: src = x) and d(x) alone (NEGATE = true: src = gy, negated shift).
-template <typename T, int H, int W, int R, bool NEGATE>
-__global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ src, const T* __restrict__ shift,
+template <typename T, typename S, int H, int W, int R, bool NEGATE>
+__global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ src, const S* __restrict__ shift,
                                                           T* __restrict__ dst, TDims2 d) {
     using G = Geo<T, H, W>;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -232,10 +232,10 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // Backward: d(x) + d(shift); partials [C][2][P = ngroups] as granules, row-sum + K9 by the finalizer blocks.
-template <typename T, int H, int W, int R>
+template <typename T, typename S, int H, int W, int R>
 __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
-                                                            const T* __restrict__ shift, T* __restrict__ gx, TDims2 d,
-                                                            Fin2<T> fin) {
+                                                            const S* __restrict__ shift, T* __restrict__ gx, TDims2 d,
+                                                            Fin2<S> fin) {
     using G = Geo<T, H, W>;
     if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
         if (threadIdx.x < kWave) dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, d.ngroups);
@@ -392,21 +392,21 @@ template <typename T> inline int backward2_partials(const Dims2& d) {
     return make_tdims<T, 14, 14>(t, d) ? t.ngroups : 0;
 }
 
-template <typename T, bool NEGATE>
-inline bool launch_interp2(const T* src, const T* shift, T* dst, const Dims2& d, hipStream_t stream) {
+template <typename T, bool NEGATE, typename S>
+inline bool launch_interp2(const T* src, const S* shift, T* dst, const Dims2& d, hipStream_t stream) {
     constexpr int R = 4;
     using G = Geo<T, 14, 14>;
     TDims2 t;
     if (!make_tdims<T, 14, 14>(t, d) || !aligned16(src) || !aligned16(dst)) return false;
     const long long waves = (long long)t.NG * t.ngroups;
     const size_t lds = (size_t)4 * R * G::STRIDE;
-    hipLaunchKernelGGL((k2d_tile_interp<T, 14, 14, R, NEGATE>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), lds, stream,
+    hipLaunchKernelGGL((k2d_tile_interp<T, S, 14, 14, R, NEGATE>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), lds, stream,
                        src, shift, dst, t);
     return true;
 }
 
-template <typename T>
-inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* gshift, void* ws, int normalize,
+template <typename T, typename S>
+inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* gshift, void* ws, int normalize,
                              const Dims2& d, hipStream_t stream) {
     constexpr int R = 3;       // (the forward's static full-group schedule was tried here too: 245 VGPRs, 26 -> 31 us)
     using G = Geo<T, 14, 14>;
@@ -414,13 +414,13 @@ inline bool launch_backward2(const T* gy, const T* x, const T* shift, T* gx, T* 
     if (!make_tdims<T, 14, 14>(t, d) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
     const long long waves = (long long)t.NG * t.ngroups;
     const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
-    Fin2<T> fin;
+    Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
     fin.f.tag = next_launch_tag();
     fin.f.producers = (int)((waves + 3) / 4);
     fin.gshift = gshift;
     fin.normalize = normalize;
-    hipLaunchKernelGGL((k2d_tile_backward<T, 14, 14, R>), dim3((unsigned)(fin.f.producers + t.C)), dim3(kBlock), lds, stream, gy,
+    hipLaunchKernelGGL((k2d_tile_backward<T, S, 14, 14, R>), dim3((unsigned)(fin.f.producers + t.C)), dim3(kBlock), lds, stream, gy,
                        x, shift, gx, t, fin);
     return true;
 }

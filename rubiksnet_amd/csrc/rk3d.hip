@@ -167,8 +167,8 @@ size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W, int sT, 
         if (chunks > per_n) per_n = chunks;
     }
     const size_t P = (size_t)N * per_n;
-    // fp32: the streaming backward keeps its partials as 8-byte {value, tag} granules (rk3d_dma.hpp)
-    return (size_t)C * 3 * P * (size_t)(elem_size == 4 ? 8 : elem_size);
+    // fp32: the streaming backward keeps its partials as 16-byte granule pairs (rk_dma.hpp: fin_publish)
+    return (size_t)C * 3 * P * (size_t)(elem_size == 4 ? 16 : elem_size);
 }
 
 int rk3d_forward_f32(const float* x, const float* shift, float* y, int N, int T, int C, int H, int W, int sT,

@@ -191,7 +191,7 @@ __device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slo
 // ---------------------------------------------------------------------------------------------
 // Row-sum of the d(shift) partials INSIDE the backward launch (instead of a separate finalize launch, ~4.5 us + a
 // kernel boundary per call).  Producers do not wait for anything: a workgroup (or wave) writes each of its D
-// partials as an 8-byte granule {fp32 value, 32-bit launch tag} with ONE device-scope (sc1, write-through) store
+// partials as a pair of 8-byte granules ({fp32 value, launch tag} + a check granule, below) with device-scope stores
 // -- the "data-tagged granule" hand-off of MI355X_MICROARCH.md (price-list rows handoff-1to1 / R2) -- and exits.  The
 // LAST C blocks of the grid are finalizers, one wave per channel: they poll that channel's D*P granules with
 // device-scope loads (s_sleep between sweeps) until every one carries this launch's tag, then sum them in index
@@ -205,18 +205,38 @@ __device__ __forceinline__ void init_tap_slots(float4* ring, int nslots, int slo
 // (The first fused version -- the last-ARRIVING producer finalizes, ticket by CAS -- cost +10 us: the store ->
 // vmcnt(0) -> CAS round trips sat on every producer's exit while it held its LDS slot.)
 struct Fin {
-    unsigned long long* gran;     // [C][D][P] granules
+    unsigned long long* gran;     // [C][D][P] granule PAIRS (16 bytes per partial)
     unsigned tag;                 // != 0, unique per launch
     int producers;                // producer blocks; blocks beyond are finalizers
 };
-inline unsigned next_launch_tag() {
+inline std::atomic<unsigned>& launch_tag_counter() {
     static std::atomic<unsigned> tag{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
+    return tag;
+}
+inline unsigned next_launch_tag() {
+    std::atomic<unsigned>& tag = launch_tag_counter();
     unsigned t = tag.fetch_add(1, std::memory_order_relaxed);
     return t ? t : tag.fetch_add(1, std::memory_order_relaxed);
 }
+// A partial is handed over as a PAIR of 8-byte granules at gran[2*at], gran[2*at + 1]:
+//   value granule {fp32 value, tag}   and   check granule {~value bits, tag2},  tag2 = a second word derived from tag.
+// Each 8-byte store is single-copy atomic; a consumer accepts the pair only if both tags match AND the two payloads
+// are complements, i.e. 128 consistent bits.  The workspace is uninitialised memory (torch.empty: stale fp32
+// activations, whose bit patterns are anything but uniform): with the one-granule form of round 2 a stale word equal
+// to the 32-bit tag would have passed for a finished partial (round-2 advisor finding); a stale 16-byte pattern that
+// satisfies all three conditions by accident is out of reach (< 2^-90 per granule even for adversarial float data,
+// tests/test_parity_3d.py::test_backward_ignores_adversarial_workspace_contents fills the workspace with near misses).
+__device__ __forceinline__ unsigned fin_tag2(unsigned tag) { return tag * 2654435761u ^ 0x9e3779b9u; }
 __device__ __forceinline__ void fin_publish(const Fin& fin, size_t at, float v) {
-    __hip_atomic_store(fin.gran + at, ((unsigned long long)fin.tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+    const unsigned bits = __float_as_uint(v);
+    __hip_atomic_store(fin.gran + 2 * at, ((unsigned long long)fin.tag << 32) | bits, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fin.gran + 2 * at + 1, ((unsigned long long)fin_tag2(fin.tag) << 32) | (unsigned)~bits,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both granules of a pair carry this launch's tags and agree on the payload
+__device__ __forceinline__ bool fin_ready(const Fin& fin, unsigned long long v, unsigned long long w) {
+    return (unsigned)(v >> 32) == fin.tag && (unsigned)(w >> 32) == fin_tag2(fin.tag) && (unsigned)v == ~(unsigned)w;
 }
 // one wave (lanes 0..63 of the block): s[k] = sum_i granule[c][k][i] over this launch's P partials; false = timed out.
 // The D loads of a lane go out together (one round trip, not D dependent ones: the finalizers' sweep is the tail of
@@ -224,37 +244,47 @@ __device__ __forceinline__ void fin_publish(const Fin& fin, size_t at, float v) 
 template <int D>
 __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double (&s)[D]) {
     const int lane = threadIdx.x;
-    const unsigned long long* g = fin.gran + (size_t)c * D * P;
-    const unsigned long long done = (unsigned long long)fin.tag << 32;          // a ready granule holding 0.0f
+    unsigned long long* g = fin.gran + 2 * (size_t)c * D * P;
+    const unsigned long long done = (unsigned long long)fin.tag << 32;          // a ready pair holding 0.0f
+    const unsigned long long done2 = ((unsigned long long)fin_tag2(fin.tag) << 32) | 0xffffffffull;
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0;
     for (int i0 = 0; i0 < P; i0 += kWave) {
         const int i = i0 + lane;
         const bool act = i < P;
-        unsigned long long v[D];
+        unsigned long long v[D], w[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k)
-            v[k] = act ? __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done;
+        for (int k = 0; k < D; ++k) {
+            const size_t at = 2 * ((size_t)k * P + i);
+            v[k] = act ? __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done;
+            w[k] = act ? __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done2;
+        }
         for (int spin = 0; spin < 8000000; ++spin) {                 // ~0.25 us per poll: gives up after ~2 s
             bool ready = true;
 #pragma unroll
-            for (int k = 0; k < D; ++k) ready = ready && (unsigned)(v[k] >> 32) == fin.tag;
+            for (int k = 0; k < D; ++k) ready = ready && fin_ready(fin, v[k], w[k]);
             if (ready) break;
             __builtin_amdgcn_s_sleep(8);
 #pragma unroll
             for (int k = 0; k < D; ++k)
-                if ((unsigned)(v[k] >> 32) != fin.tag)
-                    v[k] = __hip_atomic_load(g + (size_t)k * P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!fin_ready(fin, v[k], w[k])) {
+                    const size_t at = 2 * ((size_t)k * P + i);
+                    v[k] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[k] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            ok = ok && (unsigned)(v[k] >> 32) == fin.tag;
+            ok = ok && fin_ready(fin, v[k], w[k]);
             s[k] += (double)__uint_as_float((unsigned)v[k]);
-            // consumed: retire the granule (tag 0 is never issued), so that a REPLAY of this launch with the same
+            // consumed: retire the pair (tag 0 is never issued), so that a REPLAY of this launch with the same
             // tag -- a captured hipGraph -- cannot take the previous replay's partials for its own
-            if (act) __hip_atomic_store(const_cast<unsigned long long*>(g) + (size_t)k * P + i, 0ull, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);
+            if (act) {
+                const size_t at = 2 * ((size_t)k * P + i);
+                __hip_atomic_store(g + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + at + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 #pragma unroll

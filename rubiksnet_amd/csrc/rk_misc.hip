@@ -1,5 +1,6 @@
 // rk_misc.hip -- version / error strings / shape helper of the C ABI (include/rubiks_hip.h).
 #include "rk_common.hpp"
+#include "rk_dma.hpp"
 
 extern "C" {
 
@@ -28,6 +29,13 @@ int rk_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// Test hook: the tag the NEXT fused-finalize launch will stamp its d(shift) granules with (rk_dma.hpp), not consumed.
+// Lets tests/ pre-fill a workspace with near-miss granules; no product code calls it.
+unsigned rk_debug_peek_launch_tag(void) {
+    const unsigned t = rk::dma::launch_tag_counter().load(std::memory_order_relaxed);
+    return t ? t : 1u;
 }
 
 }  // extern "C"

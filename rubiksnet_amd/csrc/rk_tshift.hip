@@ -382,7 +382,7 @@ extern "C" {
 size_t rk_tshift3_backward_workspace_bytes(int NT, int S, int C, int HW) {
     (void)HW;
     if (NT <= 0 || S <= 0 || C <= 0) return 0;
-    return (size_t)C * 3 * (size_t)(NT / S) * 8;   // sized for fp64 partials; fp32 uses half of it
+    return (size_t)C * 3 * (size_t)(NT / S) * 16;  // fp32 partials are 16-byte granule pairs (rk_dma.hpp); fp64 ones use half
 }
 
 #define RK_DEF_TAP(SFX, TYPE, CTYPE, TAPT)                                                                     \

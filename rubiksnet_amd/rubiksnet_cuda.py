@@ -146,18 +146,25 @@ def rubiks_shift_3d_backward_double(input, shift, output_grad, strides, paddings
                        shift_grad, normalize_grad, normalize_t_factor, quantize)
 
 
-def _sfx2d(t):
+def _sfx2d(t, shift):
+    """Entry-point suffix and the dtype the shift table / d(shift) must have.  The reference runs K6-K9 at the
+    tensor's own scalar type, shift included (rubiks2d_kernels.cu:113-114); next to 16-bit activations an fp32
+    shift is accepted as well and then stays fp32 inside the kernels (rk2d_*_sf32)."""
     sfx = _native.dtype_suffix(t.dtype)
     if sfx is None:
         # AT_DISPATCH_FLOATING_TYPES_AND_HALF (rubiks2d_kernels.cu:422) raises for other dtypes
         raise RuntimeError("rubiks2d not implemented for dtype %s" % t.dtype)
-    return sfx
+    if torch.is_tensor(shift) and shift.dtype == torch.float32 and t.dtype in (torch.float16, torch.bfloat16):
+        return sfx + "_sf32", torch.float32
+    return sfx, t.dtype
 
 
 def rubiks2d_forward(input, shift, strides, paddings, quantize, output):
     """cuda_src/rubiks.cpp:44-67.  With quantize, out-of-range outputs are left untouched
     (rubiks2d_kernels.cu:116-121): pass a zero-filled `output`, as rubiksnet/utils.py:26 does."""
-    _require(input, "input"); _require(shift, "shift", input.dtype); _require(output, "output", input.dtype)
+    _require(input, "input")
+    sfx, shift_dtype = _sfx2d(input, shift)
+    _require(shift, "shift", shift_dtype); _require(output, "output", input.dtype)
     dev = _same_device(input, shift, output)
     s, p = _ints(strides, 2, "strides"), _ints(paddings, 2, "paddings")
     N, C, H, W = input.shape
@@ -167,7 +174,6 @@ def rubiks2d_forward(input, shift, strides, paddings, quantize, output):
     want = (N, C, L.rk_out_len(H, s[0], p[0]), L.rk_out_len(W, s[1], p[1]))
     if tuple(output.shape) != want:
         raise RuntimeError("output has shape %s, expected %s" % (tuple(output.shape), want))
-    sfx = _sfx2d(input)
     if input.numel() == 0 or output.numel() == 0:
         return 0
     with torch.cuda.device(dev):
@@ -183,8 +189,9 @@ def rubiks2d_backward(upstream_grad, input, shift, strides, paddings, normalize_
     """cuda_src/rubiks.cpp:94-155.  input_grad must be zero-filled when quantize is set
     (rubiks.cpp:106-107, rubiks2d_kernels.cu:294-309)."""
     _require(upstream_grad, "upstream_grad", input.dtype); _require(input, "input")
-    _require(shift, "shift", input.dtype); _require(input_grad, "input_grad", input.dtype)
-    _require(shift_grad, "shift_grad", input.dtype)
+    sfx, shift_dtype = _sfx2d(input, shift)
+    _require(shift, "shift", shift_dtype); _require(input_grad, "input_grad", input.dtype)
+    _require(shift_grad, "shift_grad", shift_dtype)
     dev = _same_device(upstream_grad, input, shift, input_grad, shift_grad)
     s, p = _ints(strides, 2, "strides"), _ints(paddings, 2, "paddings")
     N, C, H, W = input.shape
@@ -192,7 +199,6 @@ def rubiks2d_backward(upstream_grad, input, shift, strides, paddings, normalize_
     want = (N, C, L.rk_out_len(H, s[0], p[0]), L.rk_out_len(W, s[1], p[1]))
     if tuple(upstream_grad.shape) != want:
         raise RuntimeError("upstream_grad has shape %s, expected %s" % (tuple(upstream_grad.shape), want))
-    sfx = _sfx2d(input)
     if input.numel() == 0 or upstream_grad.numel() == 0:
         if enable_shift_grad:
             shift_grad.zero_()

@@ -31,12 +31,17 @@ def compute_output_shape(x, stride, padding, shift_dim=_DIM):
     return (int(x.shape[0]), int(x.shape[1]), *moved)
 
 
+def _mixed(x, shift):
+    """16-bit activations with an fp32 shift table: handled natively (the shift stays fp32 in the kernels)."""
+    return x.dtype in (torch.float16, torch.bfloat16) and shift.dtype == torch.float32
+
+
 def rubiks2d_forward(x, shift, stride=1, padding=0, quantize=False, output=None):
     """Pure forward primitive (rubiks2d/primitive.py:44-67)."""
     strides = make_tuple(stride, repeats=_DIM)
     paddings = make_tuple(padding, repeats=_DIM)
     assert x.is_cuda, "shift only works on CUDA tensors"
-    assert x.dtype == shift.dtype, "x and shift must have the same dtype"
+    assert x.dtype == shift.dtype or _mixed(x, shift), "x and shift must have the same dtype"
     out_shape = compute_output_shape(x, strides, paddings, shift_dim=_DIM)
     # quantize leaves out-of-range outputs untouched (rubiks2d_kernels.cu:116-121) -> needs zeros
     output = allocate_output(output, x, out_shape, zero=bool(quantize))
@@ -99,6 +104,7 @@ class VFS2DFunc(torch.autograd.Function):
 def rubiks2d(x, shift, stride=1, padding=0, normalize_grad=True, enable_shift_grad=True, quantize=False):
     """User-facing functional (rubiks2d/primitive.py:177-196)."""
     assert len(x.size()) == 4, "x must be [N, C, H, W]"
-    if shift.dtype != x.dtype and x.dtype in (torch.float16, torch.bfloat16):
-        shift = shift.to(x.dtype)      # autocast: fp32 parameter, half activations
+    # autocast: 16-bit activations next to the fp32 parameter.  The parameter is NOT rounded to the activations' type
+    # (2^-8 relative on the interpolation weights in bf16, and it can flip the 0.5 side of `quantize`): the kernels
+    # take the fp32 table as it is and return d(shift) in fp32 (rk2d_*_sf32).
     return VFS2DFunc.apply(x, shift, stride, padding, normalize_grad, enable_shift_grad, quantize)

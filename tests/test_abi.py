@@ -17,6 +17,7 @@ def declared_symbols():
     names = set(re.findall(r"\b(rk[0-9a-z_]*?)\s*\(", text))
     names = {n for n in names if not n.endswith("_")}
     for macro, templ in (("RK_DECL_2D", ["rk2d_forward_%s", "rk2d_backward_%s"]),
+                         ("RK_DECL_2D_SF32", ["rk2d_forward_%s_sf32", "rk2d_backward_%s_sf32"]),
                          ("RK_DECL_TAP", ["rk_tshift3_forward_%s", "rk_tshift3_backward_%s"]),
                          ("RK_DECL_BN", ["rk_bn_relu_forward_%s", "rk_bn_relu_forward_counted_%s", "rk_bn_relu_backward_%s"]),
                          ("RK_DECL_SE", ["rk_se_squeeze_%s", "rk_se_scale_%s", "rk_se_scale_backward_%s"])):
@@ -42,10 +43,10 @@ def test_version_shape_helper_and_error_strings():
     assert L.rk_out_len(8, 0, 0) == -3
     for code in (0, -1, -2, -3, -4, -5, -6, -99):
         assert len(L.rk_error_string(code)) > 0
-    assert L.rk3d_backward_workspace_bytes(32, 8, 64, 56, 56, 1, 1, 1, 0, 0, 0, 4) == 64 * 3 * 32 * 56 * 8  # per clip: max(To, H, ceil(H*W/256)) partials, 8-byte granules in fp32
+    assert L.rk3d_backward_workspace_bytes(32, 8, 64, 56, 56, 1, 1, 1, 0, 0, 0, 4) == 64 * 3 * 32 * 56 * 16  # per clip: max(To, H, ceil(H*W/256)) partials, 16-byte granule pairs in fp32
     assert L.rk3d_backward_workspace_bytes(32, 8, 64, 56, 56, 1, 1, 1, 0, 0, 0, 8) == 64 * 3 * 32 * 56 * 8
-    assert L.rk2d_backward_workspace_bytes(4, 10, 7, 7, 1, 1, 0, 0, 4) == 10 * 2 * 4 * 8      # 8-byte granules
-    assert L.rk_tshift3_backward_workspace_bytes(16, 8, 5, 49) == 5 * 3 * 2 * 8
+    assert L.rk2d_backward_workspace_bytes(4, 10, 7, 7, 1, 1, 0, 0, 4) == 10 * 2 * 4 * 16     # 16-byte granule pairs
+    assert L.rk_tshift3_backward_workspace_bytes(16, 8, 5, 49) == 5 * 3 * 2 * 16
     assert L.rk_bn_workspace_bytes(256, 54, 56 * 56) == 54 * 86 * 2 * 4      # 3 frames per workgroup -> 86 groups
     assert L.rk_bn_workspace_bytes(0, 54, 49) == 0
 

@@ -132,6 +132,43 @@ def test_half_types_are_the_fp32_oracle_rounded_once(oracle, shape, kind, tdtype
 
 
 @pytest.mark.parametrize("tdtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["generic", "wide", "integer", "half", "tiny"])
+@pytest.mark.parametrize("cfg", [(4, 12, 14, 14, 1, 0), (20, 6, 28, 28, 1, 0), (3, 5, 56, 56, 1, 0), (6, 3, 24, 64, 1, 0),
+                                 (3, 5, 28, 28, 2, 0), (16, 9, 7, 7, 1, 0), (2, 7, 9, 11, 2, 1), (9, 6, 14, 14, 2, 0)])
+def test_half_activations_with_an_fp32_shift_table(oracle, cfg, kind, tdtype):
+    """rk2d_*_sf32 (what autocast reaches: 16-bit activations, fp32 nn.Parameter): the shift is NOT rounded to the
+    storage type, so y / d(x) are the fp32 oracle with the UNROUNDED shift on the widened inputs, rounded once -- bit
+    for bit, `quantize` (whose +-0.5 side a bf16-rounded shift could flip) included -- and d(shift) comes back in fp32
+    at fp32 accuracy."""
+    from rubiksnet_amd.shiftlib.rubiks2d.primitive import rubiks2d_backward, rubiks2d_forward
+
+    N, C, H, W, s, p = cfg
+    rng = np.random.default_rng(seed_of(cfg, kind, str(tdtype), "sf32"))
+    x = torch.from_numpy(rand(rng, (N, C, H, W), np.float32)).to(tdtype)
+    sf = special_shifts(rng, 2, C, np.float32, kind)
+    if kind == "generic":
+        sf[0, 0], sf[1, 0] = 0.4990234375, -0.5009765625      # fp32 != their bf16 / f16 roundings (0.5 / -0.5)
+    shift = torch.from_numpy(sf)
+    xf = x.float().numpy()
+    for q in (False, True):
+        y = rubiks2d_forward(x.cuda(), shift.cuda(), s, p, quantize=q)
+        y_ref = oracle.rk2d_forward(xf, sf, s, p, q)
+        assert y.dtype == tdtype and torch.equal(y.cpu(), torch.from_numpy(y_ref).to(tdtype)), "forward quantize=%s" % q
+        gy = torch.from_numpy(rand(rng, y_ref.shape, np.float32)).to(tdtype)
+        gf = gy.float().numpy()
+        gx, gs = rubiks2d_backward(gy.cuda(), x.cuda(), shift.cuda(), s, p, normalize_grad=False, quantize=q)
+        gx_ref, _ = oracle.rk2d_backward(gf, xf, sf, s, p, quantize=q)
+        assert torch.equal(gx.cpu(), torch.from_numpy(gx_ref).to(tdtype)), "d(x) quantize=%s" % q
+        assert gs.dtype == torch.float32
+        _, gs_ref = oracle.rk2d_backward(gf.astype(np.float64), xf.astype(np.float64), sf.astype(np.float64), s, p,
+                                         normalize_grad=False)
+        scale = max(1.0, float(np.abs(gs_ref).max()))
+        np.testing.assert_allclose(gs.cpu().numpy(), gs_ref, rtol=0, atol=1e-5 * scale)
+    gx2, gs2 = rubiks2d_backward(gy.cuda(), x.cuda(), shift.cuda(), s, p, enable_shift_grad=False, quantize=True)
+    assert torch.equal(gx2, gx) and (gs2 == 0).all()
+
+
+@pytest.mark.parametrize("tdtype", [torch.float16, torch.bfloat16])
 def test_half_types_close_to_fp32_oracle(oracle, tdtype):
     """f16 (reference dispatches it, rubiks2d_kernels.cu:422) and bf16: computed in fp32, rounded on
     store -> compare with the fp32 oracle on the rounded inputs at the storage type's precision."""

@@ -185,6 +185,63 @@ def test_two_phase_backward_equals_the_one_call_form():
         assert torch.equal(gx1, gx2) and torch.equal(gs1, gs2)
 
 
+@pytest.mark.parametrize("shape,stride", [((2, 8, 6, 56, 56), 1), ((2, 4, 8, 14, 14), 1), ((2, 3, 4, 56, 56), 2),
+                                          ((3, 4, 5, 28, 28), 1)])
+def test_backward_ignores_adversarial_workspace_contents(shape, stride):
+    """The in-launch row-sum polls an UNINITIALISED workspace for granules stamped with this launch's tag (rk_dma.hpp).
+    Round-2 advisor finding: with one 32-bit tag per granule a stale word equal to the tag passes for a finished
+    partial.  Pre-fill the workspace with exactly such near misses -- the right tag on the value granule, on the check
+    granule, on both but with payloads that do not agree, valid pairs for the neighbouring tags -- and demand the same
+    bits as with a zeroed workspace."""
+    from rubiksnet_amd import _native
+
+    L = _native.lib()
+    N, T, C, H, W = shape
+    s = (1, stride, stride)
+    torch.manual_seed(sum(shape))
+    x = torch.rand(shape, device="cuda:0") * 2 - 1
+    shift = torch.rand(3, C, device="cuda:0") * 2 - 1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    gy = torch.rand(N, T, C, Ho, Wo, device="cuda:0") * 2 - 1
+    nbytes = int(L.rk3d_backward_workspace_bytes(N, T, C, H, W, *s, 0, 0, 0, 4))
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(ws):
+        gx, gs = torch.empty_like(x), torch.empty_like(shift)
+        _native.check(L.rk3d_backward_f32(x.data_ptr(), shift.data_ptr(), gy.data_ptr(), gx.data_ptr(), gs.data_ptr(), N, T,
+                                          C, H, W, *s, 0, 0, 0, 1, 1.0, 0, ws.data_ptr(), nbytes, st), "rk3d_backward_f32")
+        torch.cuda.synchronize()
+        return gx, gs
+
+    gx0, gs0 = run(torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0"))
+    assert torch.isfinite(gs0).all()
+    rng = np.random.default_rng(1)
+    npairs = nbytes // 16
+    for mode in range(5):
+        tag = int(L.rk_debug_peek_launch_tag())                    # the tag run() below will use
+        tag2 = ((tag * 2654435761) & 0xffffffff) ^ 0x9e3779b9
+        v = rng.integers(0, 2 ** 32, npairs, dtype=np.uint64)
+        w = rng.integers(0, 2 ** 32, npairs, dtype=np.uint64)
+        inv = (~v) & np.uint64(0xffffffff)
+        pairs = np.empty((npairs, 2), np.uint64)
+        if mode == 0:      # the old failure mode: every value granule carries the right tag, the check granule is junk
+            pairs[:, 0], pairs[:, 1] = (np.uint64(tag) << np.uint64(32)) | v, w << np.uint64(32) | v
+        elif mode == 1:    # both tags right, payloads do not agree
+            pairs[:, 0], pairs[:, 1] = (np.uint64(tag) << np.uint64(32)) | v, (np.uint64(tag2) << np.uint64(32)) | w
+        elif mode == 2:    # payloads agree, the check granule carries the VALUE tag
+            pairs[:, 0], pairs[:, 1] = (np.uint64(tag) << np.uint64(32)) | v, (np.uint64(tag) << np.uint64(32)) | inv
+        elif mode == 3:    # complete, consistent pairs -- of the previous launch (never retired, say)
+            t, t2 = (tag - 1) & 0xffffffff, (((tag - 1) * 2654435761) & 0xffffffff) ^ 0x9e3779b9
+            pairs[:, 0], pairs[:, 1] = (np.uint64(t) << np.uint64(32)) | v, (np.uint64(t2) << np.uint64(32)) | inv
+        else:              # ... and of the next one
+            t, t2 = (tag + 1) & 0xffffffff, (((tag + 1) * 2654435761) & 0xffffffff) ^ 0x9e3779b9
+            pairs[:, 0], pairs[:, 1] = (np.uint64(t) << np.uint64(32)) | v, (np.uint64(t2) << np.uint64(32)) | inv
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+        ws[:npairs * 16] = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).cuda()
+        gx, gs = run(ws)
+        assert torch.equal(gx, gx0) and torch.equal(gs, gs0), "mode %d" % mode
+
+
 def test_errors_are_raised_not_fatal():
     from rubiksnet_amd import rubiksnet_cuda
     from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_forward
