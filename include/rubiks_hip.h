@@ -300,6 +300,50 @@ int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, in
 int rk_pw_wgrad_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws,
                      size_t ws_bytes, rk_stream_t stream);
 
+/* ---- training-mode fusion of the block's BatchNorms into the 1x1 GEMMs -- rows f1 / f3 of SURVEY 8(f) ----------
+ * The reference block (rubiksnet/backbone.py:123-135) is
+ *     a1 = relu(bn1(x)); z = conv2(a1); a2 = relu(bn2(z)); s = as3(a2); out = conv3(s) + shortcut
+ * with nn.BatchNorm2d in training mode (:50-53).  Unfused, every BatchNorm is a statistics pass + a normalise pass
+ * forward and a reduction pass + a d(x) pass backward.  Here
+ *   - the STATISTICS pass rides on the epilogue of the GEMM that produces the tensor (rk_pw_gemm_stats_f32; the stem:
+ *     rk_stem_conv3x3s2_stats_f32): one float4 (pivot, sum(y - pivot), sum((y - pivot)^2), -) per (channel, 128-column
+ *     wave tile), [M][rk_pw_tiles(F, P)], finished by rk_bn_finish_tiles_f32 into save_mean / save_invstd, the affine map
+ *     (a, b) of y = a x + b, and nn.BatchNorm2d's running statistics / num_batches_tracked;
+ *   - relu(bn1(x)) is never stored: it is the PROLOGUE (ka, kb, relu_in) of conv2's forward, of the strided shortcut's
+ *     forward (rk_pw_s2_forward_fused_f32) and of their d(weight) kernels (rk_pw_wgrad_pro_f32, rk_pw_s2_wgrad_pro_f32);
+ *   - the backward REDUCTION pass of bn1 rides on conv2's d(input) GEMM (rk_pw_gemm_bnbwd_f32): the result tile is masked
+ *     with [a x + b > 0] and its (sum dz, sum dz xhat) go out as float2 per (channel, tile); rk_bn_bwd_finish_tiles_f32
+ *     turns them into k1, k2, d(gamma), d(beta); rk_bn_bwd_dx_pre_f32 is the remaining d(x) pass (+ the identity
+ *     shortcut's gradient);
+ *   - rk_bn_apply_affine_f32: y = relu?(a x + b) with the finished map (bn2 in front of the shift);
+ *   - rk_bn_tile_stats_f32: the same tile statistics for a tensor no GEMM epilogue produced them for.
+ * All fp32, P % 4 == 0; results match torch.nn.functional.batch_norm + relu (+ conv2d) and their autograd gradients. */
+int rk_pw_tiles(int F, int P);
+int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                         int a_is_mk, const float* ka, const float* kb, int relu_in, void* stats, int tiles,
+                         rk_stream_t stream);
+int rk_stem_conv3x3s2_stats_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                                void* stats, int tiles, rk_stream_t stream);
+int rk_pw_gemm_bnbwd_f32(const float* A, const float* dY, const float* R, float* dZ, int F, int K, int M, int P,
+                         int a_is_mk, const float* x, const float* ba, const float* bb, const float* mean,
+                         const float* invstd, void* bred, int tiles, rk_stream_t stream);
+int rk_pw_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, const float* ka,
+                        const float* kb, int relu_in, void* ws, size_t ws_bytes, rk_stream_t stream);
+int rk_pw_s2_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                           const float* ka, const float* kb, int relu_in, void* ws, size_t ws_bytes, rk_stream_t stream);
+int rk_bn_finish_tiles_f32(const void* stats, int tiles, long long count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* a,
+                           float* b, int C, float eps, float momentum, long long* num_batches_tracked,
+                           rk_stream_t stream);
+int rk_bn_tile_stats_f32(const float* x, void* stats, int F, int C, int P, rk_stream_t stream);
+int rk_bn_apply_affine_f32(const float* x, const float* a, const float* b, float* y, int F, int C, int P, int relu,
+                           rk_stream_t stream);
+int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, float* k12, float* dgamma, float* dbeta,
+                               int C, rk_stream_t stream);
+int rk_bn_bwd_dx_pre_f32(const float* dz, const float* x, const float* gamma, const float* save_mean,
+                         const float* save_invstd, const float* k12, const float* skip, float* dx, int F, int C, int P,
+                         rk_stream_t stream);
+
 /* ---- input side of the network on the device -- widening row f4 of SURVEY 8(f) ----------------------
  * Replaces, per batch instead of per sample on CPU workers, the reference's transform tail
  * Stack -> ToTorchFormatTensor(div=True) -> GroupNormalize (rubiksnet/transforms.py:329-363, :66-79; wired up

@@ -15,6 +15,7 @@ from . import _native, config
 from .fused_bn import bn_relu, bn_relu_skip
 from .pointwise import conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
+from .train_block import bn_relu_from_stats, fused_train_block
 
 __all__ = ["RubiksNetBackbone", "RubiksShiftBlock", "SELayer"]
 
@@ -151,6 +152,10 @@ class RubiksShiftBlock(nn.Module):
             y = fused_eval_block(self, x)
             if y is not None:
                 return y
+        else:                               # training: one autograd node, BatchNorms folded into the GEMMs (train_block.py)
+            y = fused_train_block(self, x)
+            if y is not None:
+                return y
         if isinstance(self.shortcut, nn.Identity):
             # relu(bn(.)) as one operator on GPU tensors (fused_bn.py); the shortcut's gradient joins inside its backward
             out, shortcut = bn_relu_skip(self.bn1, x)
@@ -209,7 +214,8 @@ class RubiksNetBackbone(nn.Module):
         x = stem_conv(self.conv1, x)
         for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)
-        x = bn_relu(self.bn_last, x)
+        y = bn_relu_from_stats(self.bn_last, x) if self.training else None     # statistics from the last conv3's epilogue
+        x = y if y is not None else bn_relu(self.bn_last, x)
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))
 

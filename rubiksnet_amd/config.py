@@ -3,6 +3,8 @@
     RK_FUSED_BN    1 | 0          relu(bn(x)) pairs through the fused HIP operator (fused_bn.py) / stock modules
     RK_PW          auto | 0 | all 1x1 convolutions on the HIP MFMA GEMM wherever it can run / never / (same as auto)
     RK_FUSED_EVAL  1 | 0          inference blocks with BN + residual folded into the two GEMMs / layer by layer
+    RK_FUSED_TRAIN 1 | 0          training blocks as one autograd node with the BatchNorm statistics / normalisation / backward
+                                  reduction folded into the 1x1 GEMMs (train_block.py) / layer by layer
     RK_F1          0 | 1          inference blocks: shift kernel, then the conv3 GEMM / the 3-D shift inside conv3's operand
                                   load (gather form: bit-identical, never stores the shifted activation,
                                   but 1.7x slower than the two kernels -- DESIGN 7 -- hence off)
@@ -23,6 +25,7 @@ class Switches:
     pointwise: str = "auto"          # "auto" | "0" | "all"
     fused_eval: bool = True
     fused_shift_gemm: bool = False
+    fused_train: bool = True
 
     @staticmethod
     def from_env(env=None):
@@ -32,7 +35,8 @@ class Switches:
             raise ValueError("RK_PW must be auto, 0 or all (got %r)" % pw)
         return Switches(fused_bn=env.get("RK_FUSED_BN", "1") != "0", pointwise=pw,
                         fused_eval=env.get("RK_FUSED_EVAL", "1") != "0",
-                        fused_shift_gemm=env.get("RK_F1", "0") == "1")
+                        fused_shift_gemm=env.get("RK_F1", "0") == "1",
+                        fused_train=env.get("RK_FUSED_TRAIN", "1") != "0")
 
 
 _current = Switches.from_env()

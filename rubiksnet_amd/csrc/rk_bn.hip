@@ -240,6 +240,169 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Training-mode fusion with the 1x1 GEMMs (rk_pw.hip, PwTrain): the statistics pass and the backward's reduction pass
+// are done by the GEMM that produces the tensor, one partial per (channel, 128-column wave tile); the kernels below
+// finish them.  One workgroup per channel, fp64 combination in a fixed order (deterministic).
+//
+// forward: stats[c][j] = (pivot_j, sum(y - pivot_j), sum((y - pivot_j)^2), -) over the n_j columns of tile j
+// (n_j = 128 except in the last tile).  With K = pivot_0:  sum(y - K) = s_j + n_j (p_j - K),
+// sum((y - K)^2) = q_j + 2 (p_j - K) s_j + n_j (p_j - K)^2 -- then exactly k_bn_apply's arithmetic: mean, biased variance,
+// invstd, the affine map (a, b) of y = a x + b, and nn.BatchNorm2d's running-statistics bookkeeping.
+__global__ __launch_bounds__(kBlock) void k_bn_finish_tiles(const float4* __restrict__ stats, int J, long long count,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                            float* __restrict__ a_out, float* __restrict__ b_out, float eps,
+                                                            float momentum, long long* __restrict__ num_batches_tracked) {
+    __shared__ double red[2][kBlock / kWave];
+    const int c = blockIdx.x;
+    const float4* p = stats + (size_t)c * J;
+    const double K = (double)p[0].x;
+    const long long last_n = count - 128LL * (J - 1);
+    double s1 = 0, s2 = 0;
+    for (int j = threadIdx.x; j < J; j += kBlock) {
+        const float4 t = p[j];
+        const double n = (j == J - 1) ? (double)last_n : 128.0;
+        const double dp = (double)t.x - K;
+        s1 += (double)t.y + n * dp;
+        s2 += (double)t.z + 2.0 * dp * (double)t.y + n * dp * dp;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S1 = 0, S2 = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        const double M = (double)count;
+        const double ms = S1 / M;
+        double var = S2 / M - ms * ms;
+        var = var < 0 ? 0 : var;
+        const float mean = (float)(K + ms);
+        const float invstd = 1.0f / sqrtf((float)var + eps);
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        float a, b;
+        affine(gamma[c], beta[c], mean, invstd, a, b);
+        a_out[c] = a;
+        b_out[c] = b;
+        if (running_mean) {
+            const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    }
+}
+
+// backward: bred[c][j] = (sum dz, sum dz xhat) of tile j -> the two per-channel constants of BatchNorm's d(x),
+// k1 = sum(dz) / M, k2 = sum(dz xhat) / M, and d(beta) = sum(dz), d(gamma) = sum(dz xhat).
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_finish_tiles(const float2* __restrict__ bred, int J, long long count,
+                                                                float* __restrict__ k12, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int C) {
+    __shared__ double red[2][kBlock / kWave];
+    const int c = blockIdx.x;
+    const float2* p = bred + (size_t)c * J;
+    double s1 = 0, s2 = 0;
+    for (int j = threadIdx.x; j < J; j += kBlock) {
+        const float2 t = p[j];
+        s1 += (double)t.x;
+        s2 += (double)t.y;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S1 = 0, S2 = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        dbeta[c] = (float)S1;
+        dgamma[c] = (float)S2;
+        k12[c] = (float)(S1 / (double)count);
+        k12[C + c] = (float)(S2 / (double)count);
+    }
+}
+
+// y = relu?(a[c] x + b[c]) with a GIVEN affine map (the training forward after k_bn_finish_tiles)
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(kBlock) void k_bn_apply_affine(const T* __restrict__ x, const float* __restrict__ av,
+                                                            const float* __restrict__ bv, T* __restrict__ y, BnDims d) {
+    const Where w = where_am_i(d);
+    const float a = av[w.c], b = bv[w.c];
+    sweep<VEC>(d, w, [&](size_t o) {
+        float v[VEC];
+        Pack<T, VEC>::load(x + o, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float t = fmaf(a, v[e], b);
+            v[e] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        Pack<T, VEC>::store(y + o, v);
+    });
+}
+
+// dx = a (dz - k1 - xhat k2) (+ skip) with dz ALREADY masked by the ReLU and k1, k2 given (k_bn_bwd_finish_tiles)
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre(const T* __restrict__ dz, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, const float* __restrict__ k12,
+                                                          const T* __restrict__ skip, T* __restrict__ dx, BnDims d) {
+    const Where w = where_am_i(d);
+    const float mean = save_mean[w.c], invstd = save_invstd[w.c];
+    const float a = gamma[w.c] * invstd;
+    const float k1 = k12[w.c], k2 = k12[d.C + w.c];
+    sweep<VEC>(d, w, [&](size_t o) {
+        float xv[VEC], gv[VEC];
+        Pack<T, VEC>::load(x + o, xv);
+        Pack<T, VEC>::load(dz + o, gv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xh = (xv[e] - mean) * invstd;
+            gv[e] = a * (gv[e] - k1 - xh * k2);
+        }
+        if (skip) {
+            float sv[VEC];
+            Pack<T, VEC>::load(skip + o, sv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gv[e] += sv[e];
+        }
+        Pack<T, VEC>::store(dx + o, gv);
+    });
+}
+
+// the tile statistics of a tensor nobody's epilogue produced them for (the first block after an unfused stem, tests):
+// same float4 format, one wave per (channel, group of tiles)
+__global__ __launch_bounds__(kBlock) void k_bn_tile_stats(const float* __restrict__ x, float4* __restrict__ stats, int C,
+                                                          int P, int J, long long count) {
+    const long long wave = (long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= (long long)C * J) return;
+    const int c = (int)(wave % C);
+    const long long j = wave / C;
+    // tile j = columns [128 j, 128 j + 128) of the flattened (f, p) index; a lane takes 2 consecutive columns
+    const long long n0 = 128 * j + 2 * lane;
+    float v0 = 0.f, v1 = 0.f;
+    const bool on = n0 < count;                              // (count % 4 == 0: both columns or neither)
+    if (on) {
+        const long long f = n0 / P;
+        const int p = (int)(n0 - f * P);
+        const float2 t = *reinterpret_cast<const float2*>(x + ((size_t)f * C + c) * P + p);
+        v0 = t.x; v1 = t.y;
+    }
+    const float piv = __shfl(v0, 0);
+    float s1 = 0.f, s2 = 0.f;
+    if (on) {
+        float t = v0 - piv; s1 += t; s2 = fmaf(t, t, s2);
+        t = v1 - piv; s1 += t; s2 = fmaf(t, t, s2);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) stats[(size_t)c * J + j] = make_float4(piv, s1, s2, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
 int make_bn(BnDims& d, int F, int C, int P) {
     if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;
     if ((long long)F * C * P > 0x7fffffffLL * 4) return RK_ERR_BAD_DIMS;
@@ -327,6 +490,73 @@ extern "C" {
 size_t rk_bn_workspace_bytes(int F, int C, int P) {
     BnDims d;
     return make_bn(d, F, C, P) ? 0 : ws_bn(d);
+}
+
+// ---- training-mode fusion with the GEMM epilogues (k_bn_finish_tiles & co. above) ----
+// stats: float4 [C][tiles] from rk_pw_gemm_stats_f32 / rk_stem_conv3x3s2_stats_f32 / rk_bn_tile_stats_f32 over `count` =
+// F * P elements per channel.  Writes save_mean / save_invstd / the affine map (a, b) [C] and updates the running
+// statistics (NULL: not tracked) and *num_batches_tracked (NULL: not counted), as nn.BatchNorm2d's training forward.
+int rk_bn_finish_tiles_f32(const void* stats, int tiles, long long count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* a,
+                           float* b, int C, float eps, float momentum, long long* num_batches_tracked,
+                           rk_stream_t stream) {
+    if (!stats || !gamma || !beta || !save_mean || !save_invstd || !a || !b) return RK_ERR_NULL_POINTER;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RK_ERR_NULL_POINTER;
+    if (C <= 0 || tiles <= 0 || count <= 128LL * (tiles - 1) || count > 128LL * tiles) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_bn_finish_tiles, dim3(C), dim3(kBlock), 0, (hipStream_t)stream, (const float4*)stats, tiles, count,
+                       gamma, beta, running_mean, running_var, save_mean, save_invstd, a, b, eps, momentum,
+                       num_batches_tracked);
+    return launch_status();
+}
+// x [F, C, P] fp32, P % 2 == 0 and F * P % 4 == 0 -> stats float4 [C][rk_pw_tiles(F, P)]
+int rk_bn_tile_stats_f32(const float* x, void* stats, int F, int C, int P, rk_stream_t stream) {
+    if (!x || !stats) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || C <= 0 || P <= 0 || P % 2 || ((long long)F * P) % 4 || ((uintptr_t)x & 7)) return RK_ERR_BAD_DIMS;
+    const long long count = (long long)F * P;
+    const int J = (int)((count + 127) / 128);
+    const long long waves = (long long)C * J;
+    hipLaunchKernelGGL(k_bn_tile_stats, dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x,
+                       (float4*)stats, C, P, J, count);
+    return launch_status();
+}
+// y = relu?(a[c] x + b[c])
+int rk_bn_apply_affine_f32(const float* x, const float* a, const float* b, float* y, int F, int C, int P, int relu,
+                           rk_stream_t stream) {
+    if (!x || !a || !b || !y) return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    const dim3 grid(grid_bn(d)), block(kBlock);
+    const bool v4 = vec4_ok<float>(d, x, y);
+#define RK_AA(VEC, RELU) hipLaunchKernelGGL((k_bn_apply_affine<float, VEC, RELU>), grid, block, 0, (hipStream_t)stream, x, a, b, y, d)
+    if (v4) { if (relu) RK_AA(4, true); else RK_AA(4, false); }
+    else { if (relu) RK_AA(1, true); else RK_AA(1, false); }
+#undef RK_AA
+    return launch_status();
+}
+// bred: float2 [C][tiles] from rk_pw_gemm_bnbwd_f32 (or the shift backward) -> k12 [2][C] = (sum dz / count,
+// sum dz xhat / count), d(gamma), d(beta)
+int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, float* k12, float* dgamma, float* dbeta,
+                               int C, rk_stream_t stream) {
+    if (!bred || !k12 || !dgamma || !dbeta) return RK_ERR_NULL_POINTER;
+    if (C <= 0 || tiles <= 0 || count <= 0) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_bn_bwd_finish_tiles, dim3(C), dim3(kBlock), 0, (hipStream_t)stream, (const float2*)bred, tiles,
+                       count, k12, dgamma, dbeta, C);
+    return launch_status();
+}
+// dx = gamma invstd (dz - k1 - xhat k2) (+ skip): dz already ReLU-masked, k12 from rk_bn_bwd_finish_tiles_f32
+int rk_bn_bwd_dx_pre_f32(const float* dz, const float* x, const float* gamma, const float* save_mean,
+                         const float* save_invstd, const float* k12, const float* skip, float* dx, int F, int C, int P,
+                         rk_stream_t stream) {
+    if (!dz || !x || !gamma || !save_mean || !save_invstd || !k12 || !dx) return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    const dim3 grid(grid_bn(d)), block(kBlock);
+    const bool v4 = vec4_ok<float>(d, x, dz, dx) && !((uintptr_t)skip & 15);
+    if (v4) hipLaunchKernelGGL((k_bn_bwd_dx_pre<float, 4>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
+                               save_invstd, k12, skip, dx, d);
+    else hipLaunchKernelGGL((k_bn_bwd_dx_pre<float, 1>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
+                            save_invstd, k12, skip, dx, d);
+    return launch_status();
 }
 
 #define RK_DEF_BN(SFX, TYPE, CTYPE)                                                                               \

@@ -83,6 +83,43 @@ struct PwFuse {
     int relu_in, relu_out;
 };
 
+// Training-mode fusions of the block's BatchNorms into the GEMM epilogue (rubiksnet/backbone.py:
+// 123-135).  A wave tile is 64 rows x 128 columns; tile j = the wave's index along the columns.
+//   EPI = 1 (forward): the statistics pass of the BatchNorm that CONSUMES Y (bn2 after conv2, the next block's bn1 after
+//     conv3 + shortcut) is done on the result tile while it is still in registers: per (row m, tile j) one float4
+//     (pivot, sum(y - pivot), sum((y - pivot)^2), -) with pivot = the row's first value in the tile -- the shifted-data
+//     form k_bn_stats uses, so E[y^2] - mean^2 never cancels -- written to stats[m][j]; k_bn_finish_tiles (rk_bn.hip)
+//     combines the J tiles of a channel in fp64.  k_bn_stats (one full read of Y) disappears.
+//   EPI = 2 (d(input) of conv2 = gradient of relu(bn1(x))): the result tile is the gradient da of the activation; with x
+//     read at the same positions the ReLU mask and xhat are recomputed, Y receives dz = da * [a x + b > 0] and the tile's
+//     (sum dz, sum dz * xhat) go to bred[m][j]: k_bn_bwd_reduce (one full read of da and x) becomes one read of x here.
+struct PwTrain {
+    float4* stats;                                        // EPI 1: [M][J]
+    float2* bred;                                         // EPI 2: [M][J]
+    const float* bx;                                      // EPI 2: the BatchNorm's input x, [F, M, P]
+    const float* ba; const float* bb; const float* bmean; const float* binv;    // EPI 2: [M] each
+    int J;
+};
+
+// Sum v[idx] over the 32 lanes that share (lane >> 5), for 64 values at once, in 62 shuffles instead of 64 x 5: at each
+// of the 5 butterfly levels a lane keeps one half of its values and hands the other half to its partner.  Afterwards
+// lane l holds in v[0], v[1] the totals of idx = 2 (l & 31) and 2 (l & 31) + 1.  Fixed order: deterministic.
+__device__ __forceinline__ void halfwave_transpose_sum64(float (&v)[64], int l31) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int mask = 16 >> st, half = 32 >> st;
+        const bool up = (l31 & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i < half) {
+                const float keep = up ? v[i + half] : v[i];
+                const float send = up ? v[i] : v[i + half];
+                v[i] = keep + __shfl_xor(send, mask);
+            }
+        }
+    }
+}
+
 // A chunk -> registers (global, L2-resident) -> LDS image As[kk][m], m < MT, zero padded
 template <int MT, int kKC>
 struct AStage {
@@ -121,9 +158,10 @@ struct AStage {
 // reference's trilinear tree (rk3d_generic.hpp trilerp, contraction off), so the B fragments are bit-identical to what
 // the shift kernels would have written and Y is bit-identical to "shift, then this GEMM"; the shifted activation is
 // never stored.
-template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0, bool SHIFT = false>
+template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0, bool SHIFT = false, int EPI = 0>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
-                                                    const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz) {
+                                                    const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz,
+                                                    PwTrain tr) {
     using Raw = typename Px4<T>::Raw;
     constexpr int MT = 64 * WM, WN = 4 / WM;
     __shared__ float As[2][kKC * MT];
@@ -240,7 +278,59 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
         if (more) ast.deposit(As[(c + 1) & 1]);
     }
 
-    if (valid) {
+    if constexpr (EPI != 0 && std::is_same<T, float>::value && S2 != 2) {
+        // training epilogues (PwTrain above).  Every lane walks every row: the shuffles need the whole wave.
+        float sv[64];
+        float mypiv = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 16 * b + r;
+                const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const bool on = valid && gm < d.M;
+                const size_t at = (size_t)(yp - Y) + (size_t)(on ? gm : 0) * d.P;
+                float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                if (R && on) {
+                    const float4 t = *reinterpret_cast<const float4*>(R + at);
+                    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+                }
+                if constexpr (EPI == 1) {
+                    const float piv = __shfl(o.x, kh << 5);           // the row's first column in this tile (always valid)
+                    if (l31 == i) mypiv = piv;
+                    float s1 = 0.f, s2 = 0.f;
+                    if (on) {
+                        float t;
+                        t = o.x - piv; s1 += t; s2 = fmaf(t, t, s2);
+                        t = o.y - piv; s1 += t; s2 = fmaf(t, t, s2);
+                        t = o.z - piv; s1 += t; s2 = fmaf(t, t, s2);
+                        t = o.w - piv; s1 += t; s2 = fmaf(t, t, s2);
+                    }
+                    sv[2 * i] = s1; sv[2 * i + 1] = s2;
+                } else {
+                    float s1 = 0.f, s2 = 0.f;
+                    if (on) {
+                        const float4 xv = *reinterpret_cast<const float4*>(tr.bx + at);
+                        const float pa = tr.ba[gm], pb = tr.bb[gm], mu = tr.bmean[gm], iv = tr.binv[gm];
+                        o.x = fmaf(pa, xv.x, pb) <= 0.f ? 0.f : o.x;  s1 += o.x;  s2 = fmaf(o.x, (xv.x - mu) * iv, s2);
+                        o.y = fmaf(pa, xv.y, pb) <= 0.f ? 0.f : o.y;  s1 += o.y;  s2 = fmaf(o.y, (xv.y - mu) * iv, s2);
+                        o.z = fmaf(pa, xv.z, pb) <= 0.f ? 0.f : o.z;  s1 += o.z;  s2 = fmaf(o.z, (xv.z - mu) * iv, s2);
+                        o.w = fmaf(pa, xv.w, pb) <= 0.f ? 0.f : o.w;  s1 += o.w;  s2 = fmaf(o.w, (xv.w - mu) * iv, s2);
+                    }
+                    sv[2 * i] = s1; sv[2 * i + 1] = s2;
+                }
+                if (on) *reinterpret_cast<float4*>(Y + at) = o;
+            }
+        halfwave_transpose_sum64(sv, l31);
+        // lane l31 now holds row i = l31 of its half: b = l31 >> 4, r = l31 & 15
+        const int rr = l31 & 15;
+        const int gmi = m0 + wm * 64 + 32 * (l31 >> 4) + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+        const long long tj = (long long)blockIdx.x * WN + wn;
+        if (gmi < d.M && tj * 128 < d.ntot) {
+            if constexpr (EPI == 1) tr.stats[(size_t)gmi * tr.J + tj] = make_float4(mypiv, sv[0], sv[1], 0.f);
+            else tr.bred[(size_t)gmi * tr.J + tj] = make_float2(sv[0], sv[1]);
+        }
+    } else if (valid) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -429,6 +519,35 @@ struct WgDims {
     int S;                               // pixel chunks
     int chunk;                           // pixels per chunk (multiple of kNB)
     int Cin, Hin, Win, Wo;               // STEM mode only: X is the image [F, Cin, Hin, Win], K = 9 Cin, P = Ho * Wo
+    // PRO (training): the X operand is relu?(ka[k] x + kb[k]) of the stored tensor -- the block's relu(bn1(x)) recomputed
+    // on the fly, so that the activation conv2 / the shortcut saw in the forward never has to be stored
+    const float* ka; const float* kb; int relu_in;
+};
+
+// prologue coefficients of a lane's rows of the X tile (fixed for the whole pixel loop)
+template <int NJ>
+struct RowAffine {
+    float a[NJ], b[NJ];
+    __device__ __forceinline__ void load(const WgDims& d, int r0, int rstep, int rsub) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = r0 + rstep * j + rsub;
+            const bool ok = r < d.K;
+            a[j] = ok ? d.ka[r] : 0.f;
+            b[j] = ok ? d.kb[r] : 0.f;
+        }
+    }
+    // rows past K and pixels past the range were fetched as zeros and must stay zeros (relu(b) != 0)
+    __device__ __forceinline__ void apply(float4 (&v)[NJ], const WgDims& d, int r0, int rstep, int rsub, bool nok) const {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool ok = nok && r0 + rstep * j + rsub < d.K;
+            float4 t = v[j];
+            t.x = fmaf(a[j], t.x, b[j]); t.y = fmaf(a[j], t.y, b[j]); t.z = fmaf(a[j], t.z, b[j]); t.w = fmaf(a[j], t.w, b[j]);
+            if (d.relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+            v[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 };
 
 // this lane's position in the pixel stream: n = (f, p); advanced 32 pixels per tile without dividing
@@ -507,7 +626,7 @@ __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     }
 }
 
-template <typename T, bool STEM = false, bool S2 = false>
+template <typename T, bool STEM = false, bool S2 = false, bool PRO = false>
 __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, const T* __restrict__ X,
                                                      float* __restrict__ ws, WgDims d) {
     __shared__ float tiles[4][2][64 * kNB];
@@ -546,10 +665,13 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
     float4 va[8], vb[8];
     PixCursor cur;
     cur.init(n0, d.P);
+    RowAffine<PRO ? 8 : 1> pro;
+    if constexpr (PRO) pro.load(d, 64 * kb, 8, lane >> 3);
     wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);
     if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
     else if constexpr (S2 && std::is_same<T, float>::value) wg_fetch_s2(X, d, 64 * kb, cur, nend, vb);
     else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
+    if constexpr (PRO) pro.apply(vb, d, 64 * kb, 8, lane >> 3, cur.n < nend);
     const int steps = per / kNB;                                // same for every wave: barriers stay uniform
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
@@ -562,6 +684,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
         if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
         else if constexpr (S2 && std::is_same<T, float>::value) wg_fetch_s2(X, d, 64 * kb, cur, nend, vb);
         else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
+        if constexpr (PRO) pro.apply(vb, d, 64 * kb, 8, lane >> 3, cur.n < nend);
 #pragma unroll
         for (int s = 0; s < kNB / 2; ++s) {
             const float a0 = ta[tile_at(l31, 2 * s + kh)], a1 = ta[tile_at(32 + l31, 2 * s + kh)];
@@ -619,7 +742,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
 // Against four independent wave tasks this halves the loads and LDS writes per MFMA and -- what matters for
 // 144 / 288 / 576 channels -- halves how many times each operand row is re-read across the grid (a 64-row
 // block of dY is needed by every 64-column block of X: [256,288,14,14] re-read 2 x 5 x 58 MB through L2).
-template <typename T>
+template <typename T, bool PRO = false>
 __global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ dY, const T* __restrict__ X,
                                                           float* __restrict__ ws, WgDims d) {
     __shared__ float tiles[2][128 * kNB];
@@ -666,8 +789,11 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ 
         }
     };
     float4 va[4], vb[4];
+    RowAffine<PRO ? 4 : 1> pro;
+    if constexpr (PRO) pro.load(d, 128 * kt, 32, (int)(threadIdx.x >> 3));
     fetch(dY, d.M, 128 * mt, d.M, va);
     fetch(X, d.K, 128 * kt, d.K, vb);
+    if constexpr (PRO) pro.apply(vb, d, 128 * kt, 32, (int)(threadIdx.x >> 3), cur.n < nend);
     const int steps = d.chunk / kNB;
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
@@ -678,6 +804,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ 
         cur.advance(d.P);
         fetch(dY, d.M, 128 * mt, d.M, va);
         fetch(X, d.K, 128 * kt, d.K, vb);
+        if constexpr (PRO) pro.apply(vb, d, 128 * kt, 32, (int)(threadIdx.x >> 3), cur.n < nend);
         if (a0_on && b0_on) {
 #pragma unroll
             for (int s = 0; s < kNB / 2; ++s) {
@@ -717,6 +844,7 @@ inline bool use_wide(int M, int K) {
 inline int make_wg_wide(WgDims& d, int F, int K, int M, int P) {
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0) return RK_ERR_BAD_DIMS;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
+    d.ka = d.kb = nullptr; d.relu_in = 0;
     d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
     const int pairs = ((M + 127) / 128) * ((K + 127) / 128);
     constexpr int want = 768;                                         // workgroups (3 per CU)
@@ -891,6 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_reduce(const float* __restr
 inline int make_wg(WgDims& d, int F, int K, int M, int P) {
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0) return RK_ERR_BAD_DIMS;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
+    d.ka = d.kb = nullptr; d.relu_in = 0;
     d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
     // ~1536 wave tasks (6 per CU), but keep the partials (S * M * K floats, written and read once) under a
     // quarter of the operands' bytes
@@ -917,7 +1046,7 @@ namespace {
 
 template <typename T>
 int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int K, int M, int P, int a_is_mk,
-            rk_stream_t stream_, const PwFuse* fuse = nullptr) {
+            rk_stream_t stream_, const PwFuse* fuse = nullptr, const PwTrain* train = nullptr, int epi = 0) {
     const T* X = (const T*)X_; const T* R = (const T*)R_; T* Y = (T*)Y_;
     if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
     const uintptr_t am = 4 * sizeof(T) - 1;
@@ -952,8 +1081,25 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     }
     const bool fused = fuse && (fuse->ka || fuse->ma);
     PwFuse fz = fused ? *fuse : PwFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
-#define RK_PW_GO(WMV, KCV) do { if (fused) hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV, true>), grid, block, 0, stream, A, X, R, Y, d, fz); \
-                                else hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV, false>), grid, block, 0, stream, A, X, R, Y, d, fz); } while (0)
+    PwTrain tr = train ? *train : PwTrain{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if constexpr (std::is_same<T, float>::value) {
+        if (epi) {                                           // training epilogues (fp32): statistics of Y / BN-backward sums
+            if (epi == 1 ? !tr.stats : !(tr.bred && tr.bx && tr.ba && tr.bb && tr.bmean && tr.binv)) return RK_ERR_NULL_POINTER;
+            if (fz.ma || (long long)tr.J * 128 < d.ntot) return RK_ERR_BAD_DIMS;
+            if (epi == 2 && ((uintptr_t)tr.bx & am)) return RK_ERR_BAD_DIMS;
+#define RK_PW_EP(WMV, KCV, FU, EP) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, FU, false, 0, false, EP>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
+#define RK_PW_EK(WMV, FU, EP) do { if (kc == 12) RK_PW_EP(WMV, 12, FU, EP); else RK_PW_EP(WMV, 16, FU, EP); } while (0)
+#define RK_PW_EW(FU, EP) do { if (wm == 1) RK_PW_EK(1, FU, EP); else RK_PW_EK(2, FU, EP); } while (0)
+            if (epi == 1) { if (fused) RK_PW_EW(true, 1); else RK_PW_EW(false, 1); }
+            else RK_PW_EW(false, 2);
+#undef RK_PW_EW
+#undef RK_PW_EK
+#undef RK_PW_EP
+            return launch_status();
+        }
+    }
+#define RK_PW_GO(WMV, KCV) do { if (fused) hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV, true>), grid, block, 0, stream, A, X, R, Y, d, fz, tr); \
+                                else hipLaunchKernelGGL((k_pw_gemm<T, WMV, KCV, false>), grid, block, 0, stream, A, X, R, Y, d, fz, tr); } while (0)
 #define RK_PW_KC(WMV) do { if (kc == 12) RK_PW_GO(WMV, 12); else RK_PW_GO(WMV, 16); } while (0)
     if (wm == 1) RK_PW_KC(1);
     else if (wm == 2) RK_PW_KC(2);
@@ -965,7 +1111,7 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
 
 template <typename T>
 int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
-             rk_stream_t stream_) {
+             rk_stream_t stream_, const float* ka = nullptr, const float* kb = nullptr, int relu_in = 0) {
     const T* dY = (const T*)dY_; const T* X = (const T*)X_;
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
     WgDims d;
@@ -981,9 +1127,15 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
     float* part2 = part + (size_t)d.S * M * K;
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
+    const bool pro = ka && kb;
+    d.ka = ka; d.kb = kb; d.relu_in = relu_in;
+    if (pro && std::is_same<T, __hip_bfloat16>::value) return RK_ERR_BAD_DIMS;      // prologue: fp32 activations only
     if (wide) {
         const int pairs = ((M + 127) / 128) * ((K + 127) / 128);
-        hipLaunchKernelGGL((k_pw_wgrad_wide<T>), dim3((unsigned)(d.S * pairs)), dim3(kBlock), 0, stream, dY, X, part, d);
+        if (pro) hipLaunchKernelGGL((k_pw_wgrad_wide<T, true>), dim3((unsigned)(d.S * pairs)), dim3(kBlock), 0, stream, dY, X, part, d);
+        else hipLaunchKernelGGL((k_pw_wgrad_wide<T>), dim3((unsigned)(d.S * pairs)), dim3(kBlock), 0, stream, dY, X, part, d);
+    } else if (pro) {
+        hipLaunchKernelGGL((k_pw_wgrad<T, false, false, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     } else if constexpr (std::is_same<T, __hip_bfloat16>::value) {
         hipLaunchKernelGGL(k_pw_wgrad_bf16, dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     } else {
@@ -1020,8 +1172,8 @@ int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F
 }
 // 3x3 / stride 2 / pad 1 convolution, no bias (the stem): W [Cout][Cin][3][3], X [F, Cin, Hin, Win], Y [F, Cout, Ho, Wo],
 // Ho = Hin / 2, Wo = Win / 2 (Hin even, Win % 8 == 0, 9 Cin <= 64).  Same GEMM, im2col gathered on the fly.
-int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
-                          rk_stream_t stream_) {
+static int stem_conv(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                     rk_stream_t stream_, float4* stats, int J) {
     if (!W || !X || !Y) return RK_ERR_NULL_POINTER;
     if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || 9 * Cin > 64) return RK_ERR_BAD_DIMS;
     if ((uintptr_t)Y & 15) return RK_ERR_BAD_DIMS;
@@ -1035,10 +1187,30 @@ int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int C
     hipStream_t stream = (hipStream_t)stream_;
     const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
     const float* R = nullptr;
-    if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
-    else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
-    else hipLaunchKernelGGL((k_pw_gemm<float, 4, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz);
+    if (stats) {                                          // + the statistics of Y for the first block's bn1 (PwTrain)
+        if ((long long)J * 128 < d.ntot) return RK_ERR_BAD_DIMS;
+        const PwTrain tr{stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, J};
+        if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true, 0, false, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
+        else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true, 0, false, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
+        else return RK_ERR_BAD_DIMS;
+        return launch_status();
+    }
+    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
+    else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
+    else hipLaunchKernelGGL((k_pw_gemm<float, 4, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
     return launch_status();
+}
+int rk_stem_conv3x3s2_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                          rk_stream_t stream) {
+    return stem_conv(W, X, Y, F, Cin, Cout, Hin, Win, stream, nullptr, 0);
+}
+// the same convolution + the tile statistics of Y for the BatchNorm that follows (EPI = 1 of k_pw_gemm; `stats` holds
+// Cout x rk_pw_tiles(F, Ho * Wo) float4; Cout <= 128)
+int rk_stem_conv3x3s2_stats_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                                void* stats, int tiles, rk_stream_t stream) {
+    if (!stats) return RK_ERR_NULL_POINTER;
+    return stem_conv(W, X, Y, F, Cin, Cout, Hin, Win, stream, (float4*)stats, tiles);
 }
 // d(weight) of the same stem convolution: dW [Cout][Cin][3][3] = sum over frames and output pixels of dY x im2col(X);
 // dY [F, Cout, Ho, Wo], X [F, Cin, Hin, Win]; ws of rk_pw_wgrad_workspace_bytes(F, 9 Cin, Cout, Ho * Wo) bytes.
@@ -1085,7 +1257,8 @@ static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, 
     hipStream_t stream = (hipStream_t)stream_;
     const PwFuse fz = fuse ? *fuse : PwFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
     const float* R = nullptr;
-#define RK_S2_GO(WMV, MODE, FU) hipLaunchKernelGGL((k_pw_gemm<float, WMV, 12, FU, false, MODE>), grid, block, 0, stream, A, X, R, Y, d, fz)
+    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+#define RK_S2_GO(WMV, MODE, FU) hipLaunchKernelGGL((k_pw_gemm<float, WMV, 12, FU, false, MODE>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
     if (mode == 1 && fuse) { if (wm == 1) RK_S2_GO(1, 1, true); else RK_S2_GO(2, 1, true); }
     else if (mode == 1) { if (wm == 1) RK_S2_GO(1, 1, false); else RK_S2_GO(2, 1, false); }
     else { if (wm == 1) RK_S2_GO(1, 2, false); else RK_S2_GO(2, 2, false); }
@@ -1108,8 +1281,8 @@ int rk_pw_s2_dgrad_f32(const float* W, const float* dY, float* dX, int F, int Ci
                        rk_stream_t stream) {
     return pw_s2(W, dY, dX, F, Cout, Cin, Hin, Win, 2, 0, stream);     // W read as [K=Cout][M=Cin]
 }
-int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* ws,
-                       size_t ws_bytes, rk_stream_t stream_) {
+static int pw_s2_wgrad(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* ws,
+                       size_t ws_bytes, rk_stream_t stream_, const float* ka, const float* kb, int relu_in) {
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
     if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8) return RK_ERR_BAD_DIMS;
     if ((uintptr_t)dY & 15) return RK_ERR_BAD_DIMS;
@@ -1124,7 +1297,9 @@ int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Ci
     float* part2 = part + (size_t)d.S * M * K;
     const int MK = M * K;
     const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_pw_wgrad<float, false, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    d.ka = ka; d.kb = kb; d.relu_in = relu_in;
+    if (ka && kb) hipLaunchKernelGGL((k_pw_wgrad<float, false, true, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    else hipLaunchKernelGGL((k_pw_wgrad<float, false, true>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
     if (d.S > kRedDirect) {
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
@@ -1132,6 +1307,16 @@ int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Ci
         hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
     }
     return launch_status();
+}
+int rk_pw_s2_wgrad_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* ws,
+                       size_t ws_bytes, rk_stream_t stream) {
+    return pw_s2_wgrad(dY, X, dW, F, Cin, Cout, Hin, Win, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+// training: the same d(weight) with X = relu?(ka x + kb) recomputed on the fly (the strided shortcut reads relu(bn1(x)))
+int rk_pw_s2_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                           const float* ka, const float* kb, int relu_in, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!ka || !kb) return RK_ERR_NULL_POINTER;
+    return pw_s2_wgrad(dY, X, dW, F, Cin, Cout, Hin, Win, ws, ws_bytes, stream, ka, kb, relu_in);
 }
 // SURVEY 8(f) f1, inference: Y[f] = A RubiksShift3D(X)[f] (+ R[f]) with the shift (stride 1 / pad 0, no quantize) applied
 // in the operand load -- the conv3 of a block fed by its as3 shift, plus the residual.  X [N*T, K, H, W], shift [3][K],
@@ -1151,7 +1336,8 @@ int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, c
     hipStream_t stream = (hipStream_t)stream_;
     const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
     const int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;       // the plain GEMM's choice: same k order
-#define RK_SH_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, false, false, 0, true>), grid, block, 0, stream, A, X, R, Y, d, fz)
+    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+#define RK_SH_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, false, false, 0, true>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
     if (wm == 1) { if (kc == 12) RK_SH_GO(1, 12); else RK_SH_GO(1, 16); }
     else { if (kc == 12) RK_SH_GO(2, 12); else RK_SH_GO(2, 16); }
 #undef RK_SH_GO
@@ -1174,10 +1360,42 @@ int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* 
     const PwFuse fz{ka, kb, ma, mb, relu_in, relu_out};
     return pw_gemm<float>(A, X, R, Y, F, K, M, P, a_is_mk, stream, &fz);
 }
+// ---- training-mode fusions (PwTrain) ----
+// number of 128-column wave tiles of an [F, *, P] tensor = the J of the tile-partial arrays below
+int rk_pw_tiles(int F, int P) {
+    if (F <= 0 || P <= 0) return 0;
+    return (int)(((long long)F * P + 127) / 128);
+}
+// forward of a block's conv2 / conv3 in training: Y[f] = A relu?(ka x + kb)(X[f]) (+ R[f]), and the tile statistics of Y
+// (float4 [M][tiles]) for the BatchNorm that consumes Y.  ka / kb NULL: no prologue.
+int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                         int a_is_mk, const float* ka, const float* kb, int relu_in, void* stats, int tiles,
+                         rk_stream_t stream) {
+    if ((ka == nullptr) != (kb == nullptr)) return RK_ERR_NULL_POINTER;
+    const PwFuse fz{ka, kb, nullptr, nullptr, relu_in, 0};
+    const PwTrain tr{(float4*)stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tiles};
+    return pw_gemm<float>(A, X, R, Y, F, K, M, P, a_is_mk, stream, &fz, &tr, 1);
+}
+// d(input) of conv2 in training, fused with the first half of bn1's backward: da = A dY (+ R) is masked with
+// [ba x + bb > 0] (x = bn1's input) on its way out -> dZ, and the tile sums (sum dz, sum dz xhat) go to bred (float2
+// [M][tiles]); xhat = (x - mean) invstd.
+int rk_pw_gemm_bnbwd_f32(const float* A, const float* dY, const float* R, float* dZ, int F, int K, int M, int P,
+                         int a_is_mk, const float* x, const float* ba, const float* bb, const float* mean,
+                         const float* invstd, void* bred, int tiles, rk_stream_t stream) {
+    const PwTrain tr{nullptr, (float2*)bred, x, ba, bb, mean, invstd, tiles};
+    return pw_gemm<float>(A, dY, R, dZ, F, K, M, P, a_is_mk, stream, nullptr, &tr, 2);
+}
+
 // dW[M][K] (fp32) = sum_f dY[f] X[f]^T.  dY [F,M,P], X [F,K,P] fp32 or bf16, P % 4 == 0.
 int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
                     size_t ws_bytes, rk_stream_t stream) {
     return pw_wgrad<float>(dY, X, dW, F, K, M, P, ws, ws_bytes, stream);
+}
+// training: d(weight) of conv2 with X = relu?(ka x + kb) recomputed from the block's input (fp32)
+int rk_pw_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, const float* ka,
+                        const float* kb, int relu_in, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!ka || !kb) return RK_ERR_NULL_POINTER;
+    return pw_wgrad<float>(dY, X, dW, F, K, M, P, ws, ws_bytes, stream, ka, kb, relu_in);
 }
 int rk_pw_wgrad_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws,
                      size_t ws_bytes, rk_stream_t stream) {

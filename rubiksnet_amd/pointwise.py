@@ -373,20 +373,32 @@ def fused_eval_block(block, x):
 
 class _StemFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, with_stats=False):
         Fr, Cin, H, W = x.shape
         Cout = weight.shape[0]
         y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
         dev = x.device
+        L = _native.lib()
+        stats = None
         with torch.cuda.device(dev):
-            rc = _native.lib().rk_stem_conv3x3s2_f32(weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W,
-                                                     torch.cuda.current_stream(dev).cuda_stream)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if with_stats:
+                # training: the statistics pass of the first block's bn1 rides on this GEMM's epilogue (train_block.py)
+                J = int(L.rk_pw_tiles(Fr, (H // 2) * (W // 2)))
+                stats = torch.empty(Cout, J, 4, dtype=torch.float32, device=dev)
+                rc = L.rk_stem_conv3x3s2_stats_f32(weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W,
+                                                   stats.data_ptr(), J, stream)
+            else:
+                rc = L.rk_stem_conv3x3s2_f32(weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W, stream)
         _native.check(rc, "rk_stem_conv3x3s2_f32")
         ctx.save_for_backward(x, weight)
+        if with_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         gx = gw = None
@@ -407,7 +419,7 @@ class _StemFunc(torch.autograd.Function):
                 rc = L.rk_stem_wgrad3x3s2_f32(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), Fr, Cin, Cout, H, W,
                                               ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
             _native.check(rc, "rk_stem_wgrad3x3s2_f32")
-        return gx, gw
+        return gx, gw, None
 
 
 def stem_conv(conv, x):
@@ -422,4 +434,11 @@ def stem_conv(conv, x):
           and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
     if not ok:
         return conv(x)
+    sw = config.switches()
+    if (sw.fused_train and sw.fused_bn and conv.training and torch.is_grad_enabled() and conv.out_channels <= 128
+            and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0):
+        from .train_block import _attach_stats
+
+        y, stats = _StemFunc.apply(x.contiguous(), conv.weight, True)
+        return _attach_stats(y, stats)
     return _StemFunc.apply(x.contiguous(), conv.weight)
