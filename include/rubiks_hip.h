@@ -300,6 +300,25 @@ int rk_pw_wgrad_f32(const float* dY, const float* X, float* dW, int F, int K, in
 int rk_pw_wgrad_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws,
                      size_t ws_bytes, rk_stream_t stream);
 
+/* 1x1 convolutions on planes with H * W % 4 != 0 -- the 7x7 planes of layer4 (rubiksnet/backbone.py:164), which the
+ * kernels above cannot take (a row of 49 floats is not 16-byte aligned): the streamed operand goes through LDS as whole
+ * 16-channel frame chunks (contiguous and aligned), see k_pw_gemm_odd.  37 <= P <= 64, K % 4 == 0, fp32.
+ *   rk_pw_gemm_odd_f32     : Y[f] = A X[f] (+ R[f]), forward (a_is_mk = 1) / d(input) (a_is_mk = 0)
+ *   rk_pw_wgrad_odd_f32    : d(weight); workspace rk_pw_wgrad_odd_workspace_bytes(F, K, M, P)
+ *   rk_pw_s2_*_odd_f32     : the 1x1 / stride-2 projecting shortcut onto such planes (14x14 -> 7x7, backbone.py:98-104):
+ *                            forward, d(input) (every element of dX written) and d(weight); Hin, Win even. */
+int rk_pw_gemm_odd_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                       int a_is_mk, rk_stream_t stream);
+size_t rk_pw_wgrad_odd_workspace_bytes(int F, int K, int M, int P);
+int rk_pw_wgrad_odd_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
+                        size_t ws_bytes, rk_stream_t stream);
+int rk_pw_s2_forward_odd_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                             rk_stream_t stream);
+int rk_pw_s2_dgrad_odd_f32(const float* W, const float* dY, float* dX, int F, int Cin, int Cout, int Hin, int Win,
+                           rk_stream_t stream);
+int rk_pw_s2_wgrad_odd_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                           void* ws, size_t ws_bytes, rk_stream_t stream);
+
 /* ---- training-mode fusion of the block's BatchNorms into the 1x1 GEMMs -- rows f1 / f3 of SURVEY 8(f) ----------
  * The reference block (rubiksnet/backbone.py:123-135) is
  *     a1 = relu(bn1(x)); z = conv2(a1); a2 = relu(bn2(z)); s = as3(a2); out = conv3(s) + shortcut
@@ -325,16 +344,16 @@ int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* 
 int rk_stem_conv3x3s2_stats_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
                                 void* stats, int tiles, rk_stream_t stream);
 int rk_pw_gemm_bnbwd_f32(const float* A, const float* dY, const float* R, float* dZ, int F, int K, int M, int P,
-                         int a_is_mk, const float* x, const float* ba, const float* bb, const float* mean,
-                         const float* invstd, void* bred, int tiles, rk_stream_t stream);
+                         int a_is_mk, const float* x, const float* abmi /* [M][4] = (a, b, mean, invstd) */, void* bred,
+                         int tiles, rk_stream_t stream);
 int rk_pw_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, const float* ka,
                         const float* kb, int relu_in, void* ws, size_t ws_bytes, rk_stream_t stream);
 int rk_pw_s2_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
                            const float* ka, const float* kb, int relu_in, void* ws, size_t ws_bytes, rk_stream_t stream);
 int rk_bn_finish_tiles_f32(const void* stats, int tiles, long long count, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* a,
-                           float* b, int C, float eps, float momentum, long long* num_batches_tracked,
-                           rk_stream_t stream);
+                           float* b, float* abmi /* [C][4] packed copy, may be NULL */, int C, float eps, float momentum,
+                           long long* num_batches_tracked, rk_stream_t stream);
 int rk_bn_tile_stats_f32(const float* x, void* stats, int F, int C, int P, rk_stream_t stream);
 int rk_bn_apply_affine_f32(const float* x, const float* a, const float* b, float* y, int F, int C, int P, int relu,
                            rk_stream_t stream);

@@ -53,14 +53,21 @@ SIGNATURES = {
     "rk_pw_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_pw_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_pw_wgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    # planes with H * W % 4 != 0 (7x7)
+    "rk_pw_gemm_odd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rk_pw_wgrad_odd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_pw_wgrad_odd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "rk_pw_s2_forward_odd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rk_pw_s2_dgrad_odd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rk_pw_s2_wgrad_odd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     # training-mode fusion of the block's BatchNorms into the GEMMs (include/rubiks_hip.h)
     "rk_pw_tiles": (_i, [_i, _i]),
     "rk_pw_gemm_stats_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p]),
     "rk_stem_conv3x3s2_stats_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
-    "rk_pw_gemm_bnbwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "rk_pw_gemm_bnbwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
     "rk_pw_wgrad_pro_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _sz, _p]),
     "rk_pw_s2_wgrad_pro_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _sz, _p]),
-    "rk_bn_finish_tiles_f32": (_i, [_p, _i, ctypes.c_longlong, _p, _p, _p, _p, _p, _p, _p, _p, _i, ctypes.c_float,
+    "rk_bn_finish_tiles_f32": (_i, [_p, _i, ctypes.c_longlong, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, ctypes.c_float,
                                     ctypes.c_float, _p, _p]),
     "rk_bn_tile_stats_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "rk_bn_apply_affine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),

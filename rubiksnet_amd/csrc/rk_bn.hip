@@ -248,19 +248,21 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
 // (n_j = 128 except in the last tile).  With K = pivot_0:  sum(y - K) = s_j + n_j (p_j - K),
 // sum((y - K)^2) = q_j + 2 (p_j - K) s_j + n_j (p_j - K)^2 -- then exactly k_bn_apply's arithmetic: mean, biased variance,
 // invstd, the affine map (a, b) of y = a x + b, and nn.BatchNorm2d's running-statistics bookkeeping.
-__global__ __launch_bounds__(kBlock) void k_bn_finish_tiles(const float4* __restrict__ stats, int J, long long count,
+constexpr int kFin = 1024;               // threads of a finisher block: one block per channel, J tiles to sweep
+__global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restrict__ stats, int J, long long count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                            float* __restrict__ a_out, float* __restrict__ b_out, float eps,
+                                                            float* __restrict__ a_out, float* __restrict__ b_out,
+                                                            float4* __restrict__ pack, float eps,
                                                             float momentum, long long* __restrict__ num_batches_tracked) {
-    __shared__ double red[2][kBlock / kWave];
+    __shared__ double red[2][kFin / kWave];
     const int c = blockIdx.x;
     const float4* p = stats + (size_t)c * J;
     const double K = (double)p[0].x;
     const long long last_n = count - 128LL * (J - 1);
     double s1 = 0, s2 = 0;
-    for (int j = threadIdx.x; j < J; j += kBlock) {
+    for (int j = threadIdx.x; j < J; j += kFin) {
         const float4 t = p[j];
         const double n = (j == J - 1) ? (double)last_n : 128.0;
         const double dp = (double)t.x - K;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_finish_tiles(const float4* __rest
     __syncthreads();
     if (threadIdx.x == 0) {
         double S1 = 0, S2 = 0;
-        for (int w = 0; w < kBlock / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        for (int w = 0; w < kFin / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
         const double M = (double)count;
         const double ms = S1 / M;
         double var = S2 / M - ms * ms;
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_finish_tiles(const float4* __rest
         affine(gamma[c], beta[c], mean, invstd, a, b);
         a_out[c] = a;
         b_out[c] = b;
+        if (pack) pack[c] = make_float4(a, b, mean, invstd);
         if (running_mean) {
             const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -298,14 +301,14 @@ __global__ __launch_bounds__(kBlock) void k_bn_finish_tiles(const float4* __rest
 
 // backward: bred[c][j] = (sum dz, sum dz xhat) of tile j -> the two per-channel constants of BatchNorm's d(x),
 // k1 = sum(dz) / M, k2 = sum(dz xhat) / M, and d(beta) = sum(dz), d(gamma) = sum(dz xhat).
-__global__ __launch_bounds__(kBlock) void k_bn_bwd_finish_tiles(const float2* __restrict__ bred, int J, long long count,
-                                                                float* __restrict__ k12, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int C) {
-    __shared__ double red[2][kBlock / kWave];
+__global__ __launch_bounds__(kFin) void k_bn_bwd_finish_tiles(const float2* __restrict__ bred, int J, long long count,
+                                                              float* __restrict__ k12, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int C) {
+    __shared__ double red[2][kFin / kWave];
     const int c = blockIdx.x;
     const float2* p = bred + (size_t)c * J;
     double s1 = 0, s2 = 0;
-    for (int j = threadIdx.x; j < J; j += kBlock) {
+    for (int j = threadIdx.x; j < J; j += kFin) {
         const float2 t = p[j];
         s1 += (double)t.x;
         s2 += (double)t.y;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_finish_tiles(const float2* __
     __syncthreads();
     if (threadIdx.x == 0) {
         double S1 = 0, S2 = 0;
-        for (int w = 0; w < kBlock / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        for (int w = 0; w < kFin / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
         dbeta[c] = (float)S1;
         dgamma[c] = (float)S2;
         k12[c] = (float)(S1 / (double)count);
@@ -498,13 +501,14 @@ size_t rk_bn_workspace_bytes(int F, int C, int P) {
 // statistics (NULL: not tracked) and *num_batches_tracked (NULL: not counted), as nn.BatchNorm2d's training forward.
 int rk_bn_finish_tiles_f32(const void* stats, int tiles, long long count, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* a,
-                           float* b, int C, float eps, float momentum, long long* num_batches_tracked,
+                           float* b, float* abmi, int C, float eps, float momentum, long long* num_batches_tracked,
                            rk_stream_t stream) {
     if (!stats || !gamma || !beta || !save_mean || !save_invstd || !a || !b) return RK_ERR_NULL_POINTER;
     if ((running_mean == nullptr) != (running_var == nullptr)) return RK_ERR_NULL_POINTER;
     if (C <= 0 || tiles <= 0 || count <= 128LL * (tiles - 1) || count > 128LL * tiles) return RK_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(k_bn_finish_tiles, dim3(C), dim3(kBlock), 0, (hipStream_t)stream, (const float4*)stats, tiles, count,
-                       gamma, beta, running_mean, running_var, save_mean, save_invstd, a, b, eps, momentum,
+    if ((uintptr_t)abmi & 15) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_bn_finish_tiles, dim3(C), dim3(kFin), 0, (hipStream_t)stream, (const float4*)stats, tiles, count,
+                       gamma, beta, running_mean, running_var, save_mean, save_invstd, a, b, (float4*)abmi, eps, momentum,
                        num_batches_tracked);
     return launch_status();
 }
@@ -539,7 +543,7 @@ int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, flo
                                int C, rk_stream_t stream) {
     if (!bred || !k12 || !dgamma || !dbeta) return RK_ERR_NULL_POINTER;
     if (C <= 0 || tiles <= 0 || count <= 0) return RK_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(k_bn_bwd_finish_tiles, dim3(C), dim3(kBlock), 0, (hipStream_t)stream, (const float2*)bred, tiles,
+    hipLaunchKernelGGL(k_bn_bwd_finish_tiles, dim3(C), dim3(kFin), 0, (hipStream_t)stream, (const float2*)bred, tiles,
                        count, k12, dgamma, dbeta, C);
     return launch_status();
 }

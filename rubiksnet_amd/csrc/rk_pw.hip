@@ -82,6 +82,7 @@ struct PwFuse {
     const float* ka; const float* kb; const float* ma; const float* mb;
     int relu_in, relu_out;
 };
+constexpr int kProK = 336;               // input channels a prologue supports (320, padded to whole chunks of 12 / 16)
 
 // Training-mode fusions of the block's BatchNorms into the GEMM epilogue (rubiksnet/backbone.py:
 // 123-135).  A wave tile is 64 rows x 128 columns; tile j = the wave's index along the columns.
@@ -97,27 +98,30 @@ struct PwTrain {
     float4* stats;                                        // EPI 1: [M][J]
     float2* bred;                                         // EPI 2: [M][J]
     const float* bx;                                      // EPI 2: the BatchNorm's input x, [F, M, P]
-    const float* ba; const float* bb; const float* bmean; const float* binv;    // EPI 2: [M] each
+    const float4* bpack;                                  // EPI 2: [M] (a, b, mean, invstd) of the BatchNorm
     int J;
 };
 
-// Sum v[idx] over the 32 lanes that share (lane >> 5), for 64 values at once, in 62 shuffles instead of 64 x 5: at each
-// of the 5 butterfly levels a lane keeps one half of its values and hands the other half to its partner.  Afterwards
-// lane l holds in v[0], v[1] the totals of idx = 2 (l & 31) and 2 (l & 31) + 1.  Fixed order: deterministic.
-__device__ __forceinline__ void halfwave_transpose_sum64(float (&v)[64], int l31) {
+// Sum v[idx] over the 32 lanes that share (lane >> 5), for 32 values at once, in 31 shuffles instead of 32 x 5: at each
+// of the 5 butterfly levels a lane keeps one half of its values and hands the other half to its partner (lane distance
+// 16, 8, 4, 2, 1), so that lane l ends up with the total of idx l & 31.  Fixed order: deterministic.
+template <int HALF, int N>
+__device__ __forceinline__ void halfwave_fold(float (&v)[N], int l31) {
+    const bool up = (l31 & (16 * 2 * HALF / N)) != 0;   // level with HALF = N/2 pairs lanes 16 apart, N/4: 8 apart, ...
 #pragma unroll
-    for (int st = 0; st < 5; ++st) {
-        const int mask = 16 >> st, half = 32 >> st;
-        const bool up = (l31 & mask) != 0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (i < half) {
-                const float keep = up ? v[i + half] : v[i];
-                const float send = up ? v[i] : v[i + half];
-                v[i] = keep + __shfl_xor(send, mask);
-            }
-        }
+    for (int i = 0; i < HALF; ++i) {
+        const float keep = up ? v[i + HALF] : v[i];
+        const float send = up ? v[i] : v[i + HALF];
+        v[i] = keep + __shfl_xor(send, 16 * 2 * HALF / N);
     }
+}
+// 32 values per lane, summed over the 32 lanes of a half wave: afterwards lane l holds the total of idx (l & 31) in v[0]
+__device__ __forceinline__ void halfwave_transpose_sum32(float (&v)[32], int l31) {
+    halfwave_fold<16>(v, l31);
+    halfwave_fold<8>(v, l31);
+    halfwave_fold<4>(v, l31);
+    halfwave_fold<2>(v, l31);
+    halfwave_fold<1>(v, l31);
 }
 
 // A chunk -> registers (global, L2-resident) -> LDS image As[kk][m], m < MT, zero padded
@@ -165,6 +169,15 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
     using Raw = typename Px4<T>::Raw;
     constexpr int MT = 64 * WM, WN = 4 / WM;
     __shared__ float As[2][kKC * MT];
+    // prologue coefficients (ka, kb) of every input channel, padded to whole chunks: read per k-step from LDS (two
+    // broadcast reads) -- as global loads inside the MFMA loop they cost 43 us of a 92 us GEMM at [256,54->54,56x56]
+    __shared__ float2 Ks[FUSE ? kProK : 1];
+    if constexpr (FUSE) {
+        if (fz.ka) {
+            for (int k = threadIdx.x; k < kProK; k += kBlock)
+                Ks[k] = k < d.K ? make_float2(fz.ka[k], fz.kb[k]) : make_float2(0.f, 0.f);
+        }                                                   // (visible after the first __syncthreads() of the chunk loop)
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -185,6 +198,16 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
 
     const int s_ho = (STEM || S2) ? p / d.Wo : 0, s_wo = (STEM || S2) ? p - s_ho * d.Wo : 0;   // this lane's first output pixel
+    // S2: offsets of the lane's 4 output pixels inside an input plane.  With Wo % 4 == 0 they sit in one row, 2 apart
+    // (0, 2, 4, 6); otherwise (the 28 -> 14 shortcut: Wo = 14) a group of 4 may wrap into the next row.
+    int s2o[4] = {0, 2, 4, 6};
+    if constexpr (S2 != 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pq = p + q, hq = pq / d.Wo, wq = pq - hq * d.Wo;
+            s2o[q] = (2 * hq - 2 * s_ho) * d.Win + 2 * wq - 2 * s_wo;
+        }
+    }
     const int sh_h = SHIFT ? p / d.Win : 0, sh_w = SHIFT ? p - sh_h * d.Win : 0;              // SHIFT: (h, w) of pixel 0
     const int sh_n = SHIFT ? f / d.T : 0, sh_t = SHIFT ? f - sh_n * d.T : 0;
     auto load_b = [&](int k) -> Raw {
@@ -229,10 +252,10 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             const bool ok = valid && k < d.K;
             const float* row = X + (((size_t)f * d.K + (ok ? k : 0)) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
             float4 v;
-            v.x = ok ? row[0] : 0.f;
-            v.y = ok ? row[2] : 0.f;
-            v.z = ok ? row[4] : 0.f;
-            v.w = ok ? row[6] : 0.f;
+            v.x = ok ? row[s2o[0]] : 0.f;
+            v.y = ok ? row[s2o[1]] : 0.f;
+            v.z = ok ? row[s2o[2]] : 0.f;
+            v.w = ok ? row[s2o[3]] : 0.f;
             return v;
         } else {
             return (valid && k < d.K) ? Px4<T>::load(xp + (size_t)k * d.P) : Px4<T>::zero();
@@ -259,9 +282,8 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             const float4 bw = Px4<T>::widen(bq[s]);
             float bv[4] = {bw.x, bw.y, bw.z, bw.w};
             if (FUSE && fz.ka) {                            // BN (+ReLU) of the input channel, applied on the fly
-                const int k = c * kKC + 2 * s + kh;
-                const bool kin = k < d.K;                   // (padded k: A is zero there, any finite value will do)
-                const float pa = kin ? fz.ka[k] : 0.f, pb = kin ? fz.kb[k] : 0.f;
+                const float2 pk = Ks[c * kKC + 2 * s + kh];    // (padded k: zeros; A is zero there as well)
+                const float pa = pk.x, pb = pk.y;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float t = fmaf(pa, bv[q], pb);
@@ -279,89 +301,334 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
     }
 
     if constexpr (EPI != 0 && std::is_same<T, float>::value && S2 != 2) {
-        // training epilogues (PwTrain above).  Every lane walks every row: the shuffles need the whole wave.
-        float sv[64];
-        float mypiv = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = 16 * b + r;
-                const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const bool on = valid && gm < d.M;
-                const size_t at = (size_t)(yp - Y) + (size_t)(on ? gm : 0) * d.P;
-                float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
-                if (R && on) {
-                    const float4 t = *reinterpret_cast<const float4*>(R + at);
-                    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-                }
-                if constexpr (EPI == 1) {
-                    const float piv = __shfl(o.x, kh << 5);           // the row's first column in this tile (always valid)
-                    if (l31 == i) mypiv = piv;
-                    float s1 = 0.f, s2 = 0.f;
-                    if (on) {
-                        float t;
-                        t = o.x - piv; s1 += t; s2 = fmaf(t, t, s2);
-                        t = o.y - piv; s1 += t; s2 = fmaf(t, t, s2);
-                        t = o.z - piv; s1 += t; s2 = fmaf(t, t, s2);
-                        t = o.w - piv; s1 += t; s2 = fmaf(t, t, s2);
-                    }
-                    sv[2 * i] = s1; sv[2 * i + 1] = s2;
-                } else {
-                    float s1 = 0.f, s2 = 0.f;
-                    if (on) {
-                        const float4 xv = *reinterpret_cast<const float4*>(tr.bx + at);
-                        const float pa = tr.ba[gm], pb = tr.bb[gm], mu = tr.bmean[gm], iv = tr.binv[gm];
-                        o.x = fmaf(pa, xv.x, pb) <= 0.f ? 0.f : o.x;  s1 += o.x;  s2 = fmaf(o.x, (xv.x - mu) * iv, s2);
-                        o.y = fmaf(pa, xv.y, pb) <= 0.f ? 0.f : o.y;  s1 += o.y;  s2 = fmaf(o.y, (xv.y - mu) * iv, s2);
-                        o.z = fmaf(pa, xv.z, pb) <= 0.f ? 0.f : o.z;  s1 += o.z;  s2 = fmaf(o.z, (xv.z - mu) * iv, s2);
-                        o.w = fmaf(pa, xv.w, pb) <= 0.f ? 0.f : o.w;  s1 += o.w;  s2 = fmaf(o.w, (xv.w - mu) * iv, s2);
-                    }
-                    sv[2 * i] = s1; sv[2 * i + 1] = s2;
-                }
-                if (on) *reinterpret_cast<float4*>(Y + at) = o;
-            }
-        halfwave_transpose_sum64(sv, l31);
-        // lane l31 now holds row i = l31 of its half: b = l31 >> 4, r = l31 & 15
-        const int rr = l31 & 15;
-        const int gmi = m0 + wm * 64 + 32 * (l31 >> 4) + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+        // training epilogues (PwTrain above).  Every lane walks every row: the shuffles need the whole wave.  One 32-row
+        // block at a time (its 16 rows per lane -> 32 partial sums -> folded over the 32 lanes of the half wave), the
+        // residual / x rows of 8 rows requested together before the first is used.
         const long long tj = (long long)blockIdx.x * WN + wn;
-        if (gmi < d.M && tj * 128 < d.ntot) {
-            if constexpr (EPI == 1) tr.stats[(size_t)gmi * tr.J + tj] = make_float4(mypiv, sv[0], sv[1], 0.f);
-            else tr.bred[(size_t)gmi * tr.J + tj] = make_float2(sv[0], sv[1]);
+        const bool tile_on = tj * 128 < d.ntot;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float sv[32];
+            float mypiv = 0.f;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float4 rv[8], xv[8];
+                bool on[8];
+                size_t at[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = r0 + j;
+                    const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    on[j] = valid && gm < d.M;
+                    at[j] = (size_t)(yp - Y) + (size_t)(on[j] ? gm : 0) * d.P;
+                    rv[j] = (R && on[j]) ? *reinterpret_cast<const float4*>(R + at[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (EPI == 2)
+                        xv[j] = on[j] ? *reinterpret_cast<const float4*>(tr.bx + at[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = r0 + j;
+                    const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    float4 o = make_float4(acc[b][0][r] + rv[j].x, acc[b][1][r] + rv[j].y, acc[b][2][r] + rv[j].z,
+                                           acc[b][3][r] + rv[j].w);
+                    float s1 = 0.f, s2 = 0.f;
+                    if constexpr (EPI == 1) {
+                        const float piv = __shfl(o.x, kh << 5);       // the row's first column in this tile (always valid)
+                        if ((l31 >> 1) == r) mypiv = piv;
+                        if (on[j]) {
+                            float t;
+                            t = o.x - piv; s1 += t; s2 = fmaf(t, t, s2);
+                            t = o.y - piv; s1 += t; s2 = fmaf(t, t, s2);
+                            t = o.z - piv; s1 += t; s2 = fmaf(t, t, s2);
+                            t = o.w - piv; s1 += t; s2 = fmaf(t, t, s2);
+                        }
+                    } else if (on[j]) {
+                        const float4 pk = tr.bpack[gm];
+                        const float pa = pk.x, pb = pk.y, mu = pk.z, iv = pk.w;
+                        o.x = fmaf(pa, xv[j].x, pb) <= 0.f ? 0.f : o.x;  s1 += o.x;  s2 = fmaf(o.x, (xv[j].x - mu) * iv, s2);
+                        o.y = fmaf(pa, xv[j].y, pb) <= 0.f ? 0.f : o.y;  s1 += o.y;  s2 = fmaf(o.y, (xv[j].y - mu) * iv, s2);
+                        o.z = fmaf(pa, xv[j].z, pb) <= 0.f ? 0.f : o.z;  s1 += o.z;  s2 = fmaf(o.z, (xv[j].z - mu) * iv, s2);
+                        o.w = fmaf(pa, xv[j].w, pb) <= 0.f ? 0.f : o.w;  s1 += o.w;  s2 = fmaf(o.w, (xv[j].w - mu) * iv, s2);
+                    }
+                    sv[2 * r] = s1; sv[2 * r + 1] = s2;
+                    if (on[j]) *reinterpret_cast<float4*>(Y + at[j]) = o;
+                }
+            }
+            halfwave_transpose_sum32(sv, l31);
+            // lane l31 holds sum idx l31 = 2 row + stat of this 32-row block; pair the two statistics of a row in the even lane
+            const float other = __shfl_xor(sv[0], 1);
+            const int rr = l31 >> 1;
+            const int gmi = m0 + wm * 64 + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+            if ((l31 & 1) == 0 && gmi < d.M && tile_on) {
+                if constexpr (EPI == 1) tr.stats[(size_t)gmi * tr.J + tj] = make_float4(mypiv, sv[0], other, 0.f);
+                else tr.bred[(size_t)gmi * tr.J + tj] = make_float2(sv[0], other);
+            }
         }
     } else if (valid) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;   // C/D map of 32x32 MFMA
-                if (gm < d.M) {
-                    float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
-                    if (FUSE && fz.ma) {                          // BN (+ReLU) of the output channel
-                        const float ea = fz.ma[gm], eb = fz.mb[gm];
-                        o.x = fmaf(ea, o.x, eb); o.y = fmaf(ea, o.y, eb); o.z = fmaf(ea, o.z, eb); o.w = fmaf(ea, o.w, eb);
-                        if (fz.relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                // the residual rows of 8 result rows are requested together, before the first is used: one load -> use
+                // -> store chain per row left the read of R exposed (gemm + R 150 us against 92 us without R at
+                // [256,54->54,56x56]; batched: 120 us)
+                float4 rv[8];
+                if (R) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = r0 + j;
+                        const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        rv[j] = gm < d.M ? Px4<T>::widen(Px4<T>::load(R + (yp - Y) + (size_t)gm * d.P))
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    if (R) {                                      // fused residual: Y = A X + R (the block's shortcut)
-                        const float4 t = Px4<T>::widen(Px4<T>::load(R + (yp - Y) + (size_t)gm * d.P));
-                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-                    }
-                    if constexpr (S2 == 2 && std::is_same<T, float>::value) {
-                        float* q = Y + (((size_t)f * d.M + gm) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
-                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                        *reinterpret_cast<float4*>(q) = make_float4(o.x, 0.f, o.y, 0.f);
-                        *reinterpret_cast<float4*>(q + 4) = make_float4(o.z, 0.f, o.w, 0.f);
-                        *reinterpret_cast<float4*>(q + d.Win) = z;
-                        *reinterpret_cast<float4*>(q + d.Win + 4) = z;
-                    } else {
-                        Px4<T>::store(yp + (size_t)gm * d.P, o);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = r0 + j;
+                    const int gm = m0 + wm * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kh;   // C/D map of 32x32 MFMA
+                    if (gm < d.M) {
+                        float4 o = make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                        if (FUSE && fz.ma) {                          // BN (+ReLU) of the output channel
+                            const float ea = fz.ma[gm], eb = fz.mb[gm];
+                            o.x = fmaf(ea, o.x, eb); o.y = fmaf(ea, o.y, eb); o.z = fmaf(ea, o.z, eb); o.w = fmaf(ea, o.w, eb);
+                            if (fz.relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                        }
+                        if (R) { o.x += rv[j].x; o.y += rv[j].y; o.z += rv[j].z; o.w += rv[j].w; }   // Y = A X + R (the shortcut)
+                        if constexpr (S2 == 2 && std::is_same<T, float>::value) {
+                            float* q = Y + (((size_t)f * d.M + gm) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
+                            if (d.Wo % 4 == 0) {
+                                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                                *reinterpret_cast<float4*>(q) = make_float4(o.x, 0.f, o.y, 0.f);
+                                *reinterpret_cast<float4*>(q + 4) = make_float4(o.z, 0.f, o.w, 0.f);
+                                *reinterpret_cast<float4*>(q + d.Win) = z;
+                                *reinterpret_cast<float4*>(q + d.Win + 4) = z;
+                            } else {                                  // per pixel: its 2 x 2 cell (8-byte aligned: Win even)
+                                const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    *reinterpret_cast<float2*>(q + s2o[e]) = make_float2(ov[e], 0.f);
+                                    *reinterpret_cast<float2*>(q + s2o[e] + d.Win) = make_float2(0.f, 0.f);
+                                }
+                            }
+                        } else {
+                            Px4<T>::store(yp + (size_t)gm * d.P, o);
+                        }
                     }
                 }
             }
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Planes whose pixel count is not a multiple of 4 (the 7x7 planes of layer4: 49-float rows, so a lane's "4 consecutive
+// pixels" straddle rows and frames and nothing is 16-byte aligned per row).  What IS aligned and contiguous is the run
+// of KC consecutive channels of one frame: KC * P floats starting at (f K + k0) P, 16-byte aligned whenever K, k0 are
+// multiples of 4.  So the streamed operand goes through LDS as whole frame chunks, copied flat with 16-byte loads
+// (LDS image = memory image: [frame][k][P]), and the B fragments are single-word LDS reads at lane-consecutive addresses;
+// the 128-bit trick of k_pw_gemm (a lane owns 4 consecutive columns) is not needed because nothing streams past the CU
+// fast enough to matter: these tensors are 1/4 .. 1/64 of the others and the layers are MFMA-bound (432 -> 432).
+//   wave tile 64 rows x 64 columns (2 x 2 MFMA blocks, 64 accumulators), workgroup = 4 waves along the columns = 256
+//   columns, so that [256 frames, 432 channels, 7x7] gives 49 x 7 = 343 workgroups.
+//   GATHER = 1: the streamed operand is read at stride 2 from [F, K, 2 Ho, 2 Wo] planes (the 14 -> 7 projecting shortcut,
+//   backbone.py:98-104): the frame chunk is gathered element by element into the same LDS image.
+//   SCATTER = 1: d(input) of that shortcut: the result of output pixel (ho, wo) goes to (2 ho, 2 wo) of a [2 Ho, 2 Wo]
+//   plane, zeros to the other three positions of its 2 x 2 cell (every element written, no memset).
+constexpr int kOddKC = 16;               // channels per chunk
+constexpr int kOddFr = 8;                // frames a 256-column tile can touch (P >= 37: 256 / P + 2 <= 8)
+
+template <int GATHER, int SCATTER>
+__global__ __launch_bounds__(kBlock) void k_pw_gemm_odd(const float* __restrict__ A, const float* __restrict__ X,
+                                                        const float* __restrict__ R, float* __restrict__ Y, PwDims d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = d.P;
+    const int fchunk = kOddKC * P;                          // floats of one frame chunk
+    float* As = smem;                                       // [2][kOddKC * 64]
+    float* Xs = smem + 2 * kOddKC * 64;                     // [2][kOddFr * fchunk]
+    const int xbuf = kOddFr * fchunk;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * 64;
+    const long long n0 = (long long)blockIdx.x * 256;       // first column of the workgroup
+    const int f0 = (int)(n0 / P);                           // first frame it touches
+    long long nlast = n0 + 255;
+    nlast = nlast < d.ntot - 1 ? nlast : d.ntot - 1;
+    const int nfr = (int)(nlast / P) - f0 + 1;              // frames touched (<= kOddFr)
+
+    // this lane's two columns (one per 32-column block of the wave's 64) and their LDS word offsets inside a buffer
+    long long col[2];
+    int xoff[2], cf[2], cp[2];
+    bool con[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        col[cb] = n0 + wave * 64 + cb * 32 + l31;
+        con[cb] = col[cb] < d.ntot;
+        const long long cc = con[cb] ? col[cb] : n0;
+        cf[cb] = (int)(cc / P);
+        cp[cb] = (int)(cc - (long long)cf[cb] * P);
+        xoff[cb] = (cf[cb] - f0) * fchunk + cp[cb];
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // Staging is split into fetch (global -> registers, issued BEFORE the MFMAs of the current chunk) and deposit
+    // (registers -> LDS, after them), so that the load latency hides under the 32 MFMAs of a chunk; a load -> LDS store
+    // -> MFMA sequence per chunk left it exposed 27 times per tile (152 us against MIOpen's 47 us at [256,432->432,7x7]).
+    constexpr int kXV = (kOddFr * kOddKC * 64 / 4 + kBlock - 1) / kBlock;        // float4 per thread, P <= 64: 8
+    constexpr int kAV = kOddKC * 64 / kBlock;                                    // 4 floats per thread
+    const int nv = fchunk / 4;                               // (kOddKC * P) % 4 == 0
+    // Everything about a thread's pieces that does not depend on the chunk is computed once: float4 e = tid + 256 i of
+    // the LDS image is (frame e / nv, float4 v = e % nv of its chunk); its LDS word offset is simply 4 e.  The chunk loop
+    // itself is branch-free: pieces past the touched frames are clamped onto a valid address and zeroed by a select;
+    // in the last, partial chunk (K % 16 != 0) the float4s past the real channels are read from the chunk's last valid
+    // float4 instead -- finite data in k-slots whose A column is zero.
+    int xfo[GATHER ? 1 : kXV], xv4[GATHER ? 1 : kXV];
+    bool xon[GATHER ? 1 : kXV];
+    if constexpr (GATHER == 0) {
+#pragma unroll
+        for (int i = 0; i < kXV; ++i) {
+            const int e = threadIdx.x + kBlock * i;
+            xon[i] = e < nfr * nv;
+            const int ec = xon[i] ? e : 0;
+            const int fr = ec / nv;
+            xv4[i] = 4 * (ec - fr * nv);
+            xfo[i] = fr * d.K * P;                            // (< 2^31: make_dims bounds the tensor)
+        }
+    }
+    const float* Xf0 = X + (size_t)f0 * d.K * P;
+    float4 xv[GATHER ? 1 : kXV];
+    float av[kAV];
+    auto fetch_x = [&](int k0) {
+        if constexpr (GATHER == 0) {
+            const int live4 = min(kOddKC, d.K - k0) * P - 4;  // last valid float4 start inside a frame chunk (K % 4 == 0)
+            const float* src = Xf0 + (size_t)k0 * P;
+#pragma unroll
+            for (int i = 0; i < kXV; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(src + xfo[i] + min(xv4[i], live4));
+                xv[i] = xon[i] ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto deposit_x = [&](int k0, float* dst) {
+        if constexpr (GATHER == 0) {
+#pragma unroll
+            for (int i = 0; i < kXV; ++i)
+                if (xon[i]) *reinterpret_cast<float4*>(dst + 4 * (threadIdx.x + kBlock * i)) = xv[i];
+        } else {
+            // stride-2 gather (one layer per network, small): LDS element (fr, kk, ho, wo) <- X[f0 + fr][k0 + kk][2 ho][2 wo];
+            // 8 loads in flight per thread
+            const int kc = min(kOddKC, d.K - k0);
+            const int HW = d.Hin * d.Win;
+            const int total = nfr * fchunk;
+            for (int e0 = threadIdx.x; e0 < total; e0 += 8 * kBlock) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + j * kBlock;
+                    const int ec = e < total ? e : 0;
+                    const int fr = ec / fchunk, r = ec - fr * fchunk;
+                    const int kk = r / P, p = r - kk * P;
+                    const int ho = p / d.Wo, wo = p - ho * d.Wo;
+                    const bool ok = e < total && kk < kc;
+                    t[j] = ok ? X[((size_t)(f0 + fr) * d.K + k0 + (ok ? kk : 0)) * HW + 2 * ho * d.Win + 2 * wo] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (e0 + j * kBlock < total) dst[e0 + j * kBlock] = t[j];
+            }
+        }
+    };
+    // A: element e = tid + 256 i <-> (kk = e / 64, m = e % 64); address = base + k0 * kstep
+    int abase[kAV];
+    bool am_ok[kAV];
+    const int akstep = d.a_is_mk ? 1 : d.M;
+#pragma unroll
+    for (int i = 0; i < kAV; ++i) {
+        const int e = threadIdx.x + kBlock * i;
+        const int kk = e >> 6, gm = m0 + (e & 63);
+        am_ok[i] = gm < d.M;
+        const int gmc = am_ok[i] ? gm : 0;
+        abase[i] = d.a_is_mk ? gmc * d.K + kk : kk * d.M + gmc;
+    }
+    auto fetch_a = [&](int k0) {                            // As[kk][m], m < 64, zero padded (as AStage)
+#pragma unroll
+        for (int i = 0; i < kAV; ++i) {
+            const int kk = (threadIdx.x + kBlock * i) >> 6;
+            const bool ok = am_ok[i] && k0 + kk < d.K;
+            av[i] = ok ? A[ok ? abase[i] + k0 * akstep : 0] : 0.f;
+        }
+    };
+    auto deposit_a = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < kAV; ++i) dst[threadIdx.x + kBlock * i] = av[i];
+    };
+
+    const int nchunks = (d.K + kOddKC - 1) / kOddKC;
+    fetch_a(0);
+    fetch_x(0);
+    deposit_a(As);
+    deposit_x(0, Xs);
+#pragma nounroll
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                                    // chunk c is complete; the other buffers are free
+        const bool more = c + 1 < nchunks;
+        if (more) {
+            fetch_a((c + 1) * kOddKC);
+            fetch_x((c + 1) * kOddKC);
+        }
+        const float* as = As + (c & 1) * kOddKC * 64 + l31;
+        const float* xs = Xs + (c & 1) * xbuf;
+        // all 32 fragment words of the chunk are requested before the first MFMA (one LDS round trip per chunk instead of
+        // two per k-step: with a read -> wait -> MFMA sequence per step the loop ran at half the MFMA rate); rows past M
+        // are zero columns of A, so the second 32-row block needs no test
+        float fa0[kOddKC / 2], fa1[kOddKC / 2], fb0[kOddKC / 2], fb1[kOddKC / 2];
+#pragma unroll
+        for (int s = 0; s < kOddKC / 2; ++s) {
+            const int kk = 2 * s + kh;
+            fa0[s] = as[kk * 64]; fa1[s] = as[kk * 64 + 32];
+            fb0[s] = xs[xoff[0] + kk * P]; fb1[s] = xs[xoff[1] + kk * P];
+        }
+#pragma unroll
+        for (int s = 0; s < kOddKC / 2; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb0[s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb1[s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb0[s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb1[s], acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            deposit_a(As + ((c + 1) & 1) * kOddKC * 64);
+            deposit_x((c + 1) * kOddKC, Xs + ((c + 1) & 1) * xbuf);
+        }
+    }
+
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (!con[cb]) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (gm >= d.M) continue;
+                float o = acc[a][cb][r];
+                if (SCATTER == 0) {
+                    const size_t at = ((size_t)cf[cb] * d.M + gm) * P + cp[cb];
+                    if (R) o += R[at];
+                    Y[at] = o;
+                } else {
+                    const int ho = cp[cb] / d.Wo, wo = cp[cb] - ho * d.Wo;
+                    float* q = Y + ((size_t)cf[cb] * d.M + gm) * (d.Hin * d.Win) + 2 * ho * d.Win + 2 * wo;
+                    q[0] = o; q[1] = 0.f; q[d.Win] = 0.f; q[d.Win + 1] = 0.f;
+                }
+            }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Forward / d(input) for bf16 activations on the bf16 MFMA.  Here the reduction index (channels) is the
@@ -524,29 +791,23 @@ struct WgDims {
     const float* ka; const float* kb; int relu_in;
 };
 
-// prologue coefficients of a lane's rows of the X tile (fixed for the whole pixel loop)
-template <int NJ>
-struct RowAffine {
-    float a[NJ], b[NJ];
-    __device__ __forceinline__ void load(const WgDims& d, int r0, int rstep, int rsub) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int r = r0 + rstep * j + rsub;
-            const bool ok = r < d.K;
-            a[j] = ok ? d.ka[r] : 0.f;
-            b[j] = ok ? d.kb[r] : 0.f;
-        }
+// PRO: in the MFMA loop a lane reads X-tile rows l31 and 32 + l31 of its 64-row block only -- two fixed channels -- so
+// the prologue is applied to the two fragment values right after the LDS read: 2 fma + 2 max per 4 MFMAs, four
+// registers.  Pixels past the range need no care (the dY tile is zero there); rows past K get a = b = 0.
+struct RowAffine2 {
+    float a0, b0, a1, b1;
+    int relu;
+    __device__ __forceinline__ void load(const WgDims& d, int row0) {
+        const int l31 = threadIdx.x & 31;
+        const int r0 = row0 + l31, r1 = row0 + 32 + l31;
+        a0 = r0 < d.K ? d.ka[r0] : 0.f;  b0 = r0 < d.K ? d.kb[r0] : 0.f;
+        a1 = r1 < d.K ? d.ka[r1] : 0.f;  b1 = r1 < d.K ? d.kb[r1] : 0.f;
+        relu = d.relu_in;
     }
-    // rows past K and pixels past the range were fetched as zeros and must stay zeros (relu(b) != 0)
-    __device__ __forceinline__ void apply(float4 (&v)[NJ], const WgDims& d, int r0, int rstep, int rsub, bool nok) const {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool ok = nok && r0 + rstep * j + rsub < d.K;
-            float4 t = v[j];
-            t.x = fmaf(a[j], t.x, b[j]); t.y = fmaf(a[j], t.y, b[j]); t.z = fmaf(a[j], t.z, b[j]); t.w = fmaf(a[j], t.w, b[j]);
-            if (d.relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-            v[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    __device__ __forceinline__ void apply(float& v0, float& v1) const {
+        v0 = fmaf(a0, v0, b0);
+        v1 = fmaf(a1, v1, b1);
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
     }
 };
 
@@ -608,12 +869,53 @@ __device__ __forceinline__ void wg_fetch_s2(const float* __restrict__ X, const W
     const int lane = threadIdx.x & 63;
     const bool nok = c.n < nend;
     const int ho = c.p / d.Wo, wo = c.p - ho * d.Wo;
+    int o1 = 2, o2 = 4, o3 = 6;
+    if (d.Wo % 4 != 0) {                                   // a group of 4 output pixels may wrap into the next row (Wo = 14)
+        const int p1 = c.p + 1, p2 = c.p + 2, p3 = c.p + 3;
+        const int h1 = p1 / d.Wo, h2 = p2 / d.Wo, h3 = p3 / d.Wo;
+        o1 = 2 * (h1 - ho) * d.Win + 2 * (p1 - h1 * d.Wo) - 2 * wo;
+        o2 = 2 * (h2 - ho) * d.Win + 2 * (p2 - h2 * d.Wo) - 2 * wo;
+        o3 = 2 * (h3 - ho) * d.Win + 2 * (p3 - h3 * d.Wo) - 2 * wo;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = r0 + 8 * j + (lane >> 3);
         const bool ok = nok && r < d.K;
         const float* row = X + (((size_t)(nok ? c.f : 0) * d.K + (ok ? r : 0)) * d.Hin + 2 * ho) * d.Win + 2 * wo;
-        v[j] = ok ? make_float4(row[0], row[2], row[4], row[6]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = ok ? make_float4(row[0], row[o1], row[o2], row[o3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// planes with P % 4 != 0 (7x7): the lane's 4 consecutive pixels n .. n+3 of the flattened (f, p) index are 4 separate
+// words (they may straddle rows and frames).  S2: X is [F, rows, 2 Ho, 2 Wo] read at stride 2 (the 14 -> 7 shortcut).
+template <bool S2>
+__device__ __forceinline__ void wg_fetch_odd(const float* __restrict__ T, int rows, int r0, const WgDims& d, long long n,
+                                             long long nend, float4 (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    size_t off[4];
+    bool ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long ne = n + e;
+        ok[e] = ne < nend;
+        const long long nc = ok[e] ? ne : 0;
+        const int f = (int)(nc / d.P), p = (int)(nc - (long long)f * d.P);
+        if (S2) {
+            const int ho = p / d.Wo, wo = p - ho * d.Wo;
+            off[e] = (size_t)f * rows * (d.Hin * d.Win) + 2 * ho * d.Win + 2 * wo;
+        } else {
+            off[e] = (size_t)f * rows * d.P + p;
+        }
+    }
+    const size_t rstride = S2 ? (size_t)d.Hin * d.Win : (size_t)d.P;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 8 * j + (lane >> 3);
+        const bool rok = r < rows;
+        const float* base = T + (rok ? (size_t)r * rstride : 0);
+        v[j].x = (rok && ok[0]) ? base[off[0]] : 0.f;
+        v[j].y = (rok && ok[1]) ? base[off[1]] : 0.f;
+        v[j].z = (rok && ok[2]) ? base[off[2]] : 0.f;
+        v[j].w = (rok && ok[3]) ? base[off[3]] : 0.f;
     }
 }
 __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
@@ -626,7 +928,44 @@ __device__ __forceinline__ void wg_deposit(float* tile, const float4 (&v)[8]) {
     }
 }
 
-template <typename T, bool STEM = false, bool S2 = false, bool PRO = false>
+// The MFMA phase of one staged 64 x 32 tile pair: fragments of 4 k-steps are read from LDS together, then their (up to) 16
+// MFMAs issue back to back.  A1 / B1: does the second 32-row block of the dY / X tile hold any row -- compile time here,
+// so that no branch sits between the reads and the MFMAs (with run-time tests and a read -> wait -> MFMA sequence per
+// k-step the loop ran at about a third of the MFMA rate: one LDS round trip per 4 MFMAs, exposed).
+template <bool A1, bool B1, bool PRO, typename ProT>
+__device__ __forceinline__ void wg_mfma_tile(const float* ta, const float* tb, int rowa, int rowb, int kh, const ProT& pro,
+                                             f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int s0 = 0; s0 < kNB / 2; s0 += 4) {
+        float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 2 * (s0 + j) + kh;
+            a0[j] = ta[tile_at(rowa, col)];
+            if (A1) a1[j] = ta[tile_at(rowa + 32, col)];
+            b0[j] = tb[tile_at(rowb, col)];
+            if (B1) b1[j] = tb[tile_at(rowb + 32, col)]; else b1[j] = 0.f;
+            if constexpr (PRO) pro.apply(b0[j], b1[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            if (B1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            if (A1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            if (A1 && B1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+    }
+}
+template <bool PRO, typename ProT>
+__device__ __forceinline__ void wg_mfma_tile_dyn(bool a1_on, bool b1_on, const float* ta, const float* tb, int rowa, int rowb,
+                                                 int kh, const ProT& pro, f32x16 (&acc)[2][2]) {
+    if (a1_on && b1_on) wg_mfma_tile<true, true, PRO>(ta, tb, rowa, rowb, kh, pro, acc);
+    else if (a1_on) wg_mfma_tile<true, false, PRO>(ta, tb, rowa, rowb, kh, pro, acc);
+    else if (b1_on) wg_mfma_tile<false, true, PRO>(ta, tb, rowa, rowb, kh, pro, acc);
+    else wg_mfma_tile<false, false, PRO>(ta, tb, rowa, rowb, kh, pro, acc);
+}
+
+template <typename T, bool STEM = false, bool S2 = false, bool PRO = false, int ODD = 0>
 __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, const T* __restrict__ X,
                                                      float* __restrict__ ws, WgDims d) {
     __shared__ float tiles[4][2][64 * kNB];
@@ -665,13 +1004,17 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
     float4 va[8], vb[8];
     PixCursor cur;
     cur.init(n0, d.P);
-    RowAffine<PRO ? 8 : 1> pro;
-    if constexpr (PRO) pro.load(d, 64 * kb, 8, lane >> 3);
+    RowAffine2 pro;
+    if constexpr (PRO) pro.load(d, 64 * kb);
+    if constexpr (ODD != 0 && std::is_same<T, float>::value) {
+        wg_fetch_odd<false>(dY, d.M, 64 * mb, d, cur.n, nend, va);
+        wg_fetch_odd<ODD == 2>(X, d.K, 64 * kb, d, cur.n, nend, vb);
+    } else {
     wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);
     if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
     else if constexpr (S2 && std::is_same<T, float>::value) wg_fetch_s2(X, d, 64 * kb, cur, nend, vb);
     else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
-    if constexpr (PRO) pro.apply(vb, d, 64 * kb, 8, lane >> 3, cur.n < nend);
+    }
     const int steps = per / kNB;                                // same for every wave: barriers stay uniform
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
@@ -679,21 +1022,18 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad(const T* __restrict__ dY, c
         // with barriers here the four waves marched in lock step, MFMA phases and load phases all at once)
         wg_deposit(ta, va);
         wg_deposit(tb, vb);
+        if constexpr (ODD != 0 && std::is_same<T, float>::value) {
+            cur.n += kNB;
+            wg_fetch_odd<false>(dY, d.M, 64 * mb, d, cur.n, nend, va);
+            wg_fetch_odd<ODD == 2>(X, d.K, 64 * kb, d, cur.n, nend, vb);
+        } else {
         cur.advance(d.P);
         wg_fetch(dY, d.M, 64 * mb, d.P, cur, nend, va, d.M);           // next tile, in flight during the MFMAs
         if constexpr (STEM && std::is_same<T, float>::value) wg_fetch_stem(X, d, cur, nend, vb);
         else if constexpr (S2 && std::is_same<T, float>::value) wg_fetch_s2(X, d, 64 * kb, cur, nend, vb);
         else wg_fetch(X, d.K, 64 * kb, d.P, cur, nend, vb, d.K);
-        if constexpr (PRO) pro.apply(vb, d, 64 * kb, 8, lane >> 3, cur.n < nend);
-#pragma unroll
-        for (int s = 0; s < kNB / 2; ++s) {
-            const float a0 = ta[tile_at(l31, 2 * s + kh)], a1 = ta[tile_at(32 + l31, 2 * s + kh)];
-            const float b0 = tb[tile_at(l31, 2 * s + kh)], b1 = tb[tile_at(32 + l31, 2 * s + kh)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            if (b1_on) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            if (a1_on) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            if (a1_on && b1_on) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        wg_mfma_tile_dyn<PRO>(a1_on, b1_on, ta, tb, l31, l31, kh, pro, acc);
     }
     // sum the sub-chunk waves of each block into its subc == 0 wave (fixed order), through the tile memory
     __syncthreads();
@@ -789,11 +1129,10 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ 
         }
     };
     float4 va[4], vb[4];
-    RowAffine<PRO ? 4 : 1> pro;
-    if constexpr (PRO) pro.load(d, 128 * kt, 32, (int)(threadIdx.x >> 3));
+    RowAffine2 pro;
+    if constexpr (PRO) pro.load(d, rowB);
     fetch(dY, d.M, 128 * mt, d.M, va);
     fetch(X, d.K, 128 * kt, d.K, vb);
-    if constexpr (PRO) pro.apply(vb, d, 128 * kt, 32, (int)(threadIdx.x >> 3), cur.n < nend);
     const int steps = d.chunk / kNB;
 #pragma nounroll
     for (int it = 0; it < steps; ++it) {
@@ -804,18 +1143,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_wide(const T* __restrict__ 
         cur.advance(d.P);
         fetch(dY, d.M, 128 * mt, d.M, va);
         fetch(X, d.K, 128 * kt, d.K, vb);
-        if constexpr (PRO) pro.apply(vb, d, 128 * kt, 32, (int)(threadIdx.x >> 3), cur.n < nend);
-        if (a0_on && b0_on) {
-#pragma unroll
-            for (int s = 0; s < kNB / 2; ++s) {
-                const float a0 = ta[tile_at(64 * wm + l31, 2 * s + kh)], a1 = ta[tile_at(64 * wm + 32 + l31, 2 * s + kh)];
-                const float b0 = tb[tile_at(64 * wk + l31, 2 * s + kh)], b1 = tb[tile_at(64 * wk + 32 + l31, 2 * s + kh)];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                if (b1_on) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                if (a1_on) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                if (a1_on && b1_on) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        }
+        if (a0_on && b0_on) wg_mfma_tile_dyn<PRO>(a1_on, b1_on, ta, tb, 64 * wm + l31, 64 * wk + l31, kh, pro, acc);
     }
     if (a0_on && b0_on) {
         float* out = ws + (size_t)chunk * d.M * d.K;
@@ -1016,8 +1344,8 @@ __global__ __launch_bounds__(kBlock) void k_pw_wgrad_reduce(const float* __restr
     out[(size_t)part * MK + i] = s;
 }
 
-inline int make_wg(WgDims& d, int F, int K, int M, int P) {
-    if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0) return RK_ERR_BAD_DIMS;
+inline int make_wg(WgDims& d, int F, int K, int M, int P, bool odd = false) {
+    if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || (P % 4 != 0 && !odd)) return RK_ERR_BAD_DIMS;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
     d.ka = d.kb = nullptr; d.relu_in = 0;
     d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
@@ -1080,13 +1408,14 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
         }
     }
     const bool fused = fuse && (fuse->ka || fuse->ma);
+    if (fused && fuse->ka && (K + 15) / 16 * 16 > kProK) return RK_ERR_BAD_DIMS;      // prologue table in LDS
     PwFuse fz = fused ? *fuse : PwFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
-    PwTrain tr = train ? *train : PwTrain{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    PwTrain tr = train ? *train : PwTrain{nullptr, nullptr, nullptr, nullptr, 0};
     if constexpr (std::is_same<T, float>::value) {
         if (epi) {                                           // training epilogues (fp32): statistics of Y / BN-backward sums
-            if (epi == 1 ? !tr.stats : !(tr.bred && tr.bx && tr.ba && tr.bb && tr.bmean && tr.binv)) return RK_ERR_NULL_POINTER;
+            if (epi == 1 ? !tr.stats : !(tr.bred && tr.bx && tr.bpack)) return RK_ERR_NULL_POINTER;
             if (fz.ma || (long long)tr.J * 128 < d.ntot) return RK_ERR_BAD_DIMS;
-            if (epi == 2 && ((uintptr_t)tr.bx & am)) return RK_ERR_BAD_DIMS;
+            if (epi == 2 && (((uintptr_t)tr.bx & am) || ((uintptr_t)tr.bpack & 15))) return RK_ERR_BAD_DIMS;
 #define RK_PW_EP(WMV, KCV, FU, EP) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, FU, false, 0, false, EP>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
 #define RK_PW_EK(WMV, FU, EP) do { if (kc == 12) RK_PW_EP(WMV, 12, FU, EP); else RK_PW_EP(WMV, 16, FU, EP); } while (0)
 #define RK_PW_EW(FU, EP) do { if (wm == 1) RK_PW_EK(1, FU, EP); else RK_PW_EK(2, FU, EP); } while (0)
@@ -1189,13 +1518,13 @@ static int stem_conv(const float* W, const float* X, float* Y, int F, int Cin, i
     const float* R = nullptr;
     if (stats) {                                          // + the statistics of Y for the first block's bn1 (PwTrain)
         if ((long long)J * 128 < d.ntot) return RK_ERR_BAD_DIMS;
-        const PwTrain tr{stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, J};
+        const PwTrain tr{stats, nullptr, nullptr, nullptr, J};
         if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true, 0, false, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
         else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true, 0, false, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
         else return RK_ERR_BAD_DIMS;
         return launch_status();
     }
-    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, 0};
     if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
     else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
     else hipLaunchKernelGGL((k_pw_gemm<float, 4, 16, false, true>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
@@ -1245,7 +1574,8 @@ int rk_stem_wgrad3x3s2_f32(const float* dY, const float* X, float* dW, int F, in
 static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, int Hin, int Win, int mode, int a_is_mk,
                  rk_stream_t stream_, const PwFuse* fuse = nullptr) {
     if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
-    if (F <= 0 || K <= 0 || M <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || K % 2) return RK_ERR_BAD_DIMS;
+    if (F <= 0 || K <= 0 || M <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 2 || K % 2) return RK_ERR_BAD_DIMS;
+    if (((Hin / 2) * (Win / 2)) % 4) return RK_ERR_BAD_DIMS;          // output planes of whole 4-pixel groups (Win % 8 == 0: one row each)
     if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0;
@@ -1256,8 +1586,9 @@ static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, 
     const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
     hipStream_t stream = (hipStream_t)stream_;
     const PwFuse fz = fuse ? *fuse : PwFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (fuse && fuse->ka && (K + 15) / 16 * 16 > kProK) return RK_ERR_BAD_DIMS;
     const float* R = nullptr;
-    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, 0};
 #define RK_S2_GO(WMV, MODE, FU) hipLaunchKernelGGL((k_pw_gemm<float, WMV, 12, FU, false, MODE>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
     if (mode == 1 && fuse) { if (wm == 1) RK_S2_GO(1, 1, true); else RK_S2_GO(2, 1, true); }
     else if (mode == 1) { if (wm == 1) RK_S2_GO(1, 1, false); else RK_S2_GO(2, 1, false); }
@@ -1284,7 +1615,7 @@ int rk_pw_s2_dgrad_f32(const float* W, const float* dY, float* dX, int F, int Ci
 static int pw_s2_wgrad(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* ws,
                        size_t ws_bytes, rk_stream_t stream_, const float* ka, const float* kb, int relu_in) {
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
-    if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8) return RK_ERR_BAD_DIMS;
+    if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 2) return RK_ERR_BAD_DIMS;
     if ((uintptr_t)dY & 15) return RK_ERR_BAD_DIMS;
     const int K = Cin, M = Cout, P = (Hin / 2) * (Win / 2);
     WgDims d;
@@ -1336,7 +1667,7 @@ int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, c
     hipStream_t stream = (hipStream_t)stream_;
     const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
     const int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;       // the plain GEMM's choice: same k order
-    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, 0};
 #define RK_SH_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, false, false, 0, true>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
     if (wm == 1) { if (kc == 12) RK_SH_GO(1, 12); else RK_SH_GO(1, 16); }
     else { if (kc == 12) RK_SH_GO(2, 12); else RK_SH_GO(2, 16); }
@@ -1360,6 +1691,96 @@ int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* 
     const PwFuse fz{ka, kb, ma, mb, relu_in, relu_out};
     return pw_gemm<float>(A, X, R, Y, F, K, M, P, a_is_mk, stream, &fz);
 }
+// ---- planes with H * W % 4 != 0 (7x7): k_pw_gemm_odd ----
+static int pw_gemm_odd(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P, int a_is_mk,
+                       int mode, int Hin, int Win, rk_stream_t stream_) {
+    if (!A || !X || !Y) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || K <= 0 || M <= 0 || P < 37 || P > 64) return RK_ERR_BAD_DIMS;           // 256 / P + 2 <= kOddFr; registers
+    if (mode == 0 && (K % 4 || ((uintptr_t)X & 15))) return RK_ERR_BAD_DIMS;            // aligned frame chunks
+    PwDims d;
+    d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
+    d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0; d.WM = 1; d.WN = 4;
+    const size_t lds = (size_t)(2 * kOddKC * 64 + 2 * kOddFr * kOddKC * P) * sizeof(float);
+    if (lds > 160 * 1024) return RK_ERR_BAD_DIMS;
+    const dim3 grid((unsigned)((d.ntot + 255) / 256), (unsigned)((M + 63) / 64)), block(kBlock);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (mode == 0) {
+        static bool once = ((void)hipFuncSetAttribute((const void*)k_pw_gemm_odd<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((k_pw_gemm_odd<0, 0>), grid, block, lds, stream, A, X, R, Y, d);
+    } else if (mode == 1) {
+        static bool once = ((void)hipFuncSetAttribute((const void*)k_pw_gemm_odd<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((k_pw_gemm_odd<1, 0>), grid, block, lds, stream, A, X, R, Y, d);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute((const void*)k_pw_gemm_odd<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((k_pw_gemm_odd<0, 1>), grid, block, lds, stream, A, X, R, Y, d);
+    }
+    return launch_status();
+}
+// Y[f] = A X[f] (+ R[f]) for planes of P = H * W pixels with P % 4 != 0 (37 <= P <= 200; the 7x7 planes of layer4):
+// forward (a_is_mk = 1) and d(input) (a_is_mk = 0) of a 1x1 / stride-1 convolution.  K % 4 == 0, X 16-byte aligned.
+int rk_pw_gemm_odd_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
+                       int a_is_mk, rk_stream_t stream) {
+    return pw_gemm_odd(A, X, R, Y, F, K, M, P, a_is_mk, 0, 0, 0, stream);
+}
+// the 1x1 / stride-2 projecting shortcut onto such planes (14x14 -> 7x7): forward X [F, Cin, Hin, Win] -> Y [F, Cout,
+// Hin/2, Win/2] and d(input) dY -> dX (zeros between the scattered results); Hin, Win even.
+int rk_pw_s2_forward_odd_f32(const float* W, const float* X, float* Y, int F, int Cin, int Cout, int Hin, int Win,
+                             rk_stream_t stream) {
+    if (Hin <= 0 || Win <= 0 || Hin % 2 || Win % 2) return RK_ERR_BAD_DIMS;
+    return pw_gemm_odd(W, X, nullptr, Y, F, Cin, Cout, (Hin / 2) * (Win / 2), 1, 1, Hin, Win, stream);
+}
+int rk_pw_s2_dgrad_odd_f32(const float* W, const float* dY, float* dX, int F, int Cin, int Cout, int Hin, int Win,
+                           rk_stream_t stream) {
+    if (Hin <= 0 || Win <= 0 || Hin % 2 || Win % 2) return RK_ERR_BAD_DIMS;
+    const int P = (Hin / 2) * (Win / 2);
+    if (Cout % 4 || ((uintptr_t)dY & 15)) return RK_ERR_BAD_DIMS;
+    return pw_gemm_odd(W, dY, nullptr, dX, F, Cout, Cin, P, 0, 2, Hin, Win, stream);      // W read as [K=Cout][M=Cin]
+}
+
+// d(weight) for planes with P % 4 != 0: dW[M][K] = sum_f dY[f] X[f]^T, scalar pixel loads (k_pw_wgrad<.., ODD>).
+// s2 != 0: X is [F, K, Hin, Win] read at stride 2, dY [F, M, Hin/2, Win/2] (the 14 -> 7 projecting shortcut).
+static int pw_wgrad_odd(const float* dY, const float* X, float* dW, int F, int K, int M, int P, int s2, int Hin, int Win,
+                        void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
+    WgDims d;
+    if (int rc = make_wg(d, F, K, M, P, true)) return rc;
+    d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
+    if (!ws || ws_bytes < (size_t)(d.S + kRed) * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nmk = d.MB * d.KB, bpw = nmk < 4 ? nmk : 4, groups = (nmk + bpw - 1) / bpw;
+    float* part = (float*)ws;
+    float* part2 = part + (size_t)d.S * M * K;
+    const int MK = M * K;
+    const unsigned gi = (unsigned)((MK + kBlock - 1) / kBlock);
+    if (s2) hipLaunchKernelGGL((k_pw_wgrad<float, false, false, false, 2>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    else hipLaunchKernelGGL((k_pw_wgrad<float, false, false, false, 1>), dim3((unsigned)(d.S * groups)), dim3(kBlock), 0, stream, dY, X, part, d);
+    if (d.S > kRedDirect) {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, kRed), dim3(kBlock), 0, stream, (const float*)part, part2, MK, d.S, kRed);
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part2, dW, MK, kRed, 1);
+    } else {
+        hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3(gi, 1), dim3(kBlock), 0, stream, (const float*)part, dW, MK, d.S, 1);
+    }
+    return launch_status();
+}
+// workspace: rk_pw_wgrad_odd_workspace_bytes(F, K, M, P)
+size_t rk_pw_wgrad_odd_workspace_bytes(int F, int K, int M, int P) {
+    WgDims d;
+    if (make_wg(d, F, K, M, P, true)) return 0;
+    return (size_t)(d.S + kRed) * M * K * sizeof(float);
+}
+int rk_pw_wgrad_odd_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws,
+                        size_t ws_bytes, rk_stream_t stream) {
+    return pw_wgrad_odd(dY, X, dW, F, K, M, P, 0, 0, 0, ws, ws_bytes, stream);
+}
+int rk_pw_s2_wgrad_odd_f32(const float* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win,
+                           void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (Hin <= 0 || Win <= 0 || Hin % 2 || Win % 2) return RK_ERR_BAD_DIMS;
+    return pw_wgrad_odd(dY, X, dW, F, Cin, Cout, (Hin / 2) * (Win / 2), 1, Hin, Win, ws, ws_bytes, stream);
+}
+
 // ---- training-mode fusions (PwTrain) ----
 // number of 128-column wave tiles of an [F, *, P] tensor = the J of the tile-partial arrays below
 int rk_pw_tiles(int F, int P) {
@@ -1373,16 +1794,15 @@ int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* 
                          rk_stream_t stream) {
     if ((ka == nullptr) != (kb == nullptr)) return RK_ERR_NULL_POINTER;
     const PwFuse fz{ka, kb, nullptr, nullptr, relu_in, 0};
-    const PwTrain tr{(float4*)stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tiles};
+    const PwTrain tr{(float4*)stats, nullptr, nullptr, nullptr, tiles};
     return pw_gemm<float>(A, X, R, Y, F, K, M, P, a_is_mk, stream, &fz, &tr, 1);
 }
 // d(input) of conv2 in training, fused with the first half of bn1's backward: da = A dY (+ R) is masked with
 // [ba x + bb > 0] (x = bn1's input) on its way out -> dZ, and the tile sums (sum dz, sum dz xhat) go to bred (float2
-// [M][tiles]); xhat = (x - mean) invstd.
+// [M][tiles]); xhat = (x - mean) invstd.  abmi: [M][4] = (a, b, mean, invstd) per channel, as rk_bn_finish_tiles_f32 packs it.
 int rk_pw_gemm_bnbwd_f32(const float* A, const float* dY, const float* R, float* dZ, int F, int K, int M, int P,
-                         int a_is_mk, const float* x, const float* ba, const float* bb, const float* mean,
-                         const float* invstd, void* bred, int tiles, rk_stream_t stream) {
-    const PwTrain tr{nullptr, (float2*)bred, x, ba, bb, mean, invstd, tiles};
+                         int a_is_mk, const float* x, const float* abmi, void* bred, int tiles, rk_stream_t stream) {
+    const PwTrain tr{nullptr, (float2*)bred, x, (const float4*)abmi, tiles};
     return pw_gemm<float>(A, dY, R, dZ, F, K, M, P, a_is_mk, stream, nullptr, &tr, 2);
 }
 

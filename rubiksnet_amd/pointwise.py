@@ -177,7 +177,113 @@ def _eligible_s2(conv, x):
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
             and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
             and max(conv.in_channels, conv.out_channels) <= _S2_CMAX
-            and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0)
+
+
+class _Conv1x1OddFunc(torch.autograd.Function):
+    """1x1 / stride-1 convolution (+ residual) on planes with H * W % 4 != 0 -- the 7x7 planes of layer4 -- on the
+    LDS-staged HIP GEMM (k_pw_gemm_odd) and the scalar-pixel d(weight) kernel.  MIOpen ran these as NHWC implicit GEMMs
+    between two layout transposes (igemm + Cijk_ + batched_transpose: 1.8 ms of a 25 ms Tiny train step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, residual):
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_pw_gemm_odd_f32(weight.data_ptr(), x.data_ptr(),
+                                                  residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                                  Fr, Cin, Cout, H * W, 1, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_pw_gemm_odd_f32")
+        ctx.save_for_backward(x, weight)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        L = _native.lib()
+        dx = dw = None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _native.check(L.rk_pw_gemm_odd_f32(weight.data_ptr(), dy.data_ptr(), None, dx.data_ptr(), Fr, Cout, Cin,
+                                                   H * W, 0, stream), "rk_pw_gemm_odd_f32")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                nbytes = int(L.rk_pw_wgrad_odd_workspace_bytes(Fr, Cin, Cout, H * W))
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                _native.check(L.rk_pw_wgrad_odd_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W,
+                                                    ws.data_ptr(), nbytes, stream), "rk_pw_wgrad_odd_f32")
+        return dx, dw, (dy if ctx.has_residual and ctx.needs_input_grad[2] else None)
+
+
+class _ConvS2OddFunc(torch.autograd.Function):
+    """The 1x1 / stride-2 projecting shortcut onto planes with Ho * Wo % 4 != 0 (14x14 -> 7x7)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_pw_s2_forward_odd_f32(weight.data_ptr(), x.data_ptr(), y.data_ptr(), Fr, Cin, Cout, H, W,
+                                                        torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_pw_s2_forward_odd_f32")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        L = _native.lib()
+        dx = dw = None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _native.check(L.rk_pw_s2_dgrad_odd_f32(weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), Fr, Cin, Cout, H, W,
+                                                       stream), "rk_pw_s2_dgrad_odd_f32")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                nbytes = int(L.rk_pw_wgrad_odd_workspace_bytes(Fr, Cin, Cout, (H // 2) * (W // 2)))
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                _native.check(L.rk_pw_s2_wgrad_odd_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H, W,
+                                                       ws.data_ptr(), nbytes, stream), "rk_pw_s2_wgrad_odd_f32")
+        return dx, dw
+
+
+_ODD_PMIN, _ODD_PMAX = 37, 64        # k_pw_gemm_odd: frames per 256-column tile / LDS
+
+
+def _odd_common(conv, x, stride):
+    return (pointwise_mode() != "0" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
+            and not torch.is_autocast_enabled() and x.data_ptr() % 16 == 0
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (stride, stride)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0)
+
+
+def _eligible_odd(conv, x):
+    P = x.shape[2] * x.shape[3]
+    return P % 4 != 0 and _ODD_PMIN <= P <= _ODD_PMAX and _odd_common(conv, x, 1)
+
+
+def _eligible_s2_odd(conv, x):
+    H, W = x.shape[2], x.shape[3]
+    Po = (H // 2) * (W // 2)
+    return (H % 2 == 0 and W % 2 == 0 and Po % 4 != 0 and _ODD_PMIN <= Po <= _ODD_PMAX and _odd_common(conv, x, 2))
 
 
 def conv1x1(conv, x, residual=None):
@@ -189,6 +295,11 @@ def conv1x1(conv, x, residual=None):
         conv = conv[-1]
     if residual is None and _eligible_s2(conv, x):
         return _ConvS2Func.apply(x.contiguous(), conv.weight)
+    if x.dim() == 4 and x.is_contiguous():
+        if residual is None and _eligible_s2_odd(conv, x):
+            return _ConvS2OddFunc.apply(x, conv.weight)
+        if (_eligible_odd(conv, x) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))):
+            return _Conv1x1OddFunc.apply(x, conv.weight, residual)
     hip_gemm = _eligible(conv, x, residual is not None)
     if hip_gemm is None or (residual is not None and not (residual.is_contiguous() and residual.dtype == x.dtype)):
         y = conv(x)
@@ -282,7 +393,8 @@ def _strided_shortcut_ok(conv, x):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
             and conv.in_channels % 2 == 0 and conv.out_channels % 2 == 0
-            and max(conv.in_channels, conv.out_channels) <= _S2_CMAX and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+            and max(conv.in_channels, conv.out_channels) <= _S2_CMAX and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0)
 
 
 def _as3_stride_2(as3):

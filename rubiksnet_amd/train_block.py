@@ -65,16 +65,17 @@ def _finish(L, bn, stats, count, dev):
     """Tile partials -> (save_mean, save_invstd, a, b) of `bn`'s training forward; running statistics and
     num_batches_tracked updated exactly as nn.BatchNorm2d does."""
     C = bn.num_features
-    out = torch.empty(4, C, dtype=torch.float32, device=dev)
+    out = torch.empty(8, C, dtype=torch.float32, device=dev)         # rows 0-3: mean, invstd, a, b; rows 4-7: [C][4] packed
     momentum, counter = _count_batch(bn)
     tracked = bn.training and bn.track_running_stats
     rm = bn.running_mean if tracked else None
     rv = bn.running_var if tracked else None
     rc = L.rk_bn_finish_tiles_f32(stats.data_ptr(), stats.shape[1], count, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                   _ptr(rm), _ptr(rv), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
-                                  out[3].data_ptr(), C, float(bn.eps), float(momentum), _ptr(counter), _stream(dev))
+                                  out[3].data_ptr(), out[4].data_ptr(), C, float(bn.eps), float(momentum), _ptr(counter),
+                                  _stream(dev))
     _native.check(rc, "rk_bn_finish_tiles_f32")
-    return out            # rows: mean, invstd, a, b
+    return out            # rows: mean, invstd, a, b, then (a, b, mean, invstd) per channel packed as [C][4]
 
 
 def _bn_ok(bn):
@@ -256,8 +257,8 @@ class _FusedTrainBlock(torch.autograd.Function):
             bred = torch.empty(Cin, J, 2, dtype=torch.float32, device=dev)
             dzm = res if res is not None else torch.empty_like(x)             # (the residual may alias the result)
             _native.check(L.rk_pw_gemm_bnbwd_f32(w2.data_ptr(), dz.data_ptr(), _ptr(res), dzm.data_ptr(), Fr, Cmid, Cin, P,
-                                                 0, x.data_ptr(), bn1[2].data_ptr(), bn1[3].data_ptr(), bn1[0].data_ptr(),
-                                                 bn1[1].data_ptr(), bred.data_ptr(), J, st), "rk_pw_gemm_bnbwd_f32")
+                                                 0, x.data_ptr(), bn1[4].data_ptr(), bred.data_ptr(), J, st),
+                          "rk_pw_gemm_bnbwd_f32")
             k12 = torch.empty(2, Cin, dtype=torch.float32, device=dev)
             dg1 = torch.empty(Cin, dtype=torch.float32, device=dev)
             db1 = torch.empty(Cin, dtype=torch.float32, device=dev)
@@ -301,7 +302,7 @@ def fused_train_block(block, x):
     else:
         if not _conv_ok(block.shortcut, stride):
             return None
-        if stride == 2 and (H % 2 or W % 8):
+        if stride == 2 and (H % 2 or W % 2):
             return None
     stats_in = take_stats(x, Cin, Fr * H * W)
     x = x.contiguous()

@@ -129,6 +129,75 @@ def test_ineligible_layers_take_the_stock_path(monkeypatch):
     assert "Conv1x1Func" not in type(conv1x1(conv, x4).grad_fn).__name__
 
 
+ODD_CASES = [   # frames, Cin, Cout, H, W  (H * W % 4 != 0)
+    (5, 8, 12, 7, 7),          # one partial tile, partial last chunk of channels
+    (13, 432, 432, 7, 7),      # layer4 of Tiny: 7 row tiles, 3 column tiles, the last one ragged
+    (16, 216, 100, 7, 7),
+    (6, 20, 36, 9, 7),         # 63 pixels per plane
+    (40, 16, 16, 7, 7),        # several 256-column tiles, frames straddling them
+]
+
+
+@pytest.mark.parametrize("with_residual", [False, True])
+@pytest.mark.parametrize("case", ODD_CASES)
+def test_odd_planes_forward_and_gradients(case, with_residual):
+    """rk_pw_gemm_odd_f32 / rk_pw_wgrad_odd_f32 (7x7 planes: H * W % 4 != 0) against F.conv2d in fp64: forward (+ the
+    residual in the epilogue), d(input), d(weight)."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    Fr, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(Fr, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    dy = torch.randn(Fr, Cout, H, W, generator=g)
+    res = torch.randn(Fr, Cout, H, W, generator=g) if with_residual else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_residual else None
+    yr = F.conv2d(xr, wr) + (rr if with_residual else 0)
+    yr.backward(dy.double())
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xd = x.cuda().requires_grad_(True)
+    rd = res.cuda().requires_grad_(True) if with_residual else None
+    y = conv1x1(conv, xd, rd)
+    assert "Conv1x1OddFunc" in type(y.grad_fn).__name__
+    y.backward(dy.cuda())
+    pairs = [(y, yr), (xd.grad, xr.grad), (conv.weight.grad, wr.grad)] + ([(rd.grad, rr.grad)] if with_residual else [])
+    for got, ref in pairs:
+        ref = ref.detach()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.numpy(), rtol=0,
+                                   atol=3e-6 * max(1.0, float(ref.abs().max())) * max(Cin, Cout) ** 0.5)
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 14, 14, 12), (9, 216, 14, 14, 432), (5, 20, 18, 14, 24)])
+def test_strided_shortcut_onto_odd_planes(shape):
+    """The 14x14 -> 7x7 projecting shortcut (rk_pw_s2_*_odd_f32) against F.conv2d(stride=2) in fp64."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    Fr, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(Fr, Cin, H, W, generator=g)
+    conv = nn.Conv2d(Cin, Cout, 1, stride=2, bias=False)
+    dy = torch.randn(Fr, Cout, H // 2, W // 2, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=2)
+    ref.backward(dy.double())
+    conv = conv.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = conv1x1(conv, xg)
+    assert "ConvS2OddFunc" in type(y.grad_fn).__name__
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=0,
+                               atol=3e-6 * Cin ** 0.5 * float(ref.abs().max()))
+    y.backward(dy.cuda())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=0,
+                               atol=3e-6 * Cout ** 0.5 * float(xr.grad.abs().max()))
+    assert float(xg.grad[:, :, 1::2, :].abs().max()) == 0.0 and float(xg.grad[:, :, :, 1::2].abs().max()) == 0.0
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0,
+                               atol=1e-4 * float(wr.grad.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [(3, 3, 32, 40, 54), (2, 3, 224, 224, 72), (5, 2, 18, 16, 20), (2, 7, 8, 8, 150)])
 def test_stem_conv(shape):
     """The 3x3 / stride-2 / pad-1 first layer on the MFMA GEMM (im2col gathered on the fly) against F.conv2d in fp64;
@@ -152,7 +221,7 @@ def test_stem_conv(shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 6, 16, 24, 10), (2, 54, 112, 112, 54), (4, 54, 56, 56, 108), (5, 108, 28, 24, 216),
-                                   (2, 144, 28, 32, 288)])
+                                   (2, 144, 28, 32, 288), (5, 108, 28, 28, 216), (3, 10, 12, 20, 6)])   # Wo = 14, 10: groups wrap rows
 def test_strided_shortcut_conv(shape):
     """1x1 / stride-2 convolution (projecting shortcut) on the GEMM kernels -- strided gather forward, scattered
     d(input) with every element written, gathered d(weight) -- against F.conv2d in fp64."""

@@ -89,6 +89,7 @@ CASES = [
     (16, 32, 2, (2, 4, 28, 32)),        # downsampling block: strided shift + 1x1 / stride-2 shortcut
     (54, 54, 1, (1, 8, 28, 28)),        # Tiny's layer2 shape (one clip)
     (72, 144, 2, (1, 8, 56, 56)),       # Large's first layer2 block (one clip): > 128 output rows
+    (24, 48, 2, (2, 4, 28, 28)),        # 28 -> 14: output rows of 14 pixels (4-pixel groups wrap rows in the shortcut)
 ]
 
 
@@ -200,10 +201,12 @@ def test_gemm_statistics_epilogue(shape, K, M, relu_in):
     gamma, beta = torch.rand(M, device=DEV) + 0.5, torch.randn(M, device=DEV)
     rm, rv = torch.zeros(M, device=DEV), torch.ones(M, device=DEV)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
-    out = torch.empty(4, M, device=DEV)
+    out = torch.empty(8, M, device=DEV)
     _native.check(L.rk_bn_finish_tiles_f32(stats.data_ptr(), J, Fr * P, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
                                            rv.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
-                                           out[3].data_ptr(), M, 1e-5, 0.1, nbt.data_ptr(), st), "finish")
+                                           out[3].data_ptr(), out[4].data_ptr(), M, 1e-5, 0.1, nbt.data_ptr(), st), "finish")
+    packed = out[4:].reshape(M, 4)
+    assert torch.equal(packed, torch.stack([out[2], out[3], out[0], out[1]], dim=1))
     yg = y.cpu().double()                                           # statistics of what the kernel actually stored
     mean, var = yg.mean(dim=(0, 2)), yg.var(dim=(0, 2), unbiased=False)
     assert float((out[0].cpu().double() - mean).abs().max()) <= 1e-6 * 300
@@ -218,7 +221,7 @@ def test_gemm_statistics_epilogue(shape, K, M, relu_in):
     out2 = torch.empty(4, M, device=DEV)
     _native.check(L.rk_bn_finish_tiles_f32(stats2.data_ptr(), J, Fr * P, gamma.data_ptr(), beta.data_ptr(), None, None,
                                            out2[0].data_ptr(), out2[1].data_ptr(), out2[2].data_ptr(), out2[3].data_ptr(),
-                                           M, 1e-5, 0.1, None, st), "finish")
+                                           None, M, 1e-5, 0.1, None, st), "finish")
     np.testing.assert_allclose(out2[:2].cpu().numpy(), out[:2].cpu().numpy(), rtol=3e-6)
 
 
@@ -256,9 +259,9 @@ def test_dgrad_with_bn_backward_epilogue_and_prologue_wgrad(shape, K, M):
     J = int(L.rk_pw_tiles(Fr, P))
     bred = torch.zeros(C, J, 2, device=DEV)
     dzm = torch.empty(Fr, C, P, device=DEV)
+    pack = torch.stack([ad, bd, md, ivd], dim=1).contiguous()
     _native.check(L.rk_pw_gemm_bnbwd_f32(wd.data_ptr(), dzd.data_ptr(), None, dzm.data_ptr(), Fr, K, C, P, 0, xd.data_ptr(),
-                                         ad.data_ptr(), bd.data_ptr(), md.data_ptr(), ivd.data_ptr(), bred.data_ptr(), J, st),
-                  "bnbwd")
+                                         pack.data_ptr(), bred.data_ptr(), J, st), "bnbwd")
     k12, dg, db = torch.empty(2, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     _native.check(L.rk_bn_bwd_finish_tiles_f32(bred.data_ptr(), J, Fr * P, k12.data_ptr(), dg.data_ptr(), db.data_ptr(), C, st),
                   "bwd_finish")
