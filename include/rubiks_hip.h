@@ -52,7 +52,9 @@ enum {
     RK_ERR_BAD_STRIDE = -3,    /* stride <= 0 or padding < 0 (reference only prints, rubiks.cpp:162-164) */
     RK_ERR_WORKSPACE = -4,     /* workspace NULL or smaller than *_workspace_bytes() */
     RK_ERR_LAUNCH = -5,        /* hipGetLastError() after a launch was not hipSuccess */
-    RK_ERR_NO_DEVICE = -6      /* no usable HIP device */
+    RK_ERR_NO_DEVICE = -6,     /* no usable HIP device */
+    RK_ERR_UNSUPPORTED = -7    /* the fused entry point has no kernel for this configuration: nothing was launched, use
+                                  the unfused entry points (only the *_bn_* entry points return it) */
 };
 
 int rk_version(void);                 /* 1000*major + minor */
@@ -337,6 +339,21 @@ int rk_pw_s2_wgrad_odd_f32(const float* dY, const float* X, float* dW, int F, in
  *   - rk_bn_apply_affine_f32: y = relu?(a x + b) with the finished map (bn2 in front of the shift);
  *   - rk_bn_tile_stats_f32: the same tile statistics for a tensor no GEMM epilogue produced them for.
  * All fp32, P % 4 == 0; results match torch.nn.functional.batch_norm + relu (+ conv2d) and their autograd gradients. */
+/*   - relu(bn2(z)) is never stored either (f1 "and/or the preceding ReLU(BN2(.))"): the shift kernels read z and normalise
+ *     the landed planes in LDS (rk3d_forward_bn_f32); the backward (rk3d_backward_bn_f32) reads z for the x operand,
+ *     masks d(activation) with the ReLU on the way out (dz) and reduces bn2's sum(dz), sum(dz zhat) next to the d(shift)
+ *     partials: k12 [2][C], d(gamma), d(beta) come out of the same launch and rk_bn_bwd_dx_pre_f32 finishes d(z).
+ *     abmi: [C][4] = (a, b, mean, invstd) as rk_bn_finish_tiles_f32 packs it.  Stride 1 / pad 0 planes with W % 4 == 0
+ *     (56x56, 28x28, 112x112); RK_ERR_UNSUPPORTED otherwise (the caller normalises with rk_bn_apply_affine_f32). */
+int rk3d_forward_bn_f32(const float* z, const float* abmi, const float* shift, float* y, int N, int T, int C, int H,
+                        int W, int stride_T, int stride_H, int stride_W, int pad_T, int pad_H, int pad_W, int quantize,
+                        rk_stream_t stream);
+size_t rk3d_backward_bn_workspace_bytes(int N, int T, int C, int H, int W, int stride_T, int stride_H, int stride_W,
+                                        int pad_T, int pad_H, int pad_W);
+int rk3d_backward_bn_f32(const float* z, const float* abmi, const float* shift, const float* gy, float* dz, float* gshift,
+                         float* k12, float* dgamma, float* dbeta, int N, int T, int C, int H, int W, int stride_T,
+                         int stride_H, int stride_W, int pad_T, int pad_H, int pad_W, int normalize_grad, float t_factor,
+                         int quantize, void* workspace, size_t workspace_bytes, rk_stream_t stream);
 int rk_pw_tiles(int F, int P);
 int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, void* stats, int tiles,

@@ -61,6 +61,9 @@ SIGNATURES = {
     "rk_pw_s2_dgrad_odd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_s2_wgrad_odd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     # training-mode fusion of the block's BatchNorms into the GEMMs (include/rubiks_hip.h)
+    "rk3d_forward_bn_f32": (_i, [_p, _p, _p, _p] + _DIMS3 + [_i, _p]),
+    "rk3d_backward_bn_workspace_bytes": (_sz, _DIMS3),
+    "rk3d_backward_bn_f32": (_i, [_p] * 9 + _DIMS3 + [_i, ctypes.c_float, _i, _p, _sz, _p]),
     "rk_pw_tiles": (_i, [_i, _i]),
     "rk_pw_gemm_stats_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p]),
     "rk_stem_conv3x3s2_stats_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),

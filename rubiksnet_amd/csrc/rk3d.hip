@@ -171,6 +171,43 @@ size_t rk3d_backward_workspace_bytes(int N, int T, int C, int H, int W, int sT, 
     return (size_t)C * 3 * P * (size_t)(elem_size == 4 ? 16 : elem_size);
 }
 
+// ---- training fusion: the shift applied to relu(bn(z)) without the activation ever being stored (train_block.py) ----
+// Both return RK_ERR_UNSUPPORTED (no launch, nothing touched) when no fused kernel covers the configuration; the caller
+// then normalises with rk_bn_apply_affine_f32 and calls the plain entry points.
+int rk3d_forward_bn_f32(const float* z, const float* abmi, const float* shift, float* y, int N, int T, int C, int H,
+                        int W, int sT, int sH, int sW, int pT, int pH, int pW, int quantize, rk_stream_t stream_) {
+    if (!z || !abmi || !shift || !y) return RK_ERR_NULL_POINTER;
+    Dims3 d;
+    if (int rc = make_dims(d, N, T, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
+    if (quantize) return RK_ERR_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    const float4* pk = reinterpret_cast<const float4*>(abmi);
+    if (plane3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
+    if (dma3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
+    return RK_ERR_UNSUPPORTED;
+}
+size_t rk3d_backward_bn_workspace_bytes(int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW) {
+    // five partials per (channel, column-band) instead of three, as 16-byte granule pairs
+    return rk3d_backward_workspace_bytes(N, T, C, H, W, sT, sH, sW, pT, pH, pW, 4) / 3 * 5;
+}
+int rk3d_backward_bn_f32(const float* z, const float* abmi, const float* shift, const float* gy, float* dz, float* gshift,
+                         float* k12, float* dgamma, float* dbeta, int N, int T, int C, int H, int W, int sT, int sH,
+                         int sW, int pT, int pH, int pW, int normalize_grad, float t_factor, int quantize, void* ws,
+                         size_t ws_bytes, rk_stream_t stream_) {
+    if (!z || !abmi || !shift || !gy || !dz || !gshift || !k12 || !dgamma || !dbeta) return RK_ERR_NULL_POINTER;
+    Dims3 d;
+    if (int rc = make_dims(d, N, T, C, H, W, sT, sH, sW, pT, pH, pW)) return rc;
+    if (!ws || ws_bytes < rk3d_backward_bn_workspace_bytes(N, T, C, H, W, sT, sH, sW, pT, pH, pW)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    dma3d::BnFuse bn;
+    bn.abmi = reinterpret_cast<const float4*>(abmi);
+    bn.k12 = k12; bn.dgamma = dgamma; bn.dbeta = dbeta;
+    bn.inv_count = (float)(1.0 / ((double)N * T * H * W));
+    if (dma3d::launch_bwd_bn(z, shift, gy, dz, gshift, (float*)ws, d, normalize_grad, t_factor, quantize, bn, stream))
+        return launch_status();
+    return RK_ERR_UNSUPPORTED;
+}
+
 int rk3d_forward_f32(const float* x, const float* shift, float* y, int N, int T, int C, int H, int W, int sT,
                      int sH, int sW, int pT, int pH, int pW, int quantize, rk_stream_t stream) {
     return forward_impl<float>(x, shift, y, N, T, C, H, W, sT, sH, sW, pT, pH, pW, quantize, stream);

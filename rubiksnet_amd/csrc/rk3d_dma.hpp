@@ -46,10 +46,11 @@ using namespace dma;
 
 // ---------------------------------------------------------------------------------------------
 // Forward (NEGATE = false: src = x, dst = y) and d(x) alone (NEGATE = true: src = gy, dst = gx).
-template <bool NEGATE, int ROUNDS, int D, int OFF>
+template <bool NEGATE, int ROUNDS, int D, int OFF, bool BN = false>
 __device__ __forceinline__ void dma_interp_loop(const float* __restrict__ sp, float* __restrict__ dp, float4* ring,
                                                 const BDims& d, const Band& b, const Frac<float>& fT,
-                                                const Frac<float>& fH, const Frac<float>& fW, size_t tstride) {
+                                                const Frac<float>& fH, const Frac<float>& fW, size_t tstride,
+                                                float bn_a = 0.f, float bn_b = 0.f) {
     constexpr int R = D + 1;
     const int slot_f4 = b.cells_in + 1;
     BCells<ROUNDS> cs;
@@ -105,6 +106,7 @@ __device__ __forceinline__ void dma_interp_loop(const float* __restrict__ sp, fl
 #pragma nounroll
     for (int k = 0; k < steps; ++k) {
         wait_vmcnt(issued - mark[0]);                              // my pieces of plane k have landed
+        if (BN && in_range(t_first + k)) bn_taps<ROUNDS>(ring + slot * slot_f4, cs, bn_a, bn_b);   // z -> relu(bn(z))
         __syncthreads();                                           // everyone's have; plane k-1 is retired
         {
             int sn = slot + D; if (sn >= R) sn -= R;               // = slot of plane k-1, free now
@@ -124,10 +126,11 @@ __device__ __forceinline__ void dma_interp_loop(const float* __restrict__ sp, fl
     }
 }
 
-template <bool NEGATE, int ROUNDS, int D>
+template <bool NEGATE, int ROUNDS, int D, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict__ src,
                                                          const float* __restrict__ shift,
-                                                         float* __restrict__ dst, BDims d) {
+                                                         float* __restrict__ dst, BDims d,
+                                                         const float4* __restrict__ abmi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
     const int c = col % d.C, n = col / d.C;
@@ -139,6 +142,8 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
     const float* sp = src + ((size_t)n * d.T * d.C + c) * HW;
     float* dp = dst + ((size_t)n * d.T * d.C + c) * HW;
     const Band b = make_band(d, band, fH.fl);
+    float bn_a = 0.f, bn_b = 0.f;
+    if (BN) { const float4 pk = abmi[c]; bn_a = pk.x; bn_b = pk.y; }
 
     if (NEGATE && sT == 0 && sH == 0 && sW == 0) {                  // rubiks3d_kernels.cu:819-827: plain copy
         for (int t = 0; t < d.T; ++t)
@@ -148,10 +153,10 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
         return;
     }
     switch (((fW.fl % 4) + 4) % 4) {                                // wave-uniform
-        case 0: dma_interp_loop<NEGATE, ROUNDS, D, 0>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
-        case 1: dma_interp_loop<NEGATE, ROUNDS, D, 1>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
-        case 2: dma_interp_loop<NEGATE, ROUNDS, D, 2>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
-        default: dma_interp_loop<NEGATE, ROUNDS, D, 3>(sp, dp, ring, d, b, fT, fH, fW, tstride); break;
+        case 0: dma_interp_loop<NEGATE, ROUNDS, D, 0, BN>(sp, dp, ring, d, b, fT, fH, fW, tstride, bn_a, bn_b); break;
+        case 1: dma_interp_loop<NEGATE, ROUNDS, D, 1, BN>(sp, dp, ring, d, b, fT, fH, fW, tstride, bn_a, bn_b); break;
+        case 2: dma_interp_loop<NEGATE, ROUNDS, D, 2, BN>(sp, dp, ring, d, b, fT, fH, fW, tstride, bn_a, bn_b); break;
+        default: dma_interp_loop<NEGATE, ROUNDS, D, 3, BN>(sp, dp, ring, d, b, fT, fH, fW, tstride, bn_a, bn_b); break;
     }
 }
 
@@ -180,12 +185,18 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
 // "remainder >= 0.5" (rubiks3d_kernels.cu:819 ff. with the rounding of :76-93) -- which the walk already has at hand
 // (the tap cells of the current plane, the previous plane's choice in Qprev); d(shift) is unchanged (K2 takes the
 // fractional shift whatever quantize says).
-template <int ROUNDS, bool WRITE_GX, int DG, int DX, int OFF, bool QUANT = false>
+// BN (training fusion, train_block.py): xp holds z = the input of relu(bn2(.)), not the activation.  The window keeps the
+// raw z; the activation max(a z + b, 0) is recomputed where the d(shift) sums use it (a plane outside [0, T) is the ZERO
+// activation, not max(b, 0): its (a, b) are 0 for that step), and the first half of bn2's backward happens on the way
+// out: d(x) is masked with [a z + b > 0] and its sum(dz), sum(dz zhat), zhat = (z - mean) invstd, are reduced along with
+// the d(shift) partials (accB1, accB2) -- k_bn_bwd_reduce's full pass over (d(a2), z) disappears.
+template <int ROUNDS, bool WRITE_GX, int DG, int DX, int OFF, bool QUANT = false, bool BN = false>
 __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
                                                   float* __restrict__ op, float4* ring, const BDims& d,
                                                   const Band& b, const Frac<float>& fT, const Frac<float>& fH,
                                                   const Frac<float>& fW, size_t tstride, float& accT, float& accH,
-                                                  float& accW) {
+                                                  float& accW, float4 bnp = make_float4(0.f, 0.f, 0.f, 0.f),
+                                                  float* accB1 = nullptr, float* accB2 = nullptr) {
     static_assert(DG >= DX && DX >= 1, "gy runs at least as far ahead as x");
     constexpr int RG = DG + 1, RX = DX;
     const int gslot_f4 = b.cells_in + 1, xslot_f4 = b.cells_out + 1;
@@ -206,7 +217,7 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     const float* xsrc0 = xp + (size_t)b.out0 * 4;
     float* out0 = WRITE_GX ? op + (size_t)b.out0 * 4 : nullptr;
 
-    float sT = 0.f, sH = 0.f, sW = 0.f;
+    float sT = 0.f, sH = 0.f, sW = 0.f, sB1 = 0.f, sB2 = 0.f;
     int issued = 0;
     const bool t_integer = rT == 0;                               // wave-uniform
 #pragma nounroll
@@ -222,6 +233,8 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     float4 xa[ROUNDS], xb[ROUNDS], Qprev[ROUNDS];
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) xa[i] = xb[i] = Qprev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float aA = 0.f, bA = 0.f, aB = 0.f, bB = 0.f;                   // BN: affine map of the planes in xa / xb (0: no plane)
+    const bool bn_sums = BN && (!t_integer || walk == 1);          // the walk whose d(x) stores are final
 
     // step k: gy plane tg = t_first + k is in gy slot k % RG; to = k - 1; x[k] (-> xb) is in x slot k % RX
     const int t_first = fT.fl - (t_integer && walk == 0 ? 1 : 0), steps = d.T + 1;
@@ -262,8 +275,15 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     auto round = [&](int i, const float4* cur, float4* out, bool store) {
         const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
         const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
-        const float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
-        const float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
+        float xav[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
+        float xbv[4] = {xb[i].x, xb[i].y, xb[i].z, xb[i].w};
+        if (BN) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                xav[m] = fmaxf(fmaf(aA, xav[m], bA), 0.f);
+                xbv[m] = fmaxf(fmaf(aB, xbv[m], bB), 0.f);
+            }
+        }
         float col[5], q[4];
 #pragma unroll
         for (int m = 0; m < 5; ++m) col[m] = fmaf(uH, tap<OFF>(qa0, qa1, m), rH * tap<OFF>(qb0, qb1, m));
@@ -298,6 +318,19 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
                     o.z = uT * Qprev[i].z + rT * q[2];
                     o.w = uT * Qprev[i].w + rT * q[3];
                 }
+                if (BN) {                                         // the output plane is xa's: mask + bn2's reduction sums
+                    const float zv[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
+                    float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        ov[m] = xav[m] > 0.f ? ov[m] : 0.f;
+                        if (bn_sums) {
+                            sB1 += ov[m];
+                            sB2 = fmaf(ov[m], (zv[m] - bnp.z) * bnp.w, sB2);
+                        }
+                    }
+                    o = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                }
                 stream_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + cs.off0 + 4096 * i), o);
             }
             Qprev[i] = QUANT ? make_float4(nv[0], nv[1], nv[2], nv[3]) : make_float4(q[0], q[1], q[2], q[3]);
@@ -319,6 +352,11 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
         }
         xa[ROUNDS - 1] = xb[ROUNDS - 1];
         xb[ROUNDS - 1] = reinterpret_cast<const float4*>(xs)[cs.xown];
+        if (BN) {                                                 // x[k] exists for k < T; the window slides
+            aA = aB; bA = bB;
+            aB = k < d.T ? bnp.x : 0.f;
+            bB = k < d.T ? bnp.y : 0.f;
+        }
         {
             int gs = gslot + DG; if (gs >= RG) gs -= RG;          // gy slot of plane k-1: free now
             feed(t_first + k + DG, gs, k + DX, xslot);            // (the DMA waits for the LDS reads above)
@@ -341,6 +379,7 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     for (int k = 1; k < steps; ++k) step(k, std::true_type{});
     }
     accT = sT; accH = sH; accW = sW;
+    if (BN) { *accB1 = sB1; *accB2 = sB2; }
 }
 
 // Row-sum + K5 inside the backward launch (FUSED): rk_dma.hpp, "Row-sum of the d(shift) partials INSIDE the backward
@@ -351,10 +390,25 @@ struct Fin3 {
     int normalize;
     float t_factor;
 };
-__device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, int P) {
-    double s[3];
-    const bool ok = fin_collect<3>(fin.f, c, P, s);
+// training fusion (BN above): what the shift backward needs of bn2 and where bn2's backward constants go
+struct BnFuse {
+    const float4* abmi;           // [C] (a, b, mean, invstd)
+    float* k12;                   // [2][C]: sum(dz) / count, sum(dz zhat) / count
+    float* dgamma; float* dbeta;  // [C]
+    float inv_count;              // 1 / (N T H W)
+};
+template <int D>
+__device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, int P, const BnFuse& bn = BnFuse{}) {
+    double s[D];
+    const bool ok = fin_collect<D>(fin.f, c, P, s);
     if (threadIdx.x == 0) {
+        if constexpr (D == 5) {
+            const float nanv = __uint_as_float(0x7fc00000u);
+            bn.dbeta[c] = ok ? (float)s[3] : nanv;
+            bn.dgamma[c] = ok ? (float)s[4] : nanv;
+            bn.k12[c] = ok ? (float)(s[3] * (double)bn.inv_count) : nanv;
+            bn.k12[C + c] = ok ? (float)(s[4] * (double)bn.inv_count) : nanv;
+        }
         float gT = (float)s[0], gH = (float)s[1], gW = (float)s[2];
         if (fin.normalize) {
             float a, b, w;
@@ -371,18 +425,20 @@ __device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, in
 }
 
 // (forcing <= 128 VGPRs with __launch_bounds__(256, 4) on an earlier version spilled and ran 13% slower)
-template <int ROUNDS, bool WRITE_GX, int DG, int DX, bool FUSED, bool QUANT = false>
+template <int ROUNDS, bool WRITE_GX, int DG, int DX, bool FUSED, bool QUANT = false, bool BN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k3d_dma_backward(const float* __restrict__ x,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gy,
                                                            float* __restrict__ gx,
-                                                           float* __restrict__ part, BDims d, Dims3 gd, Fin3 fin) {
+                                                           float* __restrict__ part, BDims d, Dims3 gd, Fin3 fin,
+                                                           BnFuse bn = BnFuse{}) {
+    constexpr int ND = BN ? 5 : 3;                                  // partials per (channel, column-band)
     if (FUSED && (int)blockIdx.x >= fin.f.producers) {
-        if (threadIdx.x < kWave) finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands);
+        if (threadIdx.x < kWave) finalizer_wave<ND>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands, bn);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
-    __shared__ float red[3][kBlock / kWave];
+    __shared__ float red[ND][kBlock / kWave];
     // Two bands per plane: workgroups b and b + 8 (same XCD under the round-robin dispatch, launched together) take the two
     // bands of one plane, so the halo row of gy they share is an L2 hit for the second one instead of a second HBM read.
     int bid = (int)blockIdx.x;
@@ -391,7 +447,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const int band = bid % d.nbands, col = bid / d.nbands;
     const int c = col % d.C, n = col / d.C;
     const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
-    float accT = 0.f, accH = 0.f, accW = 0.f;
+    float accT = 0.f, accH = 0.f, accW = 0.f, accB1 = 0.f, accB2 = 0.f;
+    float4 bnp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BN) bnp = bn.abmi[c];
 
     if (split_shift(s1).r == 0 || split_shift(s2).r == 0) {
         // exactly-integer H or W component (lowered-index quirk / zero-shift copy branch): rare, per element.
@@ -400,8 +458,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
             if (WRITE_GX)
                 for (int t = 0; t < d.T; ++t)
                     backward_input_plane<float, QUANT>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+            if (BN) {
+                // x holds z: d(shift) from relu(bn(z)) evaluated per tap, then mask d(x) (each thread re-reads the
+                // elements it wrote itself) and bn2's reduction sums
+                const BnAct act{bnp.x, bnp.y};
+                for (int to = 0; to < d.T; ++to)
+                    shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW, act);
+                const int HW = d.H * d.W;
+                for (int t = 0; t < d.T; ++t) {
+                    const size_t base = (((size_t)n * d.T + t) * d.C + c) * HW;
+                    for (int e = threadIdx.x; e < HW; e += kBlock) {
+                        const float zv = x[base + e];
+                        const float dz = fmaf(bnp.x, zv, bnp.y) > 0.f ? gx[base + e] : 0.f;
+                        gx[base + e] = dz;
+                        accB1 += dz;
+                        accB2 = fmaf(dz, (zv - bnp.z) * bnp.w, accB2);
+                    }
+                }
+            } else {
             for (int to = 0; to < d.T; ++to)
                 shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
+            }
         }
     } else {
         const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r'
@@ -413,23 +490,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         const Band b = make_band(d, band, fH.fl);
         const int off = ((fW.fl % 4) + 4) % 4;
         switch (off) {   // wave-uniform; one specialised copy of the loop per tap offset
-            case 0: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 0, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
-            case 1: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 1, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
-            case 2: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 2, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
-            default: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 3, QUANT>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW); break;
+            case 0: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 0, QUANT, BN>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW, bnp, &accB1, &accB2); break;
+            case 1: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 1, QUANT, BN>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW, bnp, &accB1, &accB2); break;
+            case 2: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 2, QUANT, BN>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW, bnp, &accB1, &accB2); break;
+            default: dma_backward_loop<ROUNDS, WRITE_GX, DG, DX, 3, QUANT, BN>(xp, gp, op, ring, d, b, fT, fH, fW, tstride, accT, accH, accW, bnp, &accB1, &accB2); break;
         }
     }
 
     accT = group_sum(accT, kBlock, red[0]);
     accH = group_sum(accH, kBlock, red[1]);
     accW = group_sum(accW, kBlock, red[2]);
+    if (BN) {
+        accB1 = group_sum(accB1, kBlock, red[ND - 2]);
+        accB2 = group_sum(accB2, kBlock, red[ND - 1]);
+    }
     if (threadIdx.x == 0) {
         const int P = d.N * d.nbands;
-        const size_t at = (size_t)c * 3 * P + (size_t)n * d.nbands + band;
+        const size_t at = (size_t)c * ND * P + (size_t)n * d.nbands + band;
         if (FUSED) {
             fin_publish(fin.f, at, accT);
             fin_publish(fin.f, at + P, accH);
             fin_publish(fin.f, at + 2 * P, accW);
+            if (BN) {
+                fin_publish(fin.f, at + 3 * P, accB1);
+                fin_publish(fin.f, at + 4 * P, accB2);
+            }
         } else {
             part[at] = accT;
             part[at + P] = accH;
@@ -448,15 +533,16 @@ inline bool make_bdims(BDims& b, const Dims3& d, bool backward = false) {
     return choose_bands(b, backward);
 }
 
-template <bool NEGATE, int D>
-inline void launch_interp_d(const float* src, const float* shift, float* dst, const BDims& b, hipStream_t stream) {
+template <bool NEGATE, int D, bool BN = false>
+inline void launch_interp_d(const float* src, const float* shift, float* dst, const BDims& b, hipStream_t stream,
+                            const float4* abmi = nullptr) {
     const size_t lds = interp_ring_bytes(b, D);
     const dim3 grid((unsigned)(b.N * b.C * b.nbands)), block(kBlock);
     switch (rounds_of(b)) {
-        case 1: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 1, D>), grid, block, lds, stream, src, shift, dst, b); break;
-        case 2: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 2, D>), grid, block, lds, stream, src, shift, dst, b); break;
-        case 3: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 3, D>), grid, block, lds, stream, src, shift, dst, b); break;
-        default: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 4, D>), grid, block, lds, stream, src, shift, dst, b); break;
+        case 1: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 1, D, BN>), grid, block, lds, stream, src, shift, dst, b, abmi); break;
+        case 2: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 2, D, BN>), grid, block, lds, stream, src, shift, dst, b, abmi); break;
+        case 3: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 3, D, BN>), grid, block, lds, stream, src, shift, dst, b, abmi); break;
+        default: hipLaunchKernelGGL((k3d_dma_interp<NEGATE, 4, D, BN>), grid, block, lds, stream, src, shift, dst, b, abmi); break;
     }
 }
 
@@ -470,17 +556,27 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
     launch_interp_d<NEGATE, kDepth>(src, shift, dst, b, stream);
     return true;
 }
+// forward of relu(bn(z)) (train_block.py): abmi [C] = (a, b, mean, invstd)
+inline bool launch_forward_bn(const float* z, const float* shift, float* y, const float4* abmi, const Dims3& d,
+                              hipStream_t stream) {
+    constexpr int kDepth = 2;
+    BDims b;
+    if (!make_bdims(b, d) || !aligned16(z) || !aligned16(y) || !aligned16(abmi)) return false;
+    if (interp_ring_bytes(b, kDepth) > 64 * 1024) return false;
+    launch_interp_d<false, kDepth, true>(z, shift, y, b, stream, abmi);
+    return true;
+}
 
-template <bool WRITE_GX, int DG, int DX, bool FUSED, bool QUANT = false>
+template <bool WRITE_GX, int DG, int DX, bool FUSED, bool QUANT = false, bool BN = false>
 inline void launch_bwd_d(const float* x, const float* shift, const float* gy, float* gx, float* ws, const BDims& b,
-                         const Dims3& d, const Fin3& fin, hipStream_t stream) {
+                         const Dims3& d, const Fin3& fin, hipStream_t stream, const BnFuse& bn = BnFuse{}) {
     const size_t lds = bwd_ring_bytes(b, DG, DX);
     const dim3 grid((unsigned)(b.N * b.C * b.nbands + (FUSED ? b.C : 0))), block(kBlock);
     switch (rounds_of(b)) {
-        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
-        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
-        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
-        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX, FUSED, QUANT>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin); break;
+        case 1: hipLaunchKernelGGL((k3d_dma_backward<1, WRITE_GX, DG, DX, FUSED, QUANT, BN>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin, bn); break;
+        case 2: hipLaunchKernelGGL((k3d_dma_backward<2, WRITE_GX, DG, DX, FUSED, QUANT, BN>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin, bn); break;
+        case 3: hipLaunchKernelGGL((k3d_dma_backward<3, WRITE_GX, DG, DX, FUSED, QUANT, BN>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin, bn); break;
+        default: hipLaunchKernelGGL((k3d_dma_backward<4, WRITE_GX, DG, DX, FUSED, QUANT, BN>), grid, block, lds, stream, x, shift, gy, gx, ws, b, d, fin, bn); break;
     }
 }
 
@@ -512,6 +608,29 @@ inline int launch_bwd(const float* x, const float* shift, const float* gy, float
         else launch_bwd_d<false, 1, 1, false>(x, shift, gy, gx, ws, b, d, fin, stream);
     }
     return b.N * b.nbands;
+}
+
+// training fusion: x = z (bn2's input), gx <- masked d(z-activation), + bn2's backward constants.  ws: granule pairs
+// [C][5][P].  false = shape not handled here.
+inline bool launch_bwd_bn(const float* z, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                          const Dims3& d, int normalize, float t_factor, int quantize, const BnFuse& bn, hipStream_t stream) {
+    BDims b;
+    if (!make_bdims(b, d, true) || !aligned16(z) || !aligned16(gy) || !aligned16(gx) || !aligned16(bn.abmi)) return false;
+    if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return false;
+    Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = b.N * b.C * b.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+    if (quantize) launch_bwd_d<true, 1, 1, true, true, true>(z, shift, gy, gx, ws, b, d, fin, stream, bn);
+    else launch_bwd_d<true, 1, 1, true, false, true>(z, shift, gy, gx, ws, b, d, fin, stream, bn);
+    return true;
+}
+inline int bwd_bn_partials(const Dims3& d) {
+    BDims b;
+    return make_bdims(b, d, true) ? b.N * b.nbands : 0;
 }
 
 }  // namespace dma3d

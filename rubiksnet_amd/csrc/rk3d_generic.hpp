@@ -221,10 +221,16 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_input_generic(const T* __
 //
 // Partials layout: part[c][3][P], P = N*To, p = n*To + to.
 // This thread's share of the d(shift) terms of one output plane (n, to, c) (E cooperating threads).
-template <typename T>
+// what a tap of x means: the value itself, or -- training fusion, x = z -- relu(bn(z)) = max(a z + b, 0)
+struct NoAct { template <typename T> __device__ __forceinline__ T operator()(T v) const { return v; } };
+struct BnAct {
+    float a, b;
+    __device__ __forceinline__ float operator()(float v) const { return fmaxf(fmaf(a, v, b), 0.f); }
+};
+template <typename T, typename Act = NoAct>
 __device__ __forceinline__ void shift_grad_plane(const T* __restrict__ x, const T* __restrict__ shift,
                                                  const T* __restrict__ gy, const Dims3& d, int n, int to, int c,
-                                                 int e, int E, T& aT, T& aH, T& aW) {
+                                                 int e, int E, T& aT, T& aH, T& aW, const Act act = Act()) {
     const Frac<T> fT = split_shift(shift[c]);
     const Frac<T> fH = split_shift(shift[d.C + c]);
     const Frac<T> fW = split_shift(shift[2 * d.C + c]);
@@ -248,16 +254,16 @@ __device__ __forceinline__ void shift_grad_plane(const T* __restrict__ x, const 
         const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w1 >= 0 && w1 < d.W;
         T q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
         if (v0) {
-            if (mh0 && mw0) q000 = p0[h0 * d.W + w0];
-            if (mh0 && mw1) q001 = p0[h0 * d.W + w1];
-            if (mh1 && mw0) q010 = p0[h1 * d.W + w0];
-            if (mh1 && mw1) q011 = p0[h1 * d.W + w1];
+            if (mh0 && mw0) q000 = act(p0[h0 * d.W + w0]);
+            if (mh0 && mw1) q001 = act(p0[h0 * d.W + w1]);
+            if (mh1 && mw0) q010 = act(p0[h1 * d.W + w0]);
+            if (mh1 && mw1) q011 = act(p0[h1 * d.W + w1]);
         }
         if (v1) {
-            if (mh0 && mw0) q100 = p1[h0 * d.W + w0];
-            if (mh0 && mw1) q101 = p1[h0 * d.W + w1];
-            if (mh1 && mw0) q110 = p1[h1 * d.W + w0];
-            if (mh1 && mw1) q111 = p1[h1 * d.W + w1];
+            if (mh0 && mw0) q100 = act(p1[h0 * d.W + w0]);
+            if (mh0 && mw1) q101 = act(p1[h0 * d.W + w1]);
+            if (mh1 && mw0) q110 = act(p1[h1 * d.W + w0]);
+            if (mh1 && mw1) q111 = act(p1[h1 * d.W + w1]);
         }
         const T Ts = interp2(q000, q001, q010, q011, fH.r, fW.r);
         const T Tl = interp2(q100, q101, q110, q111, fH.r, fW.r);

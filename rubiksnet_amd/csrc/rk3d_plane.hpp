@@ -49,11 +49,11 @@ __device__ __forceinline__ Item my_item(const PDims& p) {
 }
 
 // Forward (NEGATE = false: src = x, dst = y) and d(x) alone (NEGATE = true: src = gy, dst = gx).
-template <bool NEGATE, int ROUNDS, int SP, int OFF>
+template <bool NEGATE, int ROUNDS, int SP, int OFF, bool BN = false>
 __device__ __forceinline__ void plane_interp_body(const float* __restrict__ sp, float* __restrict__ dp, float4* slots,
                                                   const BDims& d, const Band& b, const Frac<float>& fT,
                                                   const Frac<float>& fH, const Frac<float>& fW, size_t tstride,
-                                                  int to0) {
+                                                  int to0, float bn_a = 0.f, float bn_b = 0.f) {
     constexpr int NS = SP + 1;
     const int slot_f4 = b.cells_in + 1;
     BCells<ROUNDS> cs;
@@ -71,10 +71,12 @@ __device__ __forceinline__ void plane_interp_body(const float* __restrict__ sp, 
     const int t0 = to0 + fT.fl;
     int issued = 0;
     int mark[NS];
+    bool real[NS];                                                  // slot i holds a real plane (BN: to be normalised)
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int t = t0 + i;
         const bool wanted = i == 0 || to0 + i - 1 < d.T;           // ragged last group
+        real[i] = wanted && t >= 0 && t < d.T;
         if (wanted && t >= 0 && t < d.T) {
             // first reader of the last slot's plane keeps it in L2 for the next group's workgroup; every other
             // plane is on its last use
@@ -112,6 +114,7 @@ __device__ __forceinline__ void plane_interp_body(const float* __restrict__ sp, 
         const bool emit = s >= 1 && to0 + s - 1 < d.T;
         if (s >= 1 && !emit) break;                                 // wave-uniform
         wait_vmcnt(issued - mark[s]);                               // my pieces of slot s have landed
+        if (BN && real[s]) bn_taps<ROUNDS>(slots + s * slot_f4, cs, bn_a, bn_b);      // z -> relu(bn(z)), my pieces
         __syncthreads();                                            // everyone's have (and the zero fills)
         const float4* cur = slots + s * slot_f4;
         float4* out = reinterpret_cast<float4*>(out0 + (size_t)(emit ? to0 + s - 1 : 0) * tstride);
@@ -122,10 +125,11 @@ __device__ __forceinline__ void plane_interp_body(const float* __restrict__ sp, 
     }
 }
 
-template <bool NEGATE, int ROUNDS, int SP>
+template <bool NEGATE, int ROUNDS, int SP, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_plane_interp(const float* __restrict__ src,
                                                            const float* __restrict__ shift,
-                                                           float* __restrict__ dst, PDims p) {
+                                                           float* __restrict__ dst, PDims p,
+                                                           const float4* __restrict__ abmi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 slots[];
     const Item it = my_item(p);
     if (!it.live) return;
@@ -140,6 +144,8 @@ __global__ __launch_bounds__(kBlock) void k3d_plane_interp(const float* __restri
     float* dp = dst + ((size_t)n * d.T * d.C + c) * HW;
     const Band b = make_band(d, it.band, fH.fl);
     const int to0 = it.g * SP;
+    float bn_a = 0.f, bn_b = 0.f;
+    if (BN) { const float4 pk = abmi[c]; bn_a = pk.x; bn_b = pk.y; }
 
     if (NEGATE && sT == 0 && sH == 0 && sW == 0) {                  // rubiks3d_kernels.cu:819-827: plain copy
         for (int t = to0; t < to0 + SP && t < d.T; ++t)
@@ -149,10 +155,10 @@ __global__ __launch_bounds__(kBlock) void k3d_plane_interp(const float* __restri
         return;
     }
     switch (((fW.fl % 4) + 4) % 4) {                                // wave-uniform
-        case 0: plane_interp_body<NEGATE, ROUNDS, SP, 0>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0); break;
-        case 1: plane_interp_body<NEGATE, ROUNDS, SP, 1>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0); break;
-        case 2: plane_interp_body<NEGATE, ROUNDS, SP, 2>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0); break;
-        default: plane_interp_body<NEGATE, ROUNDS, SP, 3>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0); break;
+        case 0: plane_interp_body<NEGATE, ROUNDS, SP, 0, BN>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0, bn_a, bn_b); break;
+        case 1: plane_interp_body<NEGATE, ROUNDS, SP, 1, BN>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0, bn_a, bn_b); break;
+        case 2: plane_interp_body<NEGATE, ROUNDS, SP, 2, BN>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0, bn_a, bn_b); break;
+        default: plane_interp_body<NEGATE, ROUNDS, SP, 3, BN>(sp, dp, slots, d, b, fT, fH, fW, tstride, to0, bn_a, bn_b); break;
     }
 }
 
@@ -180,15 +186,16 @@ inline bool make_pdims(PDims& p, int& SP, const Dims3& d) {
 }
 inline size_t slots_bytes(const BDims& b, int nslots) { return (size_t)nslots * ((b.BH + 1) * b.W4 + 1) * 16; }
 
-template <bool NEGATE, int SP>
-inline void launch_interp_sp(const float* src, const float* shift, float* dst, const PDims& p, hipStream_t stream) {
+template <bool NEGATE, int SP, bool BN = false>
+inline void launch_interp_sp(const float* src, const float* shift, float* dst, const PDims& p, hipStream_t stream,
+                             const float4* abmi = nullptr) {
     const size_t lds = slots_bytes(p.b, SP + 1);
     const dim3 grid((unsigned)(p.b.N * p.G * p.R8)), block(kBlock);
     switch (rounds_of(p.b)) {
-        case 1: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 1, SP>), grid, block, lds, stream, src, shift, dst, p); break;
-        case 2: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 2, SP>), grid, block, lds, stream, src, shift, dst, p); break;
-        case 3: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 3, SP>), grid, block, lds, stream, src, shift, dst, p); break;
-        default: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 4, SP>), grid, block, lds, stream, src, shift, dst, p); break;
+        case 1: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 1, SP, BN>), grid, block, lds, stream, src, shift, dst, p, abmi); break;
+        case 2: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 2, SP, BN>), grid, block, lds, stream, src, shift, dst, p, abmi); break;
+        case 3: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 3, SP, BN>), grid, block, lds, stream, src, shift, dst, p, abmi); break;
+        default: hipLaunchKernelGGL((k3d_plane_interp<NEGATE, 4, SP, BN>), grid, block, lds, stream, src, shift, dst, p, abmi); break;
     }
 }
 
@@ -201,6 +208,17 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
     if (slots_bytes(p.b, SP + 1) > 40 * 1024) return false;          // >= 4 workgroups per CU
     if (SP == 4) launch_interp_sp<NEGATE, 4>(src, shift, dst, p, stream);
     else launch_interp_sp<NEGATE, 2>(src, shift, dst, p, stream);
+    return true;
+}
+// forward of relu(bn(z)) (train_block.py): abmi [C] = (a, b, mean, invstd)
+inline bool launch_forward_bn(const float* z, const float* shift, float* y, const float4* abmi, const Dims3& d,
+                              hipStream_t stream) {
+    PDims p;
+    int SP;
+    if (!make_pdims(p, SP, d) || !aligned16(z) || !aligned16(y) || !aligned16(abmi)) return false;
+    if (slots_bytes(p.b, SP + 1) > 40 * 1024) return false;
+    if (SP == 4) launch_interp_sp<false, 4, true>(z, shift, y, p, stream, abmi);
+    else launch_interp_sp<false, 2, true>(z, shift, y, p, stream, abmi);
     return true;
 }
 

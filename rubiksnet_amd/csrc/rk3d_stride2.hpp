@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_backward(const float* __restric
                                                           const float* __restrict__ gy, float* __restrict__ gx,
                                                           float* __restrict__ part, SDims d, Dims3 gd, dma3d::Fin3 fin) {
     if (FUSED && (int)blockIdx.x >= fin.f.producers) {
-        if (threadIdx.x < kWave) dma3d::finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands);
+        if (threadIdx.x < kWave) dma3d::finalizer_wave<3>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float4 ring[];

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
                                                               const float* __restrict__ gy, float* __restrict__ gx,
                                                               float* __restrict__ part, TDims d, Dims3 gd, dma3d::Fin3 fin) {
     if (FUSED && (int)blockIdx.x >= fin.f.producers) {                // row-sum + K5 inside the launch (rk_dma.hpp)
-        if (threadIdx.x < kWave) dma3d::finalizer_wave(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N);
+        if (threadIdx.x < kWave) dma3d::finalizer_wave<3>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];

@@ -27,6 +27,16 @@ __device__ __forceinline__ void stream_store(float4* p, const float4& v) {
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
 }
 
+// A wave-uniform pointer, guaranteed to sit in SGPRs (the "s" operand of the DMA asm below prints whatever register the
+// value lives in: in the BN variants of the forward kernels the compiler kept the plane pointer in VGPRs and the
+// assembler rejected `global_load_lds_dwordx4 v1, v[28:29]`).  Folds away when the value is scalar already.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
 // One wave-instruction of LDS-DMA, saddr form: lane l copies 16 B from (sbase + voff_l) to LDS byte
 // address lds_dst + 16*l.  The s_waitcnt lgkmcnt(0) orders it behind this wave's earlier LDS reads of
 // the slot being refilled (and covers the M0 write -> use hazard).
@@ -143,6 +153,7 @@ __device__ __forceinline__ void make_bcells(BCells<ROUNDS>& cs, const BDims& d, 
 // DMA the band of a tap plane (uniform pointer to slot cell 0's source, may lie before the plane) into a slot
 template <int ROUNDS, bool NT = true>
 __device__ __forceinline__ void dma_taps(const float* src0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
+    src0 = uniform_ptr(src0);
     const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i)
@@ -156,9 +167,28 @@ __device__ __forceinline__ void zero_taps(float4* slot, const BCells<ROUNDS>& cs
     for (int i = 0; i < ROUNDS; ++i)
         if (cs.in_act[i]) *reinterpret_cast<float4*>(base + 4096 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
+// Training fusion (train_block.py): the planes a shift kernel reads are z = conv2's output and the shift applies to
+// relu(bn2(z)) = max(a z + b, 0).  The wave that DMA'd a piece transforms it in place once it has landed (its own
+// counted vmcnt wait) and before the step's barrier -- the slot, not the taps, so that rows outside the plane and the
+// shared zero cell, which were never DMA'd, stay zero.  Same expression as k_bn_apply_affine: bit-identical to
+// "normalise, then shift".
+template <int ROUNDS>
+__device__ __forceinline__ void bn_taps(float4* slot, const BCells<ROUNDS>& cs, float a, float b) {
+    char* base = reinterpret_cast<char*>(slot) + cs.off0;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+        if (cs.in_act[i]) {
+            float4* p = reinterpret_cast<float4*>(base + 4096 * i);
+            float4 v = *p;
+            v.x = fmaxf(fmaf(a, v.x, b), 0.f); v.y = fmaxf(fmaf(a, v.y, b), 0.f);
+            v.z = fmaxf(fmaf(a, v.z, b), 0.f); v.w = fmaxf(fmaf(a, v.w, b), 0.f);
+            *p = v;
+        }
+}
 // DMA the thread's own output-aligned cells of a plane (uniform pointer to the band's first cell)
 template <int ROUNDS>
 __device__ __forceinline__ void dma_own(const float* band0, unsigned slot_addr, const BCells<ROUNDS>& cs) {
+    band0 = uniform_ptr(band0);
     const unsigned dst = slot_addr + __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6) * 1024u;
 #pragma unroll
     for (int i = 0; i + 1 < ROUNDS; ++i) dma16s(band0, cs.off0 + 4096 * i, dst + 4096u * i);

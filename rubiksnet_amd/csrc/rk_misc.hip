@@ -15,6 +15,7 @@ const char* rk_error_string(int code) {
         case RK_ERR_WORKSPACE: return "workspace is NULL or smaller than *_workspace_bytes()";
         case RK_ERR_LAUNCH: return "HIP kernel launch failed (hipGetLastError != hipSuccess)";
         case RK_ERR_NO_DEVICE: return "no usable HIP device";
+        case RK_ERR_UNSUPPORTED: return "no fused kernel for this configuration (use the unfused entry points)";
         default: return "unknown rubiks_hip error code";
     }
 }

@@ -212,3 +212,66 @@ def rubiks2d_backward(upstream_grad, input, shift, strides, paddings, normalize_
             int(bool(enable_shift_grad)), int(bool(quantize)), ws.data_ptr(), int(ws_bytes), _stream_ptr(dev))
     _native.check(rc, "rk2d_backward_" + sfx)
     return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training fusion (train_block.py): the 3-D shift applied to relu(bn(z)) without the activation being stored.  No
+# counterpart in the reference's extension module (its block runs BatchNorm, ReLU and the shift as separate layers,
+# rubiksnet/backbone.py:131-132); same calling style as the six callables above.  Both return UNSUPPORTED -- nothing
+# launched -- when no fused kernel covers the configuration.
+UNSUPPORTED = -7
+
+
+def rubiks_shift_3d_forward_bn_float(input, abmi, shift, strides, paddings, quantize, output):
+    """output = RubiksShift3D(relu(a * input + b)); abmi [C, 4] = (a, b, mean, invstd) per channel."""
+    _require(input, "input", torch.float32); _require(shift, "shift", torch.float32)
+    _require(output, "output", torch.float32); _require(abmi, "abmi", torch.float32)
+    dev = _same_device(input, shift, output, abmi)
+    s, p = _ints(strides, 3, "strides"), _ints(paddings, 3, "paddings")
+    N, T, C, H, W = input.shape
+    if tuple(shift.shape) != (3, C) or tuple(abmi.shape) != (C, 4):
+        raise RuntimeError("shift must be [3, C] and abmi [C, 4]")
+    L = _native.lib()
+    want = (N, L.rk_out_len(T, s[0], p[0]), C, L.rk_out_len(H, s[1], p[1]), L.rk_out_len(W, s[2], p[2]))
+    if tuple(output.shape) != want:
+        raise RuntimeError("output has shape %s, expected %s" % (tuple(output.shape), want))
+    if input.numel() == 0:
+        return UNSUPPORTED
+    with torch.cuda.device(dev):
+        rc = L.rk3d_forward_bn_f32(input.data_ptr(), abmi.data_ptr(), shift.data_ptr(), output.data_ptr(), N, T, C, H, W,
+                                   *s, *p, int(bool(quantize)), _stream_ptr(dev))
+    if rc == UNSUPPORTED:
+        return rc
+    _native.check(rc, "rk3d_forward_bn_f32")
+    return 0
+
+
+def rubiks_shift_3d_backward_bn_float(input, abmi, shift, output_grad, strides, paddings, input_grad, shift_grad, k12,
+                                      dgamma, dbeta, normalize_grad, normalize_t_factor, quantize):
+    """Backward of the above: input_grad = d(relu(bn(input))) masked by the ReLU, shift_grad as the plain operator, and
+    the BatchNorm backward's constants k12 [2, C] = (sum dz, sum dz zhat) / count, dgamma, dbeta [C]."""
+    for t, name in ((input, "input"), (abmi, "abmi"), (shift, "shift"), (output_grad, "output_grad"),
+                    (input_grad, "input_grad"), (shift_grad, "shift_grad"), (k12, "k12"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _require(t, name, torch.float32)
+    dev = _same_device(input, abmi, shift, output_grad, input_grad, shift_grad, k12, dgamma, dbeta)
+    s, p = _ints(strides, 3, "strides"), _ints(paddings, 3, "paddings")
+    N, T, C, H, W = input.shape
+    L = _native.lib()
+    want = (N, L.rk_out_len(T, s[0], p[0]), C, L.rk_out_len(H, s[1], p[1]), L.rk_out_len(W, s[2], p[2]))
+    if tuple(output_grad.shape) != want or input_grad.shape != input.shape:
+        raise RuntimeError("output_grad / input_grad have the wrong shape")
+    if tuple(shift_grad.shape) != (3, C) or tuple(k12.shape) != (2, C) or dgamma.numel() != C or dbeta.numel() != C:
+        raise RuntimeError("shift_grad [3, C], k12 [2, C], dgamma / dbeta [C] expected")
+    if input.numel() == 0:
+        return UNSUPPORTED
+    with torch.cuda.device(dev):
+        ws_bytes = int(L.rk3d_backward_bn_workspace_bytes(N, T, C, H, W, *s, *p))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        rc = L.rk3d_backward_bn_f32(input.data_ptr(), abmi.data_ptr(), shift.data_ptr(), output_grad.data_ptr(),
+                                    input_grad.data_ptr(), shift_grad.data_ptr(), k12.data_ptr(), dgamma.data_ptr(),
+                                    dbeta.data_ptr(), N, T, C, H, W, *s, *p, int(bool(normalize_grad)),
+                                    float(normalize_t_factor), int(bool(quantize)), ws.data_ptr(), ws_bytes, _stream_ptr(dev))
+    if rc == UNSUPPORTED:
+        return rc
+    _native.check(rc, "rk3d_backward_bn_f32")
+    return 0

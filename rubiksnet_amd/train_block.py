@@ -156,15 +156,21 @@ class _FusedTrainBlock(torch.autograd.Function):
                                                  bn1[2].data_ptr(), bn1[3].data_ptr(), 1, stats2.data_ptr(), J, st),
                           "rk_pw_gemm_stats_f32")
             bn2 = _finish(L, blk.bn2, stats2, Fr * P, dev)
-            a2 = torch.empty_like(z)
-            _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(), a2.data_ptr(), Fr,
-                                                   Cmid, P, 1, st), "rk_bn_apply_affine_f32")
-            # the shift, on [N, T, C, H, W] views of the same memory
+            # the shift of relu(bn2(z)), on [N, T, C, H, W] views of the same memory.  Fused (the kernels normalise the
+            # landed planes in LDS: the activation is never stored) where a fused kernel exists, else normalise + shift.
             N = Fr // plan.T
             s = torch.empty(Fr, Cmid, Ho, Wo, dtype=x.dtype, device=dev)
             shift_c = shift.detach().contiguous()
-            rubiksnet_cuda.rubiks_shift_3d_forward_float(a2.view(N, plan.T, Cmid, H, W), shift_c, s3, pd,
-                                                         bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
+            abmi2 = bn2[4:].view(Cmid, 4)
+            a2 = None
+            rc = rubiksnet_cuda.rubiks_shift_3d_forward_bn_float(z.view(N, plan.T, Cmid, H, W), abmi2, shift_c, s3, pd,
+                                                                 bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
+            if rc == rubiksnet_cuda.UNSUPPORTED:
+                a2 = torch.empty_like(z)
+                _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(), a2.data_ptr(),
+                                                       Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
+                rubiksnet_cuda.rubiks_shift_3d_forward_float(a2.view(N, plan.T, Cmid, H, W), shift_c, s3, pd,
+                                                             bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
             # conv3 + shortcut, + the statistics of the block's output for whoever normalises it next
             out = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
             Jo = int(L.rk_pw_tiles(Fr, Po))
@@ -173,7 +179,9 @@ class _FusedTrainBlock(torch.autograd.Function):
                                                  Cout, Po, 1, None, None, 0, stats_out.data_ptr(), Jo, st),
                           "rk_pw_gemm_stats_f32")
         ctx.plan = plan
-        ctx.save_for_backward(x, z, a2, s, bn1, bn2, g1, g2, b2, w2, w3, wsc if wsc is not None else w3, shift_c)
+        ctx.has_a2 = a2 is not None
+        ctx.save_for_backward(x, z, a2 if a2 is not None else z, s, bn1, bn2, g1, g2, b2, w2, w3,
+                              wsc if wsc is not None else w3, shift_c)
         ctx.mark_non_differentiable(stats_out)
         return out, stats_out
 
@@ -205,25 +213,44 @@ class _FusedTrainBlock(torch.autograd.Function):
                 ws, nb = wgrad_ws(Cmid, Cout, Po)
                 _native.check(L.rk_pw_wgrad_f32(dout.data_ptr(), s.data_ptr(), dw3.data_ptr(), Fr, Cmid, Cout, Po,
                                                 ws.data_ptr(), nb, st), "rk_pw_wgrad_f32")
-            # the shift: d(a2), d(shift)
+            # the shift and bn2: d(shift), and d(z) = bn2 + ReLU backward of d(a2).  Fused: the shift backward reads z,
+            # masks its d(x) with the ReLU and reduces bn2's sums in the same launch (dg2, db2, k12); one d(x) pass finishes.
             N = Fr // plan.T
-            da2 = torch.empty_like(a2)
-            dshift = torch.empty_like(shift) if need[7] else None
-            rubiksnet_cuda.rubiks_shift_3d_backward_float(
-                a2.view(N, plan.T, Cmid, H, W), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
-                da2.view(N, plan.T, Cmid, H, W), dshift, plan.layer.normalize_grad, plan.t_factor,
-                bool(plan.layer.quantize))
-            # bn2 + ReLU backward (reduction pass + d(x) pass)
+            dshift = torch.empty_like(shift)
             dz = torch.empty_like(z)
             dg2 = torch.empty(Cmid, dtype=torch.float32, device=dev)
             db2 = torch.empty(Cmid, dtype=torch.float32, device=dev)
-            nbn = int(L.rk_bn_workspace_bytes(Fr, Cmid, P))
-            wsb = torch.empty(max(nbn, 1), dtype=torch.uint8, device=dev)
-            _native.check(L.rk_bn_relu_backward_f32(da2.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
-                                                    bn2[0].data_ptr(), bn2[1].data_ptr(), None, dz.data_ptr(),
-                                                    dg2.data_ptr(), db2.data_ptr(), Fr, Cmid, P, 1, wsb.data_ptr(), nbn,
-                                                    st), "rk_bn_relu_backward_f32")
-            del da2
+            rc = rubiksnet_cuda.UNSUPPORTED
+            if not ctx.has_a2:
+                k12b = torch.empty(2, Cmid, dtype=torch.float32, device=dev)
+                dzm = dz                                  # masked d(a2) first, finished in place by the d(x) pass
+                rc = rubiksnet_cuda.rubiks_shift_3d_backward_bn_float(
+                    z.view(N, plan.T, Cmid, H, W), bn2[4:].view(Cmid, 4), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
+                    dzm.view(N, plan.T, Cmid, H, W), dshift, k12b, dg2, db2, plan.layer.normalize_grad, plan.t_factor,
+                    bool(plan.layer.quantize))
+                if rc == 0:
+                    _native.check(L.rk_bn_bwd_dx_pre_f32(dzm.data_ptr(), z.data_ptr(), g2.data_ptr(), bn2[0].data_ptr(),
+                                                         bn2[1].data_ptr(), k12b.data_ptr(), None, dz.data_ptr(), Fr, Cmid,
+                                                         P, st), "rk_bn_bwd_dx_pre_f32")
+                else:                                     # (no fused backward for a shape the forward took: recompute a2)
+                    a2 = torch.empty_like(z)
+                    _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(),
+                                                           a2.data_ptr(), Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
+            if rc != 0:
+                da2 = torch.empty_like(a2)
+                rubiksnet_cuda.rubiks_shift_3d_backward_float(
+                    a2.view(N, plan.T, Cmid, H, W), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
+                    da2.view(N, plan.T, Cmid, H, W), dshift, plan.layer.normalize_grad, plan.t_factor,
+                    bool(plan.layer.quantize))
+                nbn = int(L.rk_bn_workspace_bytes(Fr, Cmid, P))
+                wsb = torch.empty(max(nbn, 1), dtype=torch.uint8, device=dev)
+                _native.check(L.rk_bn_relu_backward_f32(da2.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
+                                                        bn2[0].data_ptr(), bn2[1].data_ptr(), None, dz.data_ptr(),
+                                                        dg2.data_ptr(), db2.data_ptr(), Fr, Cmid, P, 1, wsb.data_ptr(), nbn,
+                                                        st), "rk_bn_relu_backward_f32")
+                del da2
+            if not need[7]:
+                dshift = None
             # the projecting shortcut's share of d(relu(bn1(x))), handed to conv2's d(input) GEMM as its residual
             res, dwsc = None, None
             if not plan.identity:

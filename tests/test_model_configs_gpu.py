@@ -67,6 +67,51 @@ class _Taps:
                                     gs=None if shift_grad is None else _np(shift_grad))
             return ret
 
+        # the training fusion's shift entry points (train_block.py): same records, with x = relu(bn(z)) materialised by
+        # the stand-alone normalise kernel -- so the checks below read "normalise, then the oracle's shift"
+        fb3, bb3 = rc.rubiks_shift_3d_forward_bn_float, rc.rubiks_shift_3d_backward_bn_float
+
+        def _act(z, abmi):
+            from rubiksnet_amd import _native
+            N, T, C, H, W = z.shape
+            a, b = abmi[:, 0].contiguous(), abmi[:, 1].contiguous()
+            out = torch.empty_like(z)
+            _native.check(_native.lib().rk_bn_apply_affine_f32(z.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(), N * T,
+                                                               C, H * W, 1, torch.cuda.current_stream().cuda_stream), "apply")
+            return out
+
+        def fwd3bn(input, abmi, shift, strides, paddings, quantize, output):
+            ret = fb3(input, abmi, shift, strides, paddings, quantize, output)
+            if ret != 0:
+                return ret                                  # not fused: the plain entry point follows (and is tapped)
+            taps.calls["f3"] += 1
+            taps.fused_f3 += 1
+            key = (tuple(input.shape), tuple(strides))
+            if key not in taps.f3:
+                taps.f3[key] = dict(x=_np(_act(input, abmi)[:k]), shift=_np(shift), s=list(strides), p=list(paddings),
+                                    q=bool(quantize), y=_np(output[:k]))
+            return ret
+
+        def bwd3bn(input, abmi, shift, output_grad, strides, paddings, input_grad, shift_grad, k12, dgamma, dbeta,
+                   normalize_grad, normalize_t_factor, quantize):
+            ret = bb3(input, abmi, shift, output_grad, strides, paddings, input_grad, shift_grad, k12, dgamma, dbeta,
+                      normalize_grad, normalize_t_factor, quantize)
+            if ret != 0:
+                return ret
+            taps.calls["b3"] += 1
+            key = (tuple(input.shape), tuple(strides))
+            if key not in taps.b3:
+                a2 = _act(input, abmi)
+                taps.b3[key] = dict(x=_np(a2), shift=_np(shift), gy=_np(output_grad), s=list(strides), p=list(paddings),
+                                    q=bool(quantize), norm=bool(normalize_grad), tf=float(normalize_t_factor),
+                                    gx=_np(input_grad), gs=_np(shift_grad), masked=True, z=_np(input), abmi=_np(abmi),
+                                    k12=_np(k12), dgamma=_np(dgamma), dbeta=_np(dbeta))
+            return ret
+
+        self.fused_f3 = 0
+        monkeypatch.setattr(rc, "rubiks_shift_3d_forward_bn_float", fwd3bn)
+        monkeypatch.setattr(rc, "rubiks_shift_3d_backward_bn_float", bwd3bn)
+
         def fwd2(input, shift, strides, paddings, quantize, output):
             ret = f2(input=input, shift=shift, strides=strides, paddings=paddings, quantize=quantize, output=output)
             taps.calls["f2"] += 1
@@ -125,6 +170,19 @@ def _check_3d_forward(oracle, rec, what):
 def _check_3d_backward(oracle, rec, what):
     for key, r in rec.items():
         gx_ref, _ = oracle.rk3d_backward(r["gy"], r["x"], r["shift"], r["s"], r["p"], quantize=r["q"])
+        if r.get("masked"):
+            # fused with bn2's backward: d(x) leaves the kernel masked by the ReLU, and the BatchNorm constants with it
+            gx_ref = np.where(r["x"] > 0, gx_ref, np.float32(0))
+            mean, inv = r["abmi"][:, 2].astype(np.float64), r["abmi"][:, 3].astype(np.float64)
+            zhat = (r["z"].astype(np.float64) - mean[None, None, :, None, None]) * inv[None, None, :, None, None]
+            s1 = gx_ref.astype(np.float64).sum(axis=(0, 1, 3, 4))
+            s2 = (gx_ref.astype(np.float64) * zhat).sum(axis=(0, 1, 3, 4))
+            count = r["z"].size / r["z"].shape[2]
+            scale = max(1.0, float(np.abs(s2).max()), float(np.abs(s1).max()))
+            np.testing.assert_allclose(r["dbeta"], s1, rtol=0, atol=2e-5 * scale, err_msg="%s d(beta) %s" % (what, key))
+            np.testing.assert_allclose(r["dgamma"], s2, rtol=0, atol=2e-5 * scale, err_msg="%s d(gamma) %s" % (what, key))
+            np.testing.assert_allclose(r["k12"], np.stack([s1, s2]) / count, rtol=0, atol=2e-5 * scale / count,
+                                       err_msg="%s k12 %s" % (what, key))
         np.testing.assert_array_equal(r["gx"], gx_ref, err_msg="%s d(x) %s" % (what, key))
         _, gs_ref = oracle.rk3d_backward(r["gy"].astype(np.float64), r["x"].astype(np.float64),
                                          r["shift"].astype(np.float64), r["s"], r["p"], normalize_grad=r["norm"],
@@ -158,6 +216,7 @@ def test_large_train_step_shift_layers_match_oracle(oracle, monkeypatch):
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     assert taps.calls["f3"] == 51 and taps.calls["b3"] == 51 and taps.calls["f2"] == 0
+    assert taps.fused_f3 >= 10, "the stride-1 layers on 112 / 56 / 28-wide planes take the BatchNorm-fused shift kernels"
     want = {((B, 8, c, h, h), (1, s, s)) for c, h, s in _expected_shapes(72)}
     assert set(taps.f3) == want and set(taps.b3) == want
     _check_3d_forward(oracle, taps.f3, "large")
