@@ -184,6 +184,7 @@ int rk3d_forward_bn_f32(const float* z, const float* abmi, const float* shift, f
     const float4* pk = reinterpret_cast<const float4*>(abmi);
     if (plane3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
     if (dma3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
+    if (tile3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
     return RK_ERR_UNSUPPORTED;
 }
 size_t rk3d_backward_bn_workspace_bytes(int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW) {
@@ -204,6 +205,8 @@ int rk3d_backward_bn_f32(const float* z, const float* abmi, const float* shift, 
     bn.k12 = k12; bn.dgamma = dgamma; bn.dbeta = dbeta;
     bn.inv_count = (float)(1.0 / ((double)N * T * H * W));
     if (dma3d::launch_bwd_bn(z, shift, gy, dz, gshift, (float*)ws, d, normalize_grad, t_factor, quantize, bn, stream))
+        return launch_status();
+    if (!quantize && tile3d::launch_bwd_bn(z, shift, gy, dz, gshift, (float*)ws, d, normalize_grad, t_factor, bn, stream))
         return launch_status();
     return RK_ERR_UNSUPPORTED;
 }

@@ -64,9 +64,13 @@ __device__ __forceinline__ void taps(unsigned (&rel)[4], unsigned slot0, int flH
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool NEGATE>
+// BN (training fusion, train_block.py): src holds z and the shift applies to max(a z + b, 0): the wave normalises the
+// plane it DMA'd -- its own 49 pieces, in place, after its counted wait -- before it reads the taps.  A plane outside
+// [0, T) is a slot of zeros and stays one.
+template <bool NEGATE, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restrict__ src, const float* __restrict__ shift,
-                                                            float* __restrict__ dst, TDims d) {
+                                                            float* __restrict__ dst, TDims d,
+                                                            const float4* __restrict__ abmi = nullptr) {
     constexpr int R = 3;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (kWave - 1);
@@ -83,6 +87,8 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restr
     const int flH = __builtin_amdgcn_readfirstlane(fH.fl), flW = __builtin_amdgcn_readfirstlane(fW.fl);
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
     const long long tstride = (long long)d.C * kHW;
+    float bn_a = 0.f, bn_b = 0.f;
+    if (BN) { const float4 pk = abmi[c]; bn_a = uni(pk.x); bn_b = uni(pk.y); }
     const float* col = src + ((size_t)n * d.T * d.C + c) * kHW;       // plane t = 0 of my column
     float* optr = dst + ((size_t)n * d.T * d.C + c) * kHW + lane;     // my element of the next output plane
 
@@ -108,6 +114,13 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restr
         constexpr int S = decltype(SC)::value;
         constexpr int W0 = decltype(LATE)::value ? 8 : 0;
         if ((unsigned)(tf - 1) < (unsigned)d.T) wait_vmcnt(W0 + 1); else wait_vmcnt(W0);
+        if (BN && (unsigned)(tf - 2) < (unsigned)d.T && lane < kPieces) {      // the plane of this step: z -> relu(bn(z))
+            float4* pc = reinterpret_cast<float4*>(ring + S * kStride + lane * 16);
+            float4 v = *pc;
+            v.x = fmaxf(fmaf(bn_a, v.x, bn_b), 0.f); v.y = fmaxf(fmaf(bn_a, v.y, bn_b), 0.f);
+            v.z = fmaxf(fmaf(bn_a, v.z, bn_b), 0.f); v.w = fmaxf(fmaf(bn_a, v.w, bn_b), 0.f);
+            *pc = v;
+        }
         fetch((S + 2) % 3);                                          // into the slot of plane k-1
         f32x2 q[2][4];                                               // rounds (0,1) and (2,3) as packed pairs
 #pragma unroll
@@ -154,12 +167,16 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restr
 // VMEM order of a step j: [gy plane j+2][x plane j+2][4 stores, j >= 1 with WRITE_GX].
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool WRITE_GX, bool FUSED>
+// BN (training fusion): x holds z; the activation is recomputed where the d(shift) sums use it, d(x) leaves masked by
+// the ReLU and bn2's reduction sums ride along (rk3d_dma.hpp, dma_backward_loop).
+template <bool WRITE_GX, bool FUSED, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __restrict__ x, const float* __restrict__ shift,
                                                               const float* __restrict__ gy, float* __restrict__ gx,
-                                                              float* __restrict__ part, TDims d, Dims3 gd, dma3d::Fin3 fin) {
+                                                              float* __restrict__ part, TDims d, Dims3 gd, dma3d::Fin3 fin,
+                                                              dma3d::BnFuse bn = dma3d::BnFuse{}) {
+    constexpr int ND = BN ? 5 : 3;
     if (FUSED && (int)blockIdx.x >= fin.f.producers) {                // row-sum + K5 inside the launch (rk_dma.hpp)
-        if (threadIdx.x < kWave) dma3d::finalizer_wave<3>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N);
+        if (threadIdx.x < kWave) dma3d::finalizer_wave<ND>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N, bn);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -167,23 +184,40 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
     const long long id = (long long)blockIdx.x * (kBlock / kWave) + wave;
     if (id >= (long long)d.N * d.C) return;
     const int n = (int)(id / d.C), c = (int)(id - (long long)n * d.C);
-    const size_t at = (size_t)c * 3 * d.N + n;
-    auto publish = [&](float a, float b, float w) {
+    const size_t at = (size_t)c * ND * d.N + n;
+    auto publish = [&](float a, float b, float w, float b1 = 0.f, float b2 = 0.f) {
         if (lane == 0) {
-            if (FUSED) { fin_publish(fin.f, at, a); fin_publish(fin.f, at + d.N, b); fin_publish(fin.f, at + 2 * d.N, w); }
-            else { part[at] = a; part[at + d.N] = b; part[at + 2 * d.N] = w; }
+            if (FUSED) {
+                fin_publish(fin.f, at, a); fin_publish(fin.f, at + d.N, b); fin_publish(fin.f, at + 2 * d.N, w);
+                if (BN) { fin_publish(fin.f, at + 3 * (size_t)d.N, b1); fin_publish(fin.f, at + 4 * (size_t)d.N, b2); }
+            } else { part[at] = a; part[at + d.N] = b; part[at + 2 * d.N] = w; }
         }
     };
+    float4 bnp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BN) bnp = bn.abmi[c];
     const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
     const bool integer = split_shift(s0).r == 0 || split_shift(s1).r == 0 || split_shift(s2).r == 0;
     if (__builtin_amdgcn_readfirstlane((int)integer)) {
         // exactly-integer component: the reference's per-element formulation (lowered-index quirk :290-298)
-        float aT = 0.f, aH = 0.f, aW = 0.f;
+        float aT = 0.f, aH = 0.f, aW = 0.f, aB1 = 0.f, aB2 = 0.f;
+        const BnAct act{bnp.x, bnp.y};
         for (int t = 0; t < d.T; ++t) {
             if (WRITE_GX) backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, lane, kWave);
-            shift_grad_plane<float>(x, shift, gy, gd, n, t, c, lane, kWave, aT, aH, aW);
+            if (BN) {
+                shift_grad_plane<float>(x, shift, gy, gd, n, t, c, lane, kWave, aT, aH, aW, act);
+                const size_t base = (((size_t)n * d.T + t) * d.C + c) * kHW;
+                for (int e = lane; e < kHW; e += kWave) {             // (each lane re-reads the elements it wrote itself)
+                    const float zv = x[base + e];
+                    const float dz = fmaf(bnp.x, zv, bnp.y) > 0.f ? gx[base + e] : 0.f;
+                    gx[base + e] = dz;
+                    aB1 += dz;
+                    aB2 = fmaf(dz, (zv - bnp.z) * bnp.w, aB2);
+                }
+            } else {
+                shift_grad_plane<float>(x, shift, gy, gd, n, t, c, lane, kWave, aT, aH, aW);
+            }
         }
-        publish(wave_sum(aT), wave_sum(aH), wave_sum(aW));
+        publish(wave_sum(aT), wave_sum(aH), wave_sum(aW), wave_sum(aB1), wave_sum(aB2));
         return;
     }
     char* ring = lds_raw + wave * (6 * kStride);                      // slots 0..2: gy, 3..5: x
@@ -221,6 +255,9 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
     const f32x2 uW2 = {uW, uW}, rW2 = {rW, rW}, uH2 = {uH, uH}, rH2 = {rH, rH}, uT2 = {uT, uT}, rT2 = {rT, rT};
     f32x2 Qprev[2] = {{0.f, 0.f}, {0.f, 0.f}}, xa[2] = {{0.f, 0.f}, {0.f, 0.f}};
     f32x2 aT = {0.f, 0.f}, aH = {0.f, 0.f}, aW = {0.f, 0.f};
+    f32x2 za[2] = {{0.f, 0.f}, {0.f, 0.f}};                           // BN: raw z of the plane in xa
+    float aB1 = 0.f, aB2 = 0.f;
+    const float bn_a = uni(bnp.x), bn_b = uni(bnp.y), bn_m = uni(bnp.z), bn_i = uni(bnp.w);
     auto step = [&](auto SC, auto LATE, bool store) {
         constexpr int S = decltype(SC)::value;
         constexpr int W0 = (decltype(LATE)::value && WRITE_GX) ? 8 : 0;
@@ -228,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
         // (planes tg - 1, tx - 1 now) and the stores of steps k-2, k-1 (LATE: k >= 3)
         const int more = ((unsigned)(tg - 1) < (unsigned)d.T ? 1 : 0) + ((unsigned)(tx - 1) < (unsigned)d.T ? 1 : 0);
         if (more == 2) wait_vmcnt(W0 + 2); else if (more == 1) wait_vmcnt(W0 + 1); else wait_vmcnt(W0);
+        const bool xb_real = (unsigned)(tx - 2) < (unsigned)d.T;     // BN: the x plane of this step exists
         f32x2 q[2][4], xb[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -242,9 +280,15 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
         fetch((S + 2) % 3);                                          // into the slots of planes k-1 (their reads are done)
         asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[1][0]), "+v"(q[1][1]),
                           "+v"(q[1][2]), "+v"(q[1][3]), "+v"(xb[0]), "+v"(xb[1]));
-        f32x2 Qnew[2];
+        f32x2 Qnew[2], xold[2], zold[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            const f32x2 zb = xb[h];
+            if (BN) {                                                // activation of the plane (zero plane: zero activation)
+                const float ea = xb_real ? bn_a : 0.f, eb = xb_real ? bn_b : 0.f;
+                xb[h].x = fmaxf(fmaf(ea, zb.x, eb), 0.f);
+                xb[h].y = fmaxf(fmaf(ea, zb.y, eb), 0.f);
+            }
             const f32x2 la = q[h][0] * uW2 + q[h][1] * rW2, lb = q[h][2] * uW2 + q[h][3] * rW2;
             Qnew[h] = uH2 * la + rH2 * lb;                           // the reference's tree, contraction off
             const f32x2 c0 = fma2(uH2, q[h][0], rH2 * q[h][2]), c1 = fma2(uH2, q[h][1], rH2 * q[h][3]);
@@ -252,11 +296,22 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
             aT = fma2(Qnew[h], dx, aT);
             aH = fma2(la - lb, mx, aH);
             aW = fma2(c0 - c1, mx, aW);
-            xa[h] = xb[h];
+            xold[h] = xa[h]; zold[h] = za[h];
+            xa[h] = xb[h]; za[h] = zb;
         }
         if (WRITE_GX) {
             if (store) {
-                const f32x2 o0 = uT2 * Qprev[0] + rT2 * Qnew[0], o1 = uT2 * Qprev[1] + rT2 * Qnew[1];
+                f32x2 o0 = uT2 * Qprev[0] + rT2 * Qnew[0], o1 = uT2 * Qprev[1] + rT2 * Qnew[1];
+                if (BN) {                                            // output plane k-1 = the plane xa held: mask + bn2's sums
+                    const bool l3 = lane < kHW - 192;
+                    o0.x = xold[0].x > 0.f ? o0.x : 0.f;  o0.y = xold[0].y > 0.f ? o0.y : 0.f;
+                    o1.x = xold[1].x > 0.f ? o1.x : 0.f;  o1.y = (l3 && xold[1].y > 0.f) ? o1.y : 0.f;
+                    aB1 += (o0.x + o0.y) + (o1.x + o1.y);
+                    aB2 = fmaf(o0.x, (zold[0].x - bn_m) * bn_i, aB2);
+                    aB2 = fmaf(o0.y, (zold[0].y - bn_m) * bn_i, aB2);
+                    aB2 = fmaf(o1.x, (zold[1].x - bn_m) * bn_i, aB2);
+                    aB2 = fmaf(o1.y, (zold[1].y - bn_m) * bn_i, aB2);
+                }
                 __builtin_nontemporal_store(o0.x, optr);
                 __builtin_nontemporal_store(o0.y, optr + 64);
                 __builtin_nontemporal_store(o1.x, optr + 128);
@@ -279,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
             step(IC<2>{}, IC<1>{}, true); if (++k > d.T) break;
         }
     } while (false);
-    publish(wave_sum(aT.x + aT.y), wave_sum(aH.x + aH.y), wave_sum(aW.x + aW.y));
+    publish(wave_sum(aT.x + aT.y), wave_sum(aH.x + aH.y), wave_sum(aW.x + aW.y), wave_sum(aB1), wave_sum(aB2));
 }
 }  // namespace t14
 
@@ -298,6 +353,36 @@ inline bool launch_interp(const float* src, const float* shift, float* dst, cons
     const unsigned grid = (unsigned)(((long long)d.N * d.C + 3) / 4);
     hipLaunchKernelGGL((t14::k3d_tile14_interp<NEGATE>), dim3(grid), dim3(kBlock), 4 * 3 * t14::kStride, stream, src, shift,
                        dst, t);
+    return true;
+}
+
+// training fusion (BN): forward of relu(bn(z)) and its backward; false = not handled here
+inline bool launch_forward_bn(const float* z, const float* shift, float* y, const float4* abmi, const Dims3& d,
+                              hipStream_t stream) {
+    if (!s1p0(d) || !aligned16(z) || !aligned16(y) || !aligned16(abmi)) return false;
+    if (d.H != 14 || d.W != 14) return false;
+    TDims t{d.N, d.T, d.C};
+    const unsigned grid = (unsigned)(((long long)d.N * d.C + 3) / 4);
+    hipLaunchKernelGGL((t14::k3d_tile14_interp<false, true>), dim3(grid), dim3(kBlock), 4 * 3 * t14::kStride, stream, z, shift,
+                       y, t, abmi);
+    return true;
+}
+inline bool launch_bwd_bn(const float* z, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                          const Dims3& d, int normalize, float t_factor, const dma3d::BnFuse& bn, hipStream_t stream) {
+    if (!s1p0(d) || !aligned16(z) || !aligned16(gy) || !aligned16(gx) || !aligned16(bn.abmi)) return false;
+    if (d.H != 14 || d.W != 14) return false;
+    TDims t{d.N, d.T, d.C};
+    const unsigned producers = (unsigned)(((long long)d.N * d.C + 3) / 4);
+    const size_t lds = 4 * 6 * t14::kStride;
+    dma3d::Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = (int)producers;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+    hipLaunchKernelGGL((t14::k3d_tile14_backward<true, true, true>), dim3(producers + d.C), dim3(kBlock), lds, stream, z, shift,
+                       gy, gx, ws, t, d, fin, bn);
     return true;
 }
 
