@@ -135,6 +135,65 @@ def op_bench(env, steps, warmup, nsets=3, settle_s=0.4):
     }
 
 
+def _steady(fn, iters, settle_s):
+    """Untimed run-in (clock / power transient), then `iters` back-to-back launches between ONE pair of HIP events."""
+    t_end = time.perf_counter() + settle_s
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def tshift_bench(env, iters=60, settle_s=0.2):
+    """The temporal 3-tap filter of AttentionShift (rubiksnet/attention_shift.py:29-39; every block of the -aq networks,
+    BASELINE configs[4]) on the first-stage shape of Large-AQ at 32 clips: x [256, 72, 56, 56], bf16 and fp32, through
+    the C ABI.  Algorithmic bytes: forward 2 passes (read x, write y), backward 3 (read gy, read x, write gx)."""
+    import ctypes  # noqa: F401
+
+    from rubiksnet_amd import _native
+    L = _native.lib()
+    dev = env.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    NT, S, C, H = 256, 8, 72, 56
+    out = {"x": [NT, C, H, H], "n_segment": S}
+    for dtype, name in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+        sets = [(torch.randn(NT, C, H, H, device=dev).to(dtype), torch.randn(NT, C, H, H, device=dev).to(dtype),
+                 torch.empty(NT, C, H, H, device=dev, dtype=dtype)) for _ in range(3)]
+        taps = torch.softmax(torch.randn(C, 3, device=dev), 1).contiguous()
+        gtaps = torch.empty_like(taps)
+        wsb = int(L.rk_tshift3_backward_workspace_bytes(NT, S, C, H * H))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        it = [0]
+
+        def fwd():
+            x, _, y = sets[it[0] % 3]
+            it[0] += 1
+            _native.check(getattr(L, "rk_tshift3_forward_" + name)(x.data_ptr(), taps.data_ptr(), y.data_ptr(), NT, S, C,
+                                                                   H * H, stream), "rk_tshift3_forward")
+
+        def bwd():
+            x, g, y = sets[it[0] % 3]
+            it[0] += 1
+            _native.check(getattr(L, "rk_tshift3_backward_" + name)(g.data_ptr(), x.data_ptr(), taps.data_ptr(), y.data_ptr(),
+                                                                    gtaps.data_ptr(), NT, S, C, H * H, ws.data_ptr(), wsb,
+                                                                    stream), "rk_tshift3_backward")
+
+        tf, tb = _steady(fwd, iters, settle_s), _steady(bwd, iters, settle_s)
+        nb = NT * C * H * H * sets[0][0].element_size()
+        out[name] = {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": 2 * nb / tf / 1e9, "bwd_GBps": 3 * nb / tb / 1e9,
+                     "fwd_plus_bwd_frac_of_hbm_peak": 5 * nb / (tf + tb) / 1e9 / HBM_PEAK_GBS}
+        del sets
+        torch.cuda.empty_cache()
+    return out
+
+
 def op2d_bench(env, iters=60, settle_s=0.3):
     """the 2-D operator of the -aq networks on the same number of elements
     ([256,64,56,56] = 32 clips x 8 frames), fp32 and bf16.  Same method as the 3-D leg: an untimed run-in (the
@@ -184,6 +243,32 @@ def op2d_bench(env, iters=60, settle_s=0.3):
                      "fwd_plus_bwd_frac_of_hbm_peak": 5 * es * n / (tf + tb) / 1e9 / HBM_PEAK_GBS}
     out["shape"] = [SHAPE[0] * SHAPE[1]] + list(SHAPE[2:])
     out["timing"] = "untimed run-in, then back-to-back launches of one kernel between one pair of HIP events"
+    # SURVEY 8 a12's own example: the 35 layer-3 blocks of Large-AQ at 32 clips per GPU, [256, 288, 14, 14] in bf16
+    shape = (256, 288, 14, 14)
+    sets = [(torch.empty(shape, device=dev, dtype=torch.bfloat16).uniform_(-1, 1),
+             torch.empty(shape, device=dev, dtype=torch.bfloat16).uniform_(-1, 1),
+             torch.empty(shape, device=dev, dtype=torch.bfloat16), torch.empty(shape, device=dev, dtype=torch.bfloat16))
+            for _ in range(3)]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shift = (torch.rand(2, shape[1], generator=g) * 1.8 - 0.9).to(dev)          # fp32 table next to bf16 activations
+    gs = torch.empty_like(shift)
+    it = [0]
+
+    def fwd14():
+        x, _, y, _ = sets[it[0] % 3]
+        it[0] += 1
+        rubiksnet_cuda.rubiks2d_forward(x, shift, [1, 1], [0, 0], False, y)
+
+    def bwd14():
+        xb, gy, _, gx = sets[it[0] % 3]
+        it[0] += 1
+        rubiksnet_cuda.rubiks2d_backward(gy, xb, shift, [1, 1], [0, 0], True, True, False, gx, gs)
+
+    tf, tb = _steady(fwd14, iters, settle_s), _steady(bwd14, iters, settle_s)
+    n = sets[0][0].numel()
+    out["bf16_14x14"] = {"x": list(shape), "shift_dtype": "f32", "fwd_us": tf * 1e6, "bwd_us": tb * 1e6,
+                         "fwd_GBps": 4 * n / tf / 1e9, "bwd_GBps": 6 * n / tb / 1e9,
+                         "fwd_plus_bwd_frac_of_hbm_peak": 10 * n / (tf + tb) / 1e9 / HBM_PEAK_GBS}
     return out
 
 
@@ -196,6 +281,8 @@ def secondary_points(env, iters=40, settle_s=0.2):
     out = {}
     points = (("stride_1_2_2", (32, 8, 54, 112, 112), [1, 2, 2], False),
               ("planes_14x14", (32, 8, 216, 14, 14), [1, 1, 1], False),
+              ("planes_7x7", (32, 8, 576, 7, 7), [1, 1, 1], False),                 # layer4 of Large
+              ("stride_1_2_2_28to14", (32, 8, 288, 28, 28), [1, 2, 2], False),      # the third downsampling layer of Large
               ("quantize", SHAPE, [1, 1, 1], True))
     for name, shape, stride, quantize in points:
         N, T, C, H, W = shape
@@ -366,11 +453,18 @@ def model_bench(env, leg, per_gpu_batch, steps, warmup):
     for _ in range(warmup):
         step()
     dt = dp.timed_region(env, step, steps)
+    # the leg against its bound: every convolution / shift at its roofline, everything elementwise fused away
+    from rubiksnet_amd.roofline import model_bound
+    bound = model_bound(net, per_gpu_batch, train=(what != "forward"), compute="bf16" if amp is not None else "f32",
+                        storage_bytes=2 if amp is not None else 4)
+    ms = 1e3 * dt / steps
+    bound["frac"] = bound["bound_ms"] / ms
+    bound["clips_per_s_at_bound"] = per_gpu_batch * env.world_size / (bound["bound_ms"] * 1e-3)
     return {
         "name": "rubiksnet-%s%s" % (tier, "-aq" if variant.endswith("aq") else ""), "what": desc + ", synthetic clips",
         "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * env.world_size, "steps": steps,
-        "ms_per_step": 1e3 * dt / steps, "clips_per_s": per_gpu_batch * env.world_size * steps / dt,
-        "parallelism": "dp%d" % env.world_size,
+        "ms_per_step": ms, "clips_per_s": per_gpu_batch * env.world_size * steps / dt,
+        "parallelism": "dp%d" % env.world_size, "roofline": bound,
     }
 
 
@@ -500,6 +594,10 @@ def main():
     if env.is_main:
         rk2d = op2d_bench(env)
         secondary = secondary_points(env)
+        try:
+            tshift = tshift_bench(env)
+        except Exception as exc:
+            tshift = {"error": repr(exc)}
         if not args.no_cpu:                  # after every timed GPU leg
             cpu = cpu_baseline()
     dp.barrier(env)
@@ -541,6 +639,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "rk2d": rk2d,
+            "tshift": tshift,
             "secondary": secondary,
             "model": models.get("tiny-train"),
             "models": models,
