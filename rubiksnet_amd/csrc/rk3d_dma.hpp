@@ -44,6 +44,8 @@ namespace dma3d {
 
 using namespace dma;
 
+__device__ __forceinline__ float tap4(const float4& v, int m) { return m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w; }
+
 // ---------------------------------------------------------------------------------------------
 // Forward (NEGATE = false: src = x, dst = y) and d(x) alone (NEGATE = true: src = gy, dst = gx).
 template <bool NEGATE, int ROUNDS, int D, int OFF, bool BN = false>
@@ -174,12 +176,13 @@ __global__ __launch_bounds__(kBlock) void k3d_dma_interp(const float* __restrict
 // Integer temporal shift (every channel of create_3d_from_2d(init_mode="tsm"), the reference's default,
 // layer.py:137-141): the reference lowers the small temporal index by one (rubiks3d_kernels.cu:290-298) and uses that
 // lowered plane, with weight 1 - rT = 1, in the H and W faces too (:362-431), which in this adjoint form reads
-//     gT = sum_k <x[k], Q(k-1)> - <x[k-1], Q(k)>,   gH = sum_k <x[k-1], QH(k)>,   gW = sum_k <x[k-1], QW(k)>:
-// walk B (this plane order, coefficients (0, -1, 0, 1)) gives the second gT term, gH, gW and d(x); walk A (gy planes
-// one step later, t_first - 1, coefficients (1, 0, 0, 0)) gives the first gT term.  Walk A runs FIRST and its
-// stores to gx are overwritten by walk B's (same thread, same addresses, in order).  Twice the traffic for such a
-// channel instead of the per-element path on one workgroup per column.  The walk loop sits INSIDE each tap-offset
-// copy: around the switch over the copies the compiler hoists the set-up of all four out of it (256 VGPRs).
+//     gT = sum_k <x[k], Q(k-1)> - <x[k-1], Q(k)>,   gH = sum_k <x[k-1], QH(k)>,   gW = sum_k <x[k-1], QW(k)>.
+// Q(k-1) is the field the step before left in Qprev, so ONE walk does it: gT += Qprev (cp xb) + Q (ca xa) with
+// (cb, ca, cp, mb, ma) = (0, -1, 1, 0, 1) against the ordinary channel's (1, -1, 0, 1-r'T, r'T).  Q(-1) -- gy plane
+// fl'T - 1, paired with x[0] -- may be a real plane, so such a channel starts one plane earlier (T + 2 steps, x[-1] = 0):
+// 1.1x the traffic of an ordinary channel.  (Round 2 walked the column twice, 2x: 221 us against 112 us at
+// [32,8,64,56,56] with the tsm table.)  The walk loop sits INSIDE each tap-offset copy: around the switch over the
+// copies the compiler hoists the set-up of all four out of it (256 VGPRs).
 
 // QUANT (quantize = True): d(x) is the single nearest tap -- plane fl'T or fl'T + 1, row a or b, column m or m + 1 by
 // "remainder >= 0.5" (rubiks3d_kernels.cu:819 ff. with the rounding of :76-93) -- which the walk already has at hand
@@ -220,24 +223,20 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
     float sT = 0.f, sH = 0.f, sW = 0.f, sB1 = 0.f, sB2 = 0.f;
     int issued = 0;
     const bool t_integer = rT == 0;                               // wave-uniform
-#pragma nounroll
-    for (int walk = t_integer ? 0 : 1; walk < 2; ++walk) {
-    const float cb = t_integer ? (walk == 0 ? 1.f : 0.f) : 1.f, ca = t_integer ? (walk == 0 ? 0.f : -1.f) : -1.f;
-    const float mb = t_integer ? 0.f : uT, ma = t_integer ? (walk == 0 ? 0.f : 1.f) : rT;
-    if (walk == 1 && t_integer) {
-        // walk A's trailing prefetches (planes it never consumed) must land before walk B's prologue zero-fills the
-        // same slots, and every wave must be done reading the ring
-        wait_vmcnt(0);
-        __syncthreads();
-    }
+    const int early = t_integer ? 1 : 0;                         // integer temporal shift: one leading step for Q(-1)
+    const float cb = t_integer ? 0.f : 1.f, ca = -1.f, cp = t_integer ? 1.f : 0.f;
+    const float mb = t_integer ? 0.f : uT, ma = t_integer ? 1.f : rT;
     float4 xa[ROUNDS], xb[ROUNDS], Qprev[ROUNDS];
+    float4 Qfield[(QUANT || !WRITE_GX) ? ROUNDS : 1];            // the previous plane's field when Qprev does not hold it
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) xa[i] = xb[i] = Qprev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < ((QUANT || !WRITE_GX) ? ROUNDS : 1); ++i) Qfield[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     float aA = 0.f, bA = 0.f, aB = 0.f, bB = 0.f;                   // BN: affine map of the planes in xa / xb (0: no plane)
-    const bool bn_sums = BN && (!t_integer || walk == 1);          // the walk whose d(x) stores are final
+    const bool bn_sums = BN;
 
-    // step k: gy plane tg = t_first + k is in gy slot k % RG; to = k - 1; x[k] (-> xb) is in x slot k % RX
-    const int t_first = fT.fl - (t_integer && walk == 0 ? 1 : 0), steps = d.T + 1;
+    // step k: gy plane tg = t_first + k is in gy slot k % RG; to = k - 1 - early; x[k - early] (-> xb) is in x slot k % RX
+    const int t_first = fT.fl - early, steps = d.T + 1 + early;
     auto in_range = [&](int t) { return t >= 0 && t < d.T; };
     auto feed = [&](int tg, int gs, int tx, int xs) {               // DMA when the plane exists, zeros when not
         if (in_range(tg)) {
@@ -247,7 +246,7 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
             zero_taps<ROUNDS>(gring + gs * gslot_f4, cs);
         }
         if (in_range(tx)) {
-            dma_own<ROUNDS>(xsrc0 + (size_t)tx * tstride, xaddr + xs * xslot_bytes, cs);
+            dma_own<ROUNDS>(xsrc0 + (ptrdiff_t)tx * (ptrdiff_t)tstride, xaddr + xs * xslot_bytes, cs);
             issued += cs.n_out_wave;
         } else {
             zero_own<ROUNDS>(xring + xs * xslot_f4, cs);
@@ -265,8 +264,12 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
             zero_taps<ROUNDS>(gring + j * gslot_f4, cs);
         }
         if (j < DX) {
-            if (in_range(j)) { dma_own<ROUNDS>(xsrc0 + (size_t)j * tstride, xaddr + j * xslot_bytes, cs); issued += cs.n_out_wave; }
-            else zero_own<ROUNDS>(xring + j * xslot_f4, cs);
+            if (in_range(j - early)) {
+                dma_own<ROUNDS>(xsrc0 + (ptrdiff_t)(j - early) * (ptrdiff_t)tstride, xaddr + j * xslot_bytes, cs);
+                issued += cs.n_out_wave;
+            } else {
+                zero_own<ROUNDS>(xring + j * xslot_f4, cs);
+            }
             mark[j] = issued;
         }
     }
@@ -295,6 +298,8 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
             const float dx = fmaf(cb, xbv[m], ca * xav[m]);
             const float mx = fmaf(mb, xbv[m], ma * xav[m]);
             sT = fmaf(q[m], dx, sT);
+            sT = fmaf(tap4((QUANT || !WRITE_GX) ? Qfield[i] : Qprev[i], m), cp * xbv[m], sT);   // integer temporal shift:
+                                                                  // + <x[k], Q(k-1)> (cp = 0 for every other channel)
             sH = fmaf(la - lb, mx, sH);
             sW = fmaf(col[m] - col[m + 1], mx, sW);
         }
@@ -335,6 +340,7 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
             }
             Qprev[i] = QUANT ? make_float4(nv[0], nv[1], nv[2], nv[3]) : make_float4(q[0], q[1], q[2], q[3]);
         }
+        if (QUANT || !WRITE_GX) Qfield[i] = make_float4(q[0], q[1], q[2], q[3]);   // (else Qprev is the field itself)
     };
 
     int gslot = 0, xslot = 0;
@@ -354,19 +360,19 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
         xb[ROUNDS - 1] = reinterpret_cast<const float4*>(xs)[cs.xown];
         if (BN) {                                                 // x[k] exists for k < T; the window slides
             aA = aB; bA = bB;
-            aB = k < d.T ? bnp.x : 0.f;
-            bB = k < d.T ? bnp.y : 0.f;
+            aB = in_range(k - early) ? bnp.x : 0.f;
+            bB = in_range(k - early) ? bnp.y : 0.f;
         }
         {
             int gs = gslot + DG; if (gs >= RG) gs -= RG;          // gy slot of plane k-1: free now
-            feed(t_first + k + DG, gs, k + DX, xslot);            // (the DMA waits for the LDS reads above)
+            feed(t_first + k + DG, gs, k + DX - early, xslot);    // (the DMA waits for the LDS reads above)
 #pragma unroll
             for (int j = 0; j + 1 < DX; ++j) mark[j] = mark[j + 1];
             mark[DX - 1] = issued;
         }
         const float4* cur = gring + gslot * gslot_f4;
-        constexpr bool emit = WRITE_GX && EMIT;                   // output plane to = k - 1
-        float4* out = reinterpret_cast<float4*>(out0 + (size_t)(emit ? k - 1 : 0) * tstride);
+        constexpr bool emit = WRITE_GX && EMIT;                   // output plane to = k - 1 - early
+        float4* out = reinterpret_cast<float4*>(out0 + (size_t)(emit ? k - 1 - early : 0) * tstride);
 #pragma unroll
         for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, out, emit);
         if (cs.tail_on) round(ROUNDS - 1, cur, out, emit && cs.tail_live);
@@ -375,9 +381,9 @@ __device__ __forceinline__ void dma_backward_loop(const float* __restrict__ xp, 
         if (++xslot == RX) xslot = 0;
     };
     step(0, std::false_type{});
+    if (early) step(1, std::false_type{});
 #pragma nounroll
-    for (int k = 1; k < steps; ++k) step(k, std::true_type{});
-    }
+    for (int k = 1 + early; k < steps; ++k) step(k, std::true_type{});
     accT = sT; accH = sH; accW = sW;
     if (BN) { *accB1 = sB1; *accB2 = sB2; }
 }
