@@ -185,6 +185,7 @@ int rk3d_forward_bn_f32(const float* z, const float* abmi, const float* shift, f
     if (plane3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
     if (dma3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
     if (tile3d::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
+    if (s2::launch_forward_bn(z, shift, y, pk, d, stream)) return launch_status();
     return RK_ERR_UNSUPPORTED;
 }
 size_t rk3d_backward_bn_workspace_bytes(int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW) {
@@ -207,6 +208,8 @@ int rk3d_backward_bn_f32(const float* z, const float* abmi, const float* shift, 
     if (dma3d::launch_bwd_bn(z, shift, gy, dz, gshift, (float*)ws, d, normalize_grad, t_factor, quantize, bn, stream))
         return launch_status();
     if (!quantize && tile3d::launch_bwd_bn(z, shift, gy, dz, gshift, (float*)ws, d, normalize_grad, t_factor, bn, stream))
+        return launch_status();
+    if (!quantize && s2::launch_backward_bn(z, shift, gy, dz, gshift, (float*)ws, d, normalize_grad, t_factor, bn, stream))
         return launch_status();
     return RK_ERR_UNSUPPORTED;
 }

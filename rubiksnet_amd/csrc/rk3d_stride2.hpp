@@ -103,11 +103,13 @@ __device__ __forceinline__ Window make_window(const SDims& d, const SBand& b, in
 
 // ---------------------------------------------------------------------------------------------
 // Forward.
-template <int DR, int D, int OFF>
+// BN (training fusion, train_block.py): xp holds z, the shift applies to max(a z + b, 0); the landed pieces of a plane are
+// normalised in the slot by the wave that DMA'd them (rk_dma.hpp bn_taps).
+template <int DR, int D, int OFF, bool BN = false>
 __device__ __forceinline__ void forward_loop(const float* __restrict__ xp, float* __restrict__ yp, float4* ring,
                                              const SDims& d, const SBand& b, const Frac<float>& fT,
                                              const Frac<float>& fH, const Frac<float>& fW, size_t tstride_in,
-                                             size_t tstride_out) {
+                                             size_t tstride_out, float bn_a = 0.f, float bn_b = 0.f) {
     constexpr int R = D + 1;
     const int slot_f4 = b.cells_in + 1;
     BCells<DR> cs;
@@ -143,6 +145,7 @@ __device__ __forceinline__ void forward_loop(const float* __restrict__ xp, float
 #pragma nounroll
     for (int k = 0; k < steps; ++k) {
         wait_vmcnt(issued - mark[0]);                              // my pieces of plane k have landed
+        if (BN && in_range(t_first + k)) bn_taps<DR>(ring + slot * slot_f4, cs, bn_a, bn_b);
         __syncthreads();                                           // everyone's have; plane k-1 is retired
         {
             int sn = slot + D; if (sn >= R) sn -= R;
@@ -178,9 +181,10 @@ __device__ __forceinline__ void forward_loop(const float* __restrict__ xp, float
     }
 }
 
-template <int DR, int D>
+template <int DR, int D, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_s2_forward(const float* __restrict__ x, const float* __restrict__ shift,
-                                                         float* __restrict__ y, SDims d) {
+                                                         float* __restrict__ y, SDims d,
+                                                         const float4* __restrict__ abmi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
     const int c = col % d.C, n = col / d.C;
@@ -189,11 +193,13 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_forward(const float* __restrict
     const float* xp = x + ((size_t)n * d.T * d.C + c) * d.H * d.W;
     float* yp = y + ((size_t)n * d.T * d.C + c) * d.Ho * d.Wo;
     const SBand b = make_sband(d, band, fH.fl);
+    float bn_a = 0.f, bn_b = 0.f;
+    if (BN) { const float4 pk = abmi[c]; bn_a = pk.x; bn_b = pk.y; }
     switch (((fW.fl % 4) + 4) % 4) {                                // wave-uniform
-        case 0: forward_loop<DR, D, 0>(xp, yp, ring, d, b, fT, fH, fW, tin, tout); break;
-        case 1: forward_loop<DR, D, 1>(xp, yp, ring, d, b, fT, fH, fW, tin, tout); break;
-        case 2: forward_loop<DR, D, 2>(xp, yp, ring, d, b, fT, fH, fW, tin, tout); break;
-        default: forward_loop<DR, D, 3>(xp, yp, ring, d, b, fT, fH, fW, tin, tout); break;
+        case 0: forward_loop<DR, D, 0, BN>(xp, yp, ring, d, b, fT, fH, fW, tin, tout, bn_a, bn_b); break;
+        case 1: forward_loop<DR, D, 1, BN>(xp, yp, ring, d, b, fT, fH, fW, tin, tout, bn_a, bn_b); break;
+        case 2: forward_loop<DR, D, 2, BN>(xp, yp, ring, d, b, fT, fH, fW, tin, tout, bn_a, bn_b); break;
+        default: forward_loop<DR, D, 3, BN>(xp, yp, ring, d, b, fT, fH, fW, tin, tout, bn_a, bn_b); break;
     }
 }
 
@@ -210,12 +216,17 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_forward(const float* __restrict
 // slot's geometry (window values land at their unaligned columns, cells no window covers stay zero), copied out as
 // aligned 16-byte nt stores by the lanes that DMA the same cells of x.  gx rows that no band covers (fl'H != -1)
 // are zero-filled by the first / last band up front.  Any exactly-integer shift component: per-element path.
-template <int DR, bool WRITE_GX, int OFF>
+// BN (training fusion): xp holds z.  The window keeps the raw z; the activation max(a z + b, 0) is recomputed where the
+// d(shift) sums use it -- zero for window cells outside the plane and for planes outside [0, T) -- and the d(x) values a
+// thread writes into the tile are masked with the ReLU of its own window of plane k - 1 (xa) while bn2's sums
+// sum(dz), sum(dz zhat) are reduced next to the d(shift) partials (rk3d_dma.hpp, dma_backward_loop).
+template <int DR, bool WRITE_GX, int OFF, bool BN = false>
 __device__ __forceinline__ void backward_loop(const float* __restrict__ xp, const float* __restrict__ gp,
                                               float* __restrict__ op, float4* ring, const SDims& d, const SBand& b,
                                               const Frac<float>& fT, const Frac<float>& fH, const Frac<float>& fW,
                                               int flW_eff, size_t tstride_in, size_t tstride_out, float& accT,
-                                              float& accH, float& accW) {
+                                              float& accH, float& accW, float4 bnp = make_float4(0.f, 0.f, 0.f, 0.f),
+                                              float* accB1 = nullptr, float* accB2 = nullptr) {
     const int slot_f4 = b.cells_in + 1;                           // x slots: + zero cell; out tile: + dump cell
     BCells<DR> cs;
     make_feed<DR>(cs, b);
@@ -270,7 +281,22 @@ __device__ __forceinline__ void backward_loop(const float* __restrict__ xp, cons
     float xa[16], xb[16], Qprev[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) xa[i] = xb[i] = Qprev[i] = 0.f;
-    float sT = 0.f, sH = 0.f, sW = 0.f;
+    float sT = 0.f, sH = 0.f, sW = 0.f, sB1 = 0.f, sB2 = 0.f;
+    // BN: which of the window's 3 cells per row lie inside the plane (a cell outside reads the zero cell: its
+    // activation must be 0, not max(b, 0)), and the affine maps of the planes in xa / xb (0: no plane)
+    bool cin_a[3], cin_b[3];
+    {
+        // (rows of the slot outside the plane are zero-FILLED cells, not the zero cell: test the row as well)
+        const int jrow = (w.live ? (int)threadIdx.x : 0) / d.Wo4;
+        const int row_a = b.src0 / d.W4 + 2 * jrow, row_b = row_a + 1;      // plane rows of the window (src0 = r0 * W4)
+        const bool ra = row_a >= 0 && row_a < d.H, rb = row_b >= 0 && row_b < d.H;
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3) {
+            cin_a[k3] = ra && w.a[k3] != b.cells_in;
+            cin_b[k3] = rb && w.b[k3] != b.cells_in;
+        }
+    }
+    float aA = 0.f, bA = 0.f, aB = 0.f, bB = 0.f;
 
 #pragma nounroll
     for (int k = 0; k < steps; ++k) {
@@ -291,9 +317,28 @@ __device__ __forceinline__ void backward_loop(const float* __restrict__ xp, cons
         }
         if (k + 1 < steps) feed(k + 1);                           // (the DMA waits for the LDS reads above)
         mark = issued;
+        if (BN) { aA = aB; bA = bB; aB = in_range(k) ? bnp.x : 0.f; bB = in_range(k) ? bnp.y : 0.f; }
         if (wave_live) {
             const float g[4] = {g4.x, g4.y, g4.z, g4.w};
             float q[16];
+            float za[16];                                         // BN: raw z of plane k - 1 at the window (for zhat)
+            if (BN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { za[e] = xa[e]; za[8 + e] = xa[8 + e]; }
+            }
+            float xav[16], xbv[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = OFF + e;
+                if (BN) {
+                    xav[e] = cin_a[j >> 2] ? fmaxf(fmaf(aA, xa[e], bA), 0.f) : 0.f;
+                    xbv[e] = cin_a[j >> 2] ? fmaxf(fmaf(aB, xb[e], bB), 0.f) : 0.f;
+                    xav[8 + e] = cin_b[j >> 2] ? fmaxf(fmaf(aA, xa[8 + e], bA), 0.f) : 0.f;
+                    xbv[8 + e] = cin_b[j >> 2] ? fmaxf(fmaf(aB, xb[8 + e], bB), 0.f) : 0.f;
+                } else {
+                    xav[e] = xa[e]; xbv[e] = xb[e]; xav[8 + e] = xa[8 + e]; xbv[8 + e] = xb[8 + e];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float wW = (e & 1) ? uW : rW;               // even e: column 2 wo - fl'W - 1 (tap w1), odd: tap w0
@@ -303,13 +348,13 @@ __device__ __forceinline__ void backward_loop(const float* __restrict__ xp, cons
                 const float ca = rH * g[e >> 1], cb = uH * g[e >> 1];   // H-blend of the single tap, per row
                 const float sgn = (e & 1) ? 1.f : -1.f;
                 {
-                    const float dx = xb[e] - xa[e], mx = fmaf(uT, xb[e], rT * xa[e]);
+                    const float dx = xbv[e] - xav[e], mx = fmaf(uT, xbv[e], rT * xav[e]);
                     sT = fmaf(q[e], dx, sT);
                     sH = fmaf(-gw, mx, sH);
                     sW = fmaf(sgn * ca, mx, sW);
                 }
                 {
-                    const float dx = xb[8 + e] - xa[8 + e], mx = fmaf(uT, xb[8 + e], rT * xa[8 + e]);
+                    const float dx = xbv[8 + e] - xav[8 + e], mx = fmaf(uT, xbv[8 + e], rT * xav[8 + e]);
                     sT = fmaf(q[8 + e], dx, sT);
                     sH = fmaf(gw, mx, sH);
                     sW = fmaf(sgn * cb, mx, sW);
@@ -320,8 +365,16 @@ __device__ __forceinline__ void backward_loop(const float* __restrict__ xp, cons
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int j = OFF + e;                        // constant
-                    *reinterpret_cast<float*>(tile + wa[j >> 2] + 4 * (j & 3)) = uT * Qprev[e] + rT * q[e];
-                    *reinterpret_cast<float*>(tile + wb[j >> 2] + 4 * (j & 3)) = uT * Qprev[8 + e] + rT * q[8 + e];
+                    float oa = uT * Qprev[e] + rT * q[e], ob = uT * Qprev[8 + e] + rT * q[8 + e];
+                    if (BN) {                                     // plane k - 1 = the plane in xa: ReLU mask + bn2's sums
+                        oa = xav[e] > 0.f ? oa : 0.f;             // (xav is 0 outside the plane: nothing leaks into the sums)
+                        ob = xav[8 + e] > 0.f ? ob : 0.f;
+                        sB1 += oa + ob;
+                        sB2 = fmaf(oa, (za[e] - bnp.z) * bnp.w, sB2);
+                        sB2 = fmaf(ob, (za[8 + e] - bnp.z) * bnp.w, sB2);
+                    }
+                    *reinterpret_cast<float*>(tile + wa[j >> 2] + 4 * (j & 3)) = oa;
+                    *reinterpret_cast<float*>(tile + wb[j >> 2] + 4 * (j & 3)) = ob;
                 }
             }
 #pragma unroll
@@ -339,22 +392,27 @@ __device__ __forceinline__ void backward_loop(const float* __restrict__ xp, cons
         }
     }
     accT = sT; accH = sH; accW = sW;
+    if (BN) { *accB1 = sB1; *accB2 = sB2; }
 }
 
-template <int DR, bool WRITE_GX, bool FUSED>
+template <int DR, bool WRITE_GX, bool FUSED, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_s2_backward(const float* __restrict__ x, const float* __restrict__ shift,
                                                           const float* __restrict__ gy, float* __restrict__ gx,
-                                                          float* __restrict__ part, SDims d, Dims3 gd, dma3d::Fin3 fin) {
+                                                          float* __restrict__ part, SDims d, Dims3 gd, dma3d::Fin3 fin,
+                                                          dma3d::BnFuse bn = dma3d::BnFuse{}) {
+    constexpr int ND = BN ? 5 : 3;
     if (FUSED && (int)blockIdx.x >= fin.f.producers) {
-        if (threadIdx.x < kWave) dma3d::finalizer_wave<3>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands);
+        if (threadIdx.x < kWave) dma3d::finalizer_wave<ND>(fin, (int)blockIdx.x - fin.f.producers, d.C, d.N * d.nbands, bn);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
-    __shared__ float red[3][kBlock / kWave];
+    __shared__ float red[ND][kBlock / kWave];
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
     const int c = col % d.C, n = col / d.C;
     const float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
-    float accT = 0.f, accH = 0.f, accW = 0.f;
+    float accT = 0.f, accH = 0.f, accW = 0.f, accB1 = 0.f, accB2 = 0.f;
+    float4 bnp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BN) bnp = bn.abmi[c];
     const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r'
 
     if (fT.r == 0 || fH.r == 0 || fW.r == 0) {
@@ -363,8 +421,25 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_backward(const float* __restric
             if (WRITE_GX)
                 for (int t = 0; t < d.T; ++t)
                     backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, threadIdx.x, kBlock);
+            if (BN) {
+                const BnAct act{bnp.x, bnp.y};
+                for (int to = 0; to < d.T; ++to)
+                    shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW, act);
+                const int HW = d.H * d.W;
+                for (int t = 0; t < d.T; ++t) {                     // (each thread re-reads the elements it wrote itself)
+                    const size_t base = (((size_t)n * d.T + t) * d.C + c) * HW;
+                    for (int e = threadIdx.x; e < HW; e += kBlock) {
+                        const float zv = x[base + e];
+                        const float dz = fmaf(bnp.x, zv, bnp.y) > 0.f ? gx[base + e] : 0.f;
+                        gx[base + e] = dz;
+                        accB1 += dz;
+                        accB2 = fmaf(dz, (zv - bnp.z) * bnp.w, accB2);
+                    }
+                }
+            } else {
             for (int to = 0; to < d.T; ++to)
                 shift_grad_plane<float>(x, shift, gy, gd, n, to, c, threadIdx.x, kBlock, accT, accH, accW);
+            }
         }
     } else {
         const size_t tin = (size_t)d.C * d.H * d.W, tout = (size_t)d.C * d.Ho * d.Wo;
@@ -385,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_backward(const float* __restric
             if (band == d.nbands - 1) zero_rows(2 * d.Ho + flH_eff, d.H);
         }
         const SBand b = make_sband(d, band, flH_eff);
-#define RK_S2_BWD(O) backward_loop<DR, WRITE_GX, O>(xp, gp, op, ring, d, b, fT, fH, fW, flW_eff, tin, tout, accT, accH, accW)
+#define RK_S2_BWD(O) backward_loop<DR, WRITE_GX, O, BN>(xp, gp, op, ring, d, b, fT, fH, fW, flW_eff, tin, tout, accT, accH, accW, bnp, &accB1, &accB2)
         switch (((flW_eff % 4) + 4) % 4) {                          // wave-uniform
             case 0: RK_S2_BWD(0); break;
             case 1: RK_S2_BWD(1); break;
@@ -398,13 +473,21 @@ __global__ __launch_bounds__(kBlock) void k3d_s2_backward(const float* __restric
     accT = group_sum(accT, kBlock, red[0]);
     accH = group_sum(accH, kBlock, red[1]);
     accW = group_sum(accW, kBlock, red[2]);
+    if (BN) {
+        accB1 = group_sum(accB1, kBlock, red[ND - 2]);
+        accB2 = group_sum(accB2, kBlock, red[ND - 1]);
+    }
     if (threadIdx.x == 0) {
         const int P = d.N * d.nbands;
-        const size_t at = (size_t)c * 3 * P + (size_t)n * d.nbands + band;
+        const size_t at = (size_t)c * ND * P + (size_t)n * d.nbands + band;
         if (FUSED) {
             fin_publish(fin.f, at, accT);
             fin_publish(fin.f, at + P, accH);
             fin_publish(fin.f, at + 2 * P, accW);
+            if (BN) {
+                fin_publish(fin.f, at + 3 * (size_t)P, accB1);
+                fin_publish(fin.f, at + 4 * (size_t)P, accB2);
+            }
         } else {
             part[at] = accT;
             part[at + P] = accH;
@@ -439,6 +522,37 @@ inline bool launch_forward(const float* x, const float* shift, float* y, const D
     if (lds > 64 * 1024) return false;
     const dim3 grid((unsigned)(s.N * s.C * s.nbands)), block(kBlock);
     hipLaunchKernelGGL((k3d_s2_forward<4, D>), grid, block, lds, stream, x, shift, y, s);
+    return true;
+}
+
+// training fusion (BN): forward of relu(bn(z)) and its backward; false = not handled here
+inline bool launch_forward_bn(const float* z, const float* shift, float* y, const float4* abmi, const Dims3& d,
+                              hipStream_t stream) {
+    constexpr int D = 2;
+    SDims s;
+    if (!make_sdims(s, d) || !aligned16(z) || !aligned16(y) || !aligned16(abmi)) return false;
+    const size_t lds = ring_bytes(s, D + 1);
+    if (lds > 64 * 1024) return false;
+    const dim3 grid((unsigned)(s.N * s.C * s.nbands)), block(kBlock);
+    hipLaunchKernelGGL((k3d_s2_forward<4, D, true>), grid, block, lds, stream, z, shift, y, s, abmi);
+    return true;
+}
+inline size_t bwd_lds_bytes(const SDims& s);
+inline bool launch_backward_bn(const float* z, const float* shift, const float* gy, float* gx, float* gshift, float* ws,
+                               const Dims3& d, int normalize, float t_factor, const dma3d::BnFuse& bn, hipStream_t stream) {
+    SDims s;
+    if (!make_sdims(s, d) || !aligned16(z) || !aligned16(gy) || !aligned16(gx) || !aligned16(bn.abmi)) return false;
+    const size_t lds = bwd_lds_bytes(s);
+    if (lds > 64 * 1024) return false;
+    dma3d::Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = s.N * s.C * s.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+    hipLaunchKernelGGL((k3d_s2_backward<4, true, true, true>), dim3((unsigned)(fin.f.producers + s.C)), dim3(kBlock), lds, stream,
+                       z, shift, gy, gx, ws, s, d, fin, bn);
     return true;
 }
 
