@@ -428,8 +428,9 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
 // (LDS image = memory image: [frame][k][P]), and the B fragments are single-word LDS reads at lane-consecutive addresses;
 // the 128-bit trick of k_pw_gemm (a lane owns 4 consecutive columns) is not needed because nothing streams past the CU
 // fast enough to matter: these tensors are 1/4 .. 1/64 of the others and the layers are MFMA-bound (432 -> 432).
-//   wave tile 64 rows x 64 columns (2 x 2 MFMA blocks, 64 accumulators), workgroup = 4 waves along the columns = 256
-//   columns, so that [256 frames, 432 channels, 7x7] gives 49 x 7 = 343 workgroups.
+//   wave tile 64 rows x 32 NCB columns (2 x NCB MFMA blocks), workgroup = 4 waves along the columns.  NCB = 2 (256
+//   columns) gives [256 frames, 432 channels, 7x7] only 49 x 7 = 343 workgroups for 256 CUs -- a second, third-full round:
+//   87 us; NCB = 1 (128 columns, 686 workgroups of half the LDS) balances better and is what the launcher uses.
 //   GATHER = 1: the streamed operand is read at stride 2 from [F, K, 2 Ho, 2 Wo] planes (the 14 -> 7 projecting shortcut,
 //   backbone.py:98-104): the frame chunk is gathered element by element into the same LDS image.
 //   SCATTER = 1: d(input) of that shortcut: the result of output pixel (ho, wo) goes to (2 ho, 2 wo) of a [2 Ho, 2 Wo]
@@ -437,31 +438,33 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
 constexpr int kOddKC = 16;               // channels per chunk
 constexpr int kOddFr = 8;                // frames a 256-column tile can touch (P >= 37: 256 / P + 2 <= 8)
 
-template <int GATHER, int SCATTER>
+template <int GATHER, int SCATTER, int NCB>
 __global__ __launch_bounds__(kBlock) void k_pw_gemm_odd(const float* __restrict__ A, const float* __restrict__ X,
                                                         const float* __restrict__ R, float* __restrict__ Y, PwDims d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = d.P;
     const int fchunk = kOddKC * P;                          // floats of one frame chunk
     float* As = smem;                                       // [2][kOddKC * 64]
-    float* Xs = smem + 2 * kOddKC * 64;                     // [2][kOddFr * fchunk]
-    const int xbuf = kOddFr * fchunk;
+    constexpr int kFr = NCB == 2 ? kOddFr : 6;             // frames a tile of 128 NCB columns can touch (P >= 37)
+    constexpr int kCols = 128 * NCB;                        // columns per workgroup: 4 waves x NCB blocks of 32
+    float* Xs = smem + 2 * kOddKC * 64;                     // [2][kFr * fchunk]
+    const int xbuf = kFr * fchunk;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l31 = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.y * 64;
-    const long long n0 = (long long)blockIdx.x * 256;       // first column of the workgroup
+    const long long n0 = (long long)blockIdx.x * kCols;     // first column of the workgroup
     const int f0 = (int)(n0 / P);                           // first frame it touches
-    long long nlast = n0 + 255;
+    long long nlast = n0 + kCols - 1;
     nlast = nlast < d.ntot - 1 ? nlast : d.ntot - 1;
     const int nfr = (int)(nlast / P) - f0 + 1;              // frames touched (<= kOddFr)
 
     // this lane's two columns (one per 32-column block of the wave's 64) and their LDS word offsets inside a buffer
-    long long col[2];
-    int xoff[2], cf[2], cp[2];
-    bool con[2];
+    long long col[NCB];
+    int xoff[NCB], cf[NCB], cp[NCB];
+    bool con[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        col[cb] = n0 + wave * 64 + cb * 32 + l31;
+    for (int cb = 0; cb < NCB; ++cb) {
+        col[cb] = n0 + wave * (32 * NCB) + cb * 32 + l31;
         con[cb] = col[cb] < d.ntot;
         const long long cc = con[cb] ? col[cb] : n0;
         cf[cb] = (int)(cc / P);
@@ -469,18 +472,18 @@ __global__ __launch_bounds__(kBlock) void k_pw_gemm_odd(const float* __restrict_
         xoff[cb] = (cf[cb] - f0) * fchunk + cp[cb];
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NCB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NCB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // Staging is split into fetch (global -> registers, issued BEFORE the MFMAs of the current chunk) and deposit
     // (registers -> LDS, after them), so that the load latency hides under the 32 MFMAs of a chunk; a load -> LDS store
     // -> MFMA sequence per chunk left it exposed 27 times per tile (152 us against MIOpen's 47 us at [256,432->432,7x7]).
-    constexpr int kXV = (kOddFr * kOddKC * 64 / 4 + kBlock - 1) / kBlock;        // float4 per thread, P <= 64: 8
+    constexpr int kXV = (kFr * kOddKC * 64 / 4 + kBlock - 1) / kBlock;           // float4 per thread, P <= 64: 8 / 6
     constexpr int kAV = kOddKC * 64 / kBlock;                                    // 4 floats per thread
     const int nv = fchunk / 4;                               // (kOddKC * P) % 4 == 0
     // Everything about a thread's pieces that does not depend on the chunk is computed once: float4 e = tid + 256 i of
@@ -587,19 +590,21 @@ __global__ __launch_bounds__(kBlock) void k_pw_gemm_odd(const float* __restrict_
         // all 32 fragment words of the chunk are requested before the first MFMA (one LDS round trip per chunk instead of
         // two per k-step: with a read -> wait -> MFMA sequence per step the loop ran at half the MFMA rate); rows past M
         // are zero columns of A, so the second 32-row block needs no test
-        float fa0[kOddKC / 2], fa1[kOddKC / 2], fb0[kOddKC / 2], fb1[kOddKC / 2];
+        float fa0[kOddKC / 2], fa1[kOddKC / 2], fb[NCB][kOddKC / 2];
 #pragma unroll
         for (int s = 0; s < kOddKC / 2; ++s) {
             const int kk = 2 * s + kh;
             fa0[s] = as[kk * 64]; fa1[s] = as[kk * 64 + 32];
-            fb0[s] = xs[xoff[0] + kk * P]; fb1[s] = xs[xoff[1] + kk * P];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) fb[cb][s] = xs[xoff[cb] + kk * P];
         }
 #pragma unroll
         for (int s = 0; s < kOddKC / 2; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb0[s], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb1[s], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb0[s], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb1[s], acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb[cb][s], acc[0][cb], 0, 0, 0);
+                acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb[cb][s], acc[1][cb], 0, 0, 0);
+            }
         }
         if (more) {
             deposit_a(As + ((c + 1) & 1) * kOddKC * 64);
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void k_pw_gemm_odd(const float* __restrict_
     }
 
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         if (!con[cb]) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1700,23 +1705,13 @@ static int pw_gemm_odd(const float* A, const float* X, const float* R, float* Y,
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
     d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0; d.WM = 1; d.WN = 4;
-    const size_t lds = (size_t)(2 * kOddKC * 64 + 2 * kOddFr * kOddKC * P) * sizeof(float);
-    if (lds > 160 * 1024) return RK_ERR_BAD_DIMS;
-    const dim3 grid((unsigned)((d.ntot + 255) / 256), (unsigned)((M + 63) / 64)), block(kBlock);
+    constexpr int NCB = 1, kFr = 6;                          // 128 columns per workgroup (k_pw_gemm_odd)
+    const size_t lds = (size_t)(2 * kOddKC * 64 + 2 * kFr * kOddKC * P) * sizeof(float);      // <= 57 KB at P = 64
+    const dim3 grid((unsigned)((d.ntot + 128 * NCB - 1) / (128 * NCB)), (unsigned)((M + 63) / 64)), block(kBlock);
     hipStream_t stream = (hipStream_t)stream_;
-    if (mode == 0) {
-        static bool once = ((void)hipFuncSetAttribute((const void*)k_pw_gemm_odd<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((k_pw_gemm_odd<0, 0>), grid, block, lds, stream, A, X, R, Y, d);
-    } else if (mode == 1) {
-        static bool once = ((void)hipFuncSetAttribute((const void*)k_pw_gemm_odd<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((k_pw_gemm_odd<1, 0>), grid, block, lds, stream, A, X, R, Y, d);
-    } else {
-        static bool once = ((void)hipFuncSetAttribute((const void*)k_pw_gemm_odd<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((k_pw_gemm_odd<0, 1>), grid, block, lds, stream, A, X, R, Y, d);
-    }
+    if (mode == 0) hipLaunchKernelGGL((k_pw_gemm_odd<0, 0, NCB>), grid, block, lds, stream, A, X, R, Y, d);
+    else if (mode == 1) hipLaunchKernelGGL((k_pw_gemm_odd<1, 0, NCB>), grid, block, lds, stream, A, X, R, Y, d);
+    else hipLaunchKernelGGL((k_pw_gemm_odd<0, 1, NCB>), grid, block, lds, stream, A, X, R, Y, d);
     return launch_status();
 }
 // Y[f] = A X[f] (+ R[f]) for planes of P = H * W pixels with P % 4 != 0 (37 <= P <= 200; the 7x7 planes of layer4):
