@@ -189,7 +189,7 @@ def test_bn_relu_on_cpu_is_the_stock_pair():
 
 
 def test_switches_are_read_once_into_a_frozen_object(monkeypatch):
-    """rubiksnet_amd.config: four switches, read at import / on reload(), nothing else consulted per call."""
+    """rubiksnet_amd.config: five switches, read at import / on reload(), nothing else consulted per call."""
     import dataclasses
 
     from rubiksnet_amd import config, fused_bn, pointwise
@@ -243,3 +243,48 @@ def test_optim_policy_groups_follow_the_reference_rules():
     net.extra = Leaf()
     with pytest.raises(ValueError, match="New atomic module type"):
         net.get_optim_policy()
+
+
+def test_model_roofline_bound_is_consistent():
+    """rubiksnet_amd/roofline.py: the bound the bench's model legs are reported against (pure host arithmetic)."""
+    from rubiksnet_amd.roofline import HBM_PEAK, MFMA_PEAK, model_bound
+
+    tiny = RubiksNet("tiny", 174, verbose=False)
+    tr = model_bound(tiny, 32, train=True)
+    fw = model_bound(tiny, 32, train=False)
+    assert set(tr) >= {"algorithmic_bytes", "mfma_flops", "bound_ms", "hbm_only_ms", "mfma_only_ms", "formula"}
+    assert tr["bound_ms"] >= max(tr["hbm_only_ms"], tr["mfma_only_ms"]) - 1e-9          # sum of per-operator maxima
+    assert tr["bound_ms"] <= tr["hbm_only_ms"] + tr["mfma_only_ms"] + 1e-9
+    assert abs(tr["hbm_only_ms"] - 1e3 * tr["algorithmic_bytes"] / HBM_PEAK) < 1e-9
+    assert abs(tr["mfma_only_ms"] - 1e3 * tr["mfma_flops"] / MFMA_PEAK["f32"]) < 1e-9
+    assert 2.9 < tr["mfma_flops"] / fw["mfma_flops"] < 3.0        # forward + d(input) + d(weight); the stem has no d(input)
+    assert tr["algorithmic_bytes"] > 2 * fw["algorithmic_bytes"]
+    assert abs(model_bound(tiny, 64, train=True)["bound_ms"] - 2 * tr["bound_ms"]) < 1e-6       # linear in the batch
+    # shift traffic alone, per clip, forward: SURVEY 8(d) quotes 148.3 MB for Tiny
+    from rubiksnet_amd.roofline import _shift
+    total, h = 0, 112
+    for stage in (tiny.backbone.layer0, tiny.backbone.layer1, tiny.backbone.layer2, tiny.backbone.layer3, tiny.backbone.layer4):
+        for blk in stage:
+            stride = int(blk.shortcut.stride[0]) if hasattr(blk.shortcut, "weight") else 1
+            ho = (h - 1) // stride + 1
+            total += _shift(blk.conv2.out_channels, h * h, ho * ho, 8, 4, False)[0]
+            h = ho
+    assert abs(total / 1e6 - 148.3) < 0.1
+    aq = model_bound(RubiksNet("large", 174, variant="rubiks3d-aq", verbose=False), 32, True, "bf16", 2)
+    assert aq["bound_ms"] == pytest.approx(aq["hbm_only_ms"])     # bf16 MFMA peak: every layer HBM-bound
+
+
+def test_fused_train_block_declines_what_it_cannot_run():
+    """train_block.fused_train_block returns None -- the layer-by-layer path follows -- for CPU tensors, eval mode and the
+    -aq variant; no oracle, no CPU arithmetic of its own."""
+    from rubiksnet_amd import train_block
+
+    net = RubiksNet("tiny", 5, verbose=False).train()
+    blk = net.backbone.layer1[1]
+    x = torch.randn(8, 54, 8, 8, requires_grad=True)
+    assert train_block.fused_train_block(blk, x) is None                      # CPU tensor
+    assert train_block.bn_relu_from_stats(net.backbone.bn_last, torch.randn(8, 432, 7, 7)) is None
+    aq = RubiksNet("tiny", 5, variant="rubiks3d-aq", verbose=False).train()
+    assert train_block._shift_config(aq.backbone.layer1[1].as3) is None       # 2-D shift + AttentionShift: not this path
+    assert train_block._shift_config(blk.as3) is not None
+    assert train_block.take_stats(x, 54, x.numel() // 54) is None             # no producer attached statistics
