@@ -620,7 +620,7 @@ def main():
             "clips_per_s": env.world_size * SHAPE[0] / t_step,
             "frac_of_hbm_peak": value / env.world_size / HBM_PEAK_GBS,   # per GPU, from the wall-clock value
             "roofline": {
-                "kernel": "rk::dma3d::k3d_dma_backward<2,true,1,1,true,false> (two 28-row bands per plane): d(x) + d(shift) + row-sum + K5 in ONE launch "
+                "kernel": "rk::dma3d::k3d_dma_backward<2,true,1,1,true,false,false> (two 28-row bands per plane): d(x) + d(shift) + row-sum + K5 in ONE launch "
                           "(= the rk3d_backward_f32 call; the dominant kernel)",
                 "bound": "hbm",
                 "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
