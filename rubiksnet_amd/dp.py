@@ -85,6 +85,14 @@ def make_optimizer(model, lr=0.01, lr_shift_mult=0.01, kind="adam", momentum=0.9
         (shift_params if name.endswith("shift") else regular).append(p)
     groups = [{"params": shift_params, "lr": lr * lr_shift_mult}, {"params": regular}]
     if kind == "adam":
+        # one fused multi-tensor launch per parameter group instead of ~20 foreach kernels per step (RubiksNet-Large: 43
+        # multi_tensor_apply launches, 0.6 ms); same update rule.  CPU parameters (the gloo tests) keep the default.
+        on_gpu = all(p.is_cuda and p.is_floating_point() for g in groups for p in g["params"])
+        if on_gpu and (shift_params or regular):
+            try:
+                return torch.optim.Adam(groups, lr=lr, weight_decay=weight_decay, fused=True)
+            except (RuntimeError, TypeError):
+                pass
         return torch.optim.Adam(groups, lr=lr, weight_decay=weight_decay)
     return torch.optim.SGD(groups, lr=lr, momentum=momentum, weight_decay=weight_decay)
 

@@ -24,6 +24,9 @@ CASES = [   # frames, Cin, Cout, H, W
     (2, 50, 22, 6, 6),         # K = 50: padded last chunk
     (3, 72, 144, 8, 8),        # Large's widths: the last 32-row block of a 64-row tile is all padding (skipped)
     (2, 144, 72, 8, 8),
+    (3, 288, 288, 12, 12),     # channel counts that are multiples of 96: the 96 x 96-per-wave d(weight) kernel, ragged chunk
+    (2, 288, 96, 8, 8),
+    (1, 576, 192, 4, 8),       # two 288-row groups of X
 ]
 
 
