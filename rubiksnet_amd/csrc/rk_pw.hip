@@ -1356,8 +1356,10 @@ inline int make_wg(WgDims& d, int F, int K, int M, int P, bool odd = false) {
     d.MB = (M + 63) / 64; d.KB = (K + 63) / 64;
     // ~1536 wave tasks (6 per CU), but keep the partials (S * M * K floats, written and read once) under a
     // quarter of the operands' bytes
-    constexpr int want_tasks = 1536;
     const int nmk = d.MB * d.KB;
+    // wave tasks: all 2 048 wave slots for layers of up to 4 (mb, kb) blocks (54 -> 54 at 56x56: 93 -> 80 us); with many
+    // blocks per chunk (288 -> 288: 25) more chunks only add partials (142 -> 155 us)
+    const int want_tasks = nmk <= 4 ? 2048 : 1536;
     long long S = want_tasks / (nmk < 4 ? 4 : nmk);                   // one partial per workgroup-chunk
     const long long cap = ((long long)(M + K) * d.ntot) / (4LL * M * K);
     if (S > cap) S = cap;
