@@ -5,6 +5,8 @@
     RK_FUSED_EVAL  1 | 0          inference blocks with BN + residual folded into the two GEMMs / layer by layer
     RK_FUSED_TRAIN 1 | 0          training blocks as one autograd node with the BatchNorm statistics / normalisation / backward
                                   reduction folded into the 1x1 GEMMs (train_block.py) / layer by layer
+    RK_WGRAD_OVERLAP 1 | 0        the d(weight) kernels of a fused training block on a second HIP stream, next to the
+                                  streaming kernels of the same backward / on the current stream
     RK_F1          0 | 1          inference blocks: shift kernel, then the conv3 GEMM / the 3-D shift inside conv3's operand
                                   load (gather form: bit-identical, never stores the shifted activation,
                                   but 1.7x slower than the two kernels -- DESIGN 7 -- hence off)
@@ -26,6 +28,7 @@ class Switches:
     fused_eval: bool = True
     fused_shift_gemm: bool = False
     fused_train: bool = True
+    wgrad_overlap: bool = True
 
     @staticmethod
     def from_env(env=None):
@@ -36,7 +39,8 @@ class Switches:
         return Switches(fused_bn=env.get("RK_FUSED_BN", "1") != "0", pointwise=pw,
                         fused_eval=env.get("RK_FUSED_EVAL", "1") != "0",
                         fused_shift_gemm=env.get("RK_F1", "0") == "1",
-                        fused_train=env.get("RK_FUSED_TRAIN", "1") != "0")
+                        fused_train=env.get("RK_FUSED_TRAIN", "1") != "0",
+                        wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0")
 
 
 _current = Switches.from_env()

@@ -33,6 +33,22 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+_SIDE = {}        # device index -> the HIP stream the d(weight) kernels of a backward run on
+
+
+def _side_stream(dev):
+    """d(weight) has no consumer inside the block's backward, is MFMA / latency bound (its waves sit in s_waitcnt 60 % of
+    the time, PMC) and runs next to pure streaming kernels (BatchNorm d(x), the shift backward): launched on a second
+    stream it fills their gaps.  The backward joins the streams before it returns, so autograd sees finished gradients."""
+    if not config.switches().wgrad_overlap:
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(dev)
+    return st
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -198,10 +214,22 @@ class _FusedTrainBlock(torch.autograd.Function):
         need = ctx.needs_input_grad
         with torch.cuda.device(dev):
             st = _stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            keep = []                                       # buffers the side stream uses: alive until the streams have joined
 
             def wgrad_ws(K, M, Pn):
                 nbytes = int(L.rk_pw_wgrad_workspace_bytes(Fr, K, M, Pn))
-                return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev), nbytes
+                buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                keep.append(buf)
+                return buf, nbytes
+
+            def wg_stream():
+                """Stream handle for a d(weight) launch: the side stream (after everything queued so far), or the current one."""
+                if side is None:
+                    return st
+                side.wait_stream(cur)
+                return side.cuda_stream
 
             # conv3: d(s) = W3^T dout, d(W3) = dout s^T
             ds = torch.empty_like(s)
@@ -212,7 +240,7 @@ class _FusedTrainBlock(torch.autograd.Function):
                 dw3 = torch.empty_like(w3)
                 ws, nb = wgrad_ws(Cmid, Cout, Po)
                 _native.check(L.rk_pw_wgrad_f32(dout.data_ptr(), s.data_ptr(), dw3.data_ptr(), Fr, Cmid, Cout, Po,
-                                                ws.data_ptr(), nb, st), "rk_pw_wgrad_f32")
+                                                ws.data_ptr(), nb, wg_stream()), "rk_pw_wgrad_f32")
             # the shift and bn2: d(shift), and d(z) = bn2 + ReLU backward of d(a2).  Fused: the shift backward reads z,
             # masks its d(x) with the ReLU and reduces bn2's sums in the same launch (dg2, db2, k12); one d(x) pass finishes.
             N = Fr // plan.T
@@ -267,18 +295,18 @@ class _FusedTrainBlock(torch.autograd.Function):
                     if plan.stride == 2:
                         _native.check(L.rk_pw_s2_wgrad_pro_f32(dout.data_ptr(), x.data_ptr(), dwsc.data_ptr(), Fr, Cin, Cout,
                                                                H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(),
-                                                               nb, st), "rk_pw_s2_wgrad_pro_f32")
+                                                               nb, wg_stream()), "rk_pw_s2_wgrad_pro_f32")
                     else:
                         _native.check(L.rk_pw_wgrad_pro_f32(dout.data_ptr(), x.data_ptr(), dwsc.data_ptr(), Fr, Cin, Cout, P,
-                                                            bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb, st),
-                                      "rk_pw_wgrad_pro_f32")
+                                                            bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb,
+                                                            wg_stream()), "rk_pw_wgrad_pro_f32")
             # conv2: d(W2) from (dz, relu(bn1(x)) recomputed); d(input) masked by the ReLU, + bn1's reduction sums
             dw2 = None
             if need[4]:
                 dw2 = torch.empty_like(w2)
                 ws, nb = wgrad_ws(Cin, Cmid, P)
                 _native.check(L.rk_pw_wgrad_pro_f32(dz.data_ptr(), x.data_ptr(), dw2.data_ptr(), Fr, Cin, Cmid, P,
-                                                    bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb, st),
+                                                    bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb, wg_stream()),
                               "rk_pw_wgrad_pro_f32")
             J = int(L.rk_pw_tiles(Fr, P))
             bred = torch.empty(Cin, J, 2, dtype=torch.float32, device=dev)
@@ -298,6 +326,9 @@ class _FusedTrainBlock(torch.autograd.Function):
                 _native.check(L.rk_bn_bwd_dx_pre_f32(dzm.data_ptr(), x.data_ptr(), g1.data_ptr(), bn1[0].data_ptr(),
                                                      bn1[1].data_ptr(), k12.data_ptr(), _ptr(skip), dx.data_ptr(), Fr, Cin,
                                                      P, st), "rk_bn_bwd_dx_pre_f32")
+            if side is not None:
+                cur.wait_stream(side)                       # gradients complete before autograd touches them
+            del keep
         return (dx, None, dg1, db1, dw2, dg2, db2, dshift, dw3, dwsc if not plan.identity else None, None)
 
 
