@@ -189,7 +189,7 @@ def test_bn_relu_on_cpu_is_the_stock_pair():
 
 
 def test_switches_are_read_once_into_a_frozen_object(monkeypatch):
-    """rubiksnet_amd.config: five switches, read at import / on reload(), nothing else consulted per call."""
+    """rubiksnet_amd.config: six switches, read at import / on reload(), nothing else consulted per call."""
     import dataclasses
 
     from rubiksnet_amd import config, fused_bn, pointwise
