@@ -151,19 +151,28 @@ class _FusedTrainBlock(torch.autograd.Function):
             if stats_in is None:
                 stats_in = _tile_stats(L, x, Fr, Cin, P)
             bn1 = _finish(L, blk.bn1, stats_in, Fr * P, dev)                       # mean, invstd, a, b
-            # shortcut branch: x itself, or the projection of relu(bn1(x)) (prologue in the operand load)
+            # shortcut branch: x itself, or the projection of relu(bn1(x)) (prologue in the operand load).  The projection
+            # has no consumer before conv3's epilogue: it runs on the second stream next to conv2 and the shift.
+            side = None
             if plan.identity:
                 short = x
-            elif plan.stride == 2:
-                short = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
-                _native.check(L.rk_pw_s2_forward_fused_f32(wsc.data_ptr(), x.data_ptr(), short.data_ptr(), Fr, Cin, Cout,
-                                                           H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, st),
-                              "rk_pw_s2_forward_fused_f32")
             else:
-                short = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=dev)
-                _native.check(L.rk_pw_gemm_fused_f32(wsc.data_ptr(), x.data_ptr(), None, short.data_ptr(), Fr, Cin, Cout,
-                                                     P, 1, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, None, None, 0, st),
-                              "rk_pw_gemm_fused_f32")
+                side = _side_stream(dev)
+                cur = torch.cuda.current_stream(dev)
+                sst = st
+                if side is not None:
+                    side.wait_stream(cur)
+                    sst = side.cuda_stream
+                if plan.stride == 2:
+                    short = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
+                    _native.check(L.rk_pw_s2_forward_fused_f32(wsc.data_ptr(), x.data_ptr(), short.data_ptr(), Fr, Cin, Cout,
+                                                               H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, sst),
+                                  "rk_pw_s2_forward_fused_f32")
+                else:
+                    short = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=dev)
+                    _native.check(L.rk_pw_gemm_fused_f32(wsc.data_ptr(), x.data_ptr(), None, short.data_ptr(), Fr, Cin, Cout,
+                                                         P, 1, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, None, None, 0, sst),
+                                  "rk_pw_gemm_fused_f32")
             # conv2 on relu(bn1(x)), + the statistics of its output for bn2
             z = torch.empty(Fr, Cmid, H, W, dtype=x.dtype, device=dev)
             J = int(L.rk_pw_tiles(Fr, P))
@@ -188,6 +197,8 @@ class _FusedTrainBlock(torch.autograd.Function):
                 rubiksnet_cuda.rubiks_shift_3d_forward_float(a2.view(N, plan.T, Cmid, H, W), shift_c, s3, pd,
                                                              bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
             # conv3 + shortcut, + the statistics of the block's output for whoever normalises it next
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)      # the projection is complete
             out = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
             Jo = int(L.rk_pw_tiles(Fr, Po))
             stats_out = torch.empty(Cout, Jo, 4, dtype=torch.float32, device=dev)
