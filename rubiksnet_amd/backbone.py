@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import _native, config
 from .fused_bn import bn_relu, bn_relu_skip
-from .pointwise import conv1x1, fused_eval_block, stem_conv
+from .pointwise import all_frozen, conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 from .train_block import bn_relu_from_stats, fused_train_block
 
@@ -212,8 +212,13 @@ class RubiksNetBackbone(nn.Module):
 
     def forward(self, x):
         x = stem_conv(self.conv1, x)
-        for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
-            x = stage(x)
+        if self.training or not torch.is_grad_enabled():
+            for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
+                x = stage(x)
+        else:
+            with all_frozen(self):          # eval with grad mode on: one parameter walk per forward, not one per block
+                for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
+                    x = stage(x)
         y = bn_relu_from_stats(self.bn_last, x) if self.training else None     # statistics from the last conv3's epilogue
         x = y if y is not None else bn_relu(self.bn_last, x)
         x = self.avgpool(x)

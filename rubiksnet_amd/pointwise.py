@@ -11,6 +11,8 @@ memory-bound 112x112 / 56x56 stages; elsewhere they stay on aten (MIOpen).  Othe
 shortcuts, CPU tensors: `conv(x)`.  `RK_PW=0` disables the HIP path, `RK_PW=all` forces the HIP GEMM wherever
 the kernel's constraints allow (config.py).  Forward, d(input) and d(weight) are HIP MFMA kernels.
 """
+import threading
+
 import torch
 
 from . import _native, config
@@ -20,7 +22,7 @@ _FUSED_EVAL_CMAX = 320      # inference fusion: channel limit of rk_pw_gemm_fuse
 _FUSED_EVAL_PMIN = 196      # ... and smallest plane it pays for
 _F1_WMIN = 28               # shift-in-GEMM (f1): smallest plane width it is used for
 
-__all__ = ["conv1x1", "stem_conv", "pointwise_mode", "fused_eval_block"]
+__all__ = ["conv1x1", "stem_conv", "pointwise_mode", "fused_eval_block", "all_frozen"]
 
 
 def pointwise_mode():
@@ -397,10 +399,18 @@ def _strided_shortcut_ok(conv, x):
             and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0)
 
 
+def _shift_layers(as3):
+    """The shift modules inside a block's `as3` (RubiksShift2D, or the 3-D layer behind the temporal wrapper) -- by type,
+    not by "anything with a `stride` attribute"."""
+    from .shiftlib import RubiksShift2D, RubiksShiftBase
+
+    return [m for m in as3.modules() if isinstance(m, (RubiksShift2D, RubiksShiftBase))]
+
+
 def _as3_stride_2(as3):
     """True when the only subsampling inside `as3` is one shift with spatial stride (2, 2) and temporal stride 1."""
     strides = []
-    for m in as3.modules():
+    for m in _shift_layers(as3):
         st = getattr(m, "stride", None)
         if st is None:
             continue
@@ -426,7 +436,7 @@ def _gemm_s2_fused(conv, x, pro):
 
 def _stride_one(as3):
     """True when no shift inside `as3` (RubiksShift2D, the 3-D wrapper, the attention + 2-D pair) subsamples."""
-    for m in as3.modules():
+    for m in _shift_layers(as3):
         st = getattr(m, "stride", None)
         if st is None:
             continue
@@ -434,6 +444,33 @@ def _stride_one(as3):
         if any(int(v) != 1 for v in st):
             return False
     return True
+
+
+# "Does anything in this block want a gradient?" -- asked once per MODEL forward (RubiksNetBackbone.forward brackets its
+# stage loop with `all_frozen(...)`), not once per block per forward by walking block.parameters() (advisor finding: host
+# overhead on the launch-bound inference path).  Outside such a bracket the block's own parameters are walked.
+_ALL_FROZEN = threading.local()
+
+
+class all_frozen:
+    def __init__(self, module):
+        self.value = not any(p.requires_grad for p in module.parameters())
+
+    def __enter__(self):
+        self.prev = getattr(_ALL_FROZEN, "value", None)
+        _ALL_FROZEN.value = self.value
+        return self
+
+    def __exit__(self, *exc):
+        _ALL_FROZEN.value = self.prev
+        return False
+
+
+def _frozen(block):
+    hint = getattr(_ALL_FROZEN, "value", None)
+    if hint:
+        return True                                   # the whole backbone is frozen
+    return not any(p.requires_grad for p in block.parameters())
 
 
 def fused_eval_block(block, x):
@@ -447,7 +484,7 @@ def fused_eval_block(block, x):
             or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4)
             or block.se is not None or x.numel() == 0):
         return None
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in block.parameters())):
+    if torch.is_grad_enabled() and (x.requires_grad or not _frozen(block)):
         return None
     P = x.shape[2] * x.shape[3]
     identity = isinstance(block.shortcut, torch.nn.Identity)
