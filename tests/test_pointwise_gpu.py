@@ -283,6 +283,30 @@ def test_f1_shift_inside_the_gemm_is_bit_identical(shape, kind):
         assert torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("shape", [(16, 54, 54, 56, 56), (8, 10, 70, 12, 28)])
+def test_f1_against_the_oracle_shift_and_an_fp64_convolution(oracle, shape):
+    """The same fused kernel against the REFERENCE arithmetic (round-2 review: the test above compares it with two other
+    HIP kernels): the oracle's RubiksShift3D forward (K1) in fp32, then F.conv2d + residual in fp64 on the CPU."""
+    from _util import special_shifts
+    from rubiksnet_amd import _native
+
+    NT, K, M, H, W = shape
+    T = 8
+    L = _native.lib()
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(NT, K, H, W, generator=g)
+    r = torch.randn(NT, M, H, W, generator=g)
+    wt = torch.randn(M, K, generator=g) * 0.1
+    sh = special_shifts(np.random.default_rng(sum(shape)), 3, K, np.float32, "wide")
+    xs = oracle.rk3d_forward(x.view(NT // T, T, K, H, W).numpy(), sh, 1, 0).reshape(NT, K, H, W)
+    ref = F.conv2d(torch.from_numpy(xs).double(), wt.double().view(M, K, 1, 1)) + r.double()
+    y = torch.empty(NT, M, H, W, device="cuda")
+    xd, rd, wd, sd = x.cuda(), r.cuda(), wt.cuda(), torch.from_numpy(sh).cuda()
+    _native.check(L.rk_pw_gemm_shift3d_f32(wd.data_ptr(), xd.data_ptr(), sd.data_ptr(), rd.data_ptr(), y.data_ptr(), NT, T, K, M,
+                                           H, W, torch.cuda.current_stream().cuda_stream), "f1")
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6 * K ** 0.5 * float(ref.abs().max()))
+
+
 def test_f1_switch_gives_the_same_logits(monkeypatch):
     """RK_F1=1 routes the inference blocks' conv3 through the fused kernel: same logits, bit for bit."""
     from rubiksnet_amd import RubiksNet
