@@ -255,6 +255,16 @@ int rk_pw_gemm_f32(const float* A, const float* X, const float* R, float* Y, int
                    int a_is_mk, rk_stream_t stream);
 int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F, int K, int M, int P,
                     int a_is_mk, rk_stream_t stream);
+/*   bf16 activations, second generation (rk_pw16.hip): the weight is packed ONCE per version into bf16 MFMA-fragment
+ *   order and the GEMM streams X by LDS-DMA, every row of a 128-pixel tile in one workgroup (X crosses HBM once).
+ *   rk_pw_packed_bytes(rows, depth): bytes of a packed operand;
+ *   rk_pw_pack_bf16: W [Cout][Cin] fp32 -> `fwd` (rows Cout, depth Cin: forward) and / or `bwd` (rows Cin, depth
+ *                   Cout: W^T for d(input)); either may be NULL;
+ *   rk_pw_gemm_packed_bf16: Y[f] = A X[f] (+ R[f]) with A packed (M rows, depth K); R may be NULL or Y itself. */
+size_t rk_pw_packed_bytes(int rows, int depth);
+int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_stream_t stream);
+int rk_pw_gemm_packed_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P,
+                           rk_stream_t stream);
 /*   rk_pw_gemm_fused_f32: inference form, Y[f] = epi(A pro(X[f])) (+ R[f]) with
  *                   pro: x' = relu?(ka[k] x + kb[k]) per input channel  (relu(bn1(x)) feeding conv2, backbone.py:129-131)
  *                   epi: y  = relu?(ma[m] y + mb[m]) per output channel (relu(bn2(conv2(.))), BatchNorm in eval mode:
