@@ -265,6 +265,12 @@ size_t rk_pw_packed_bytes(int rows, int depth);
 int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_stream_t stream);
 int rk_pw_gemm_packed_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P,
                            rk_stream_t stream);
+/*   rk_pw_wgrad16_bf16: d(weight)[M][K] (fp32) = sum_f dY[f] X[f]^T for bf16 dY [F,M,P], X [F,K,P] (P % 4 == 0, P >= 8):
+ *                   both operands DMA'd fragment-wise, output tiles of up to 160 x 160 per workgroup; ws of
+ *                   rk_pw_wgrad16_workspace_bytes() bytes (per-split partial matrices, summed in a fixed order). */
+size_t rk_pw_wgrad16_workspace_bytes(int F, int K, int M, int P);
+int rk_pw_wgrad16_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
+                       rk_stream_t stream);
 /*   rk_pw_gemm_fused_f32: inference form, Y[f] = epi(A pro(X[f])) (+ R[f]) with
  *                   pro: x' = relu?(ka[k] x + kb[k]) per input channel  (relu(bn1(x)) feeding conv2, backbone.py:129-131)
  *                   epi: y  = relu?(ma[m] y + mb[m]) per output channel (relu(bn2(conv2(.))), BatchNorm in eval mode:

@@ -44,6 +44,8 @@ SIGNATURES = {
     "rk_pw_packed_bytes": (_sz, [_i, _i]),
     "rk_pw_pack_bf16": (_i, [_p, _i, _i, _p, _p, _p]),
     "rk_pw_gemm_packed_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_pw_wgrad16_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_pw_wgrad16_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_stem_conv3x3s2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_stem_wgrad3x3s2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_pw_s2_forward_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -70,16 +70,16 @@ __device__ __forceinline__ const char* uniform_bytes(const char* p) {
 }
 
 // Y[f] = A X[f] (+ R[f]).  RB: 16-row blocks per wave; the workgroup's 4 waves are 2 column groups x 2 row halves, so
-// a workgroup covers 32 RB rows (blockIdx.y selects the row range when M is larger).  DX / DA: stages of the X / A
-// rings.  Waves 0-1 issue the X DMAs and waves 2-3 the A DMAs: vmcnt is per wave and in order, so each stream is
-// counted on its own (a wave issuing both could not wait for the one-ahead A chunk without draining the X prefetch).
-template <int RB, bool RES, int DX, int DA>
+// a workgroup covers 32 RB rows (blockIdx.y selects the row range when M is larger).  DX: stages of the X ring.
+// Waves 0-1 issue the X DMAs (counted vmcnt), waves 2-3 move the A chunks (ordinary loads, compiler-counted): vmcnt is
+// per wave and in order, so a wave doing both could not wait for its A chunk without draining the X prefetch.
+template <int RB, bool RES, int DX>
 __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict__ Apk, const __hip_bfloat16* __restrict__ X,
                                                          const __hip_bfloat16* R, __hip_bfloat16* Y, Dims d) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int kAStage = 2 * RB * 1024;
     char* Xs = lds;                                  // [DX][kXStage]
-    char* As = lds + DX * kXStage;                   // [DA][kAStage]
+    char* As = lds + DX * kXStage;                   // [2][kAStage]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cgp = wave & 1, rh = wave >> 1;
     const int n = lane & 15, g = lane >> 4;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         xoff0 = (((long long)f * d.K) * d.P + px) * 2;
     }
     const char* xbase = uniform_bytes(reinterpret_cast<const char*>(X));
-    const unsigned xs0 = dma::lds_byte_addr(Xs), as0 = dma::lds_byte_addr(As);
+    const unsigned xs0 = dma::lds_byte_addr(Xs);
     auto issue_x = [&](int c, int stage) {
         const unsigned dst = xs0 + (unsigned)(stage * kXStage + 4 * wave * kXGroup);
 #pragma unroll
@@ -112,35 +112,40 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
             if (dma_ok) dma::dma16s<false>(xbase, voff, dst + (unsigned)(i * kXGroup));
         }
     };
-    // A DMA: the chunk's 2 RB blocks are contiguous in the packed operand; wave w (2, 3) copies blocks w - 2, w, ...
-    int nA = 0;                                      // DMAs per chunk of this wave
+    // A: ordinary 16-byte loads of the packed fragments by waves 2-3 (block w - 2, w, ... of the chunk's 2 RB), written to
+    // LDS a chunk ahead.  NOT by LDS-DMA: a CU's DMA engine lands about 25 GB/s (MI355X_MICROARCH.md, ldsdma-fill), and
+    // every workgroup re-reads the whole operand from L2 -- 2.2x the bytes of X at 288 rows; measured 19.7 -> see DESIGN.
+    u32x4 areg[RB];
+    auto fetch_a = [&](int c) {
+        const u32x4* src0 = reinterpret_cast<const u32x4*>(Apk + (size_t)c * d.nrb * 1024) + lane;
 #pragma unroll
-    for (int b = 0; b < RB; ++b)
-        if (rb0 + (wave & 1) + 2 * b < d.nrb) ++nA;
-    auto issue_a = [&](int c, int stage) {
-        const char* src0 = Apk + ((size_t)c * d.nrb + rb0) * 1024;
-        const unsigned dst0 = as0 + (unsigned)(stage * kAStage);
+        for (int b = 0; b < RB; ++b) {
+            int blk = rb0 + (wave & 1) + 2 * b;
+            blk = blk < d.nrb ? blk : d.nrb - 1;                     // (blocks past the operand: a copy, never multiplied)
+            areg[b] = src0[(size_t)blk * 64];
+        }
+    };
+    auto deposit_a = [&](int stage) {
+        u32x4* dst0 = reinterpret_cast<u32x4*>(As + stage * kAStage) + lane;
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int blk = (wave & 1) + 2 * b;
-            if (rb0 + blk < d.nrb && !(d.dbg & 4))
-                dma::dma16s<false>(uniform_bytes(src0 + (size_t)blk * 1024), lane * 16, dst0 + (unsigned)(blk * 1024));
+            dst0[blk * 64] = areg[b];
         }
     };
 
     // output geometry of this lane, and its residual values: loaded up front (they land under the K loop; being older
     // than every DMA of the wave they do not disturb the counted waits below)
     const long long ug = (long long)blockIdx.x * 16 + 8 * cgp + (n >> 1);
-    bool out_ok = ug < d.nunits;
-    size_t at0 = 0;
+    const bool out_ok = ug < d.nunits;
+    size_t at0 = 0;                                  // element offset of this lane's UNIT in row 0 of its frame's output
     {
         const long long q = out_ok ? ug : 0;
         const int f = (int)(q / d.U), j = (int)(q - (long long)f * d.U);
-        const bool tail = odd_tail && j == d.U - 1;
-        if (tail && !(n & 1)) out_ok = false;                        // the repeated half of a frame's last unit
-        const int p = tail ? d.P - 4 : 8 * j + 4 * (n & 1);
-        at0 = ((size_t)f * d.M) * d.P + p;
+        const int p = (odd_tail && j == d.U - 1) ? d.P - 8 : 8 * j;  // (a frame's last unit: its repeated half is stored again,
+        at0 = ((size_t)f * d.M) * d.P + p;                           //  with the identical values)
     }
+    const int half = n & 1;                          // this lane's 4 pixels within the unit
     const int rowb = 16 * (rb0 + rh * RB) + 4 * g;
     uint2 rr[RES ? RB : 1][4];
     if (RES) {
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rowb + 16 * r + i;
-                rr[r][i] = (out_ok && row < d.M) ? *reinterpret_cast<const uint2*>(R + at0 + (size_t)row * d.P) : make_uint2(0u, 0u);
+                rr[r][i] = (out_ok && row < d.M) ? *reinterpret_cast<const uint2*>(R + at0 + 4 * half + (size_t)row * d.P) : make_uint2(0u, 0u);
             }
     }
 
@@ -161,11 +166,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         for (int j = 0; j < DX - 1; ++j)
             if (j < nch) issue_x(j, j);
     } else {
-#pragma unroll
-        for (int j = 0; j < DA - 1; ++j)
-            if (j < nch) issue_a(j, j);
+        fetch_a(0);
+        deposit_a(0);
     }
-    int sx = 0, sa = 0;                              // stages of chunk c: c % DX, c % DA
+    int sx = 0, sa = 0;                              // stages of chunk c: c % DX, c & 1
     const bool ragged = (d.K & (kCh - 1)) != 0;
     const char* xrd = Xs + (2 * g) * kXGroup + cgp * 128 + n * 8;          // row 8 g + i: group 2 g + (i >> 2), row i & 3
     const char* ard = As + (rh * RB) * 1024 + lane * 16;
@@ -174,14 +178,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         // chunk c has landed when only the younger chunks of this wave's stream (up to D - 2 of them) are outstanding
         const int left = nch - 1 - c;
         if (x_wave) dma::wait_vmcnt(4 * (left < DX - 2 ? left : DX - 2));
-        else dma::wait_vmcnt(nA * (left < DA - 2 ? left : DA - 2));
         __syncthreads();
-        if (x_wave) {
-            if (c + DX - 1 < nch) issue_x(c + DX - 1, sx == 0 ? DX - 1 : sx - 1);      // into the stage of chunk c - 1
-        } else {
-            if (c + DA - 1 < nch) issue_a(c + DA - 1, sa == 0 ? DA - 1 : sa - 1);
-        }
-
         if (decltype(first)::value) {
             // the accumulators start from the residual: no register is spent on it past this point (the compiler's wait
             // for these loads also drains the DMAs issued so far -- once per workgroup)
@@ -199,10 +196,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
                     }
                 }
         }
+        if (x_wave) {
+            if (c + DX - 1 < nch) issue_x(c + DX - 1, sx == 0 ? DX - 1 : sx - 1);      // into the stage of chunk c - 1
+        } else {
+            if (c + 1 < nch) fetch_a(c + 1);                                           // lands under this chunk's MFMAs
+        }
+
         const char* xs = xrd + sx * kXStage;
         const char* as = ard + sa * kAStage;
         sx = sx == DX - 1 ? 0 : sx + 1;
-        sa = sa == DA - 1 ? 0 : sa + 1;
+        sa ^= 1;
         uint2 raw[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) raw[i] = *reinterpret_cast<const uint2*>(xs + (i >> 2) * kXGroup + (i & 3) * 256);
@@ -235,42 +238,266 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
                 for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q], acc[r][q], 0, 0, 0);
             }
         }
+        if (!x_wave && c + 1 < nch) deposit_a(sa);           // sa is already the stage of chunk c + 1 (last read in step c - 1)
     };
     step(0, std::true_type{});
 #pragma nounroll
     for (int c = 1; c < nch; ++c) step(c, std::false_type{});
 
-    // results: lane (n, g) holds rows 16 rb + 4 g + i, columns 4 n + q of its column group = half a unit: 4 consecutive
-    // pixels per row
-    if (!out_ok) return;
+    // results: lane (n, g) holds rows 16 rb + 4 g + i, columns 4 n + q of its column group = half a unit.  Lane pairs
+    // swap two rows each (DPP) so that every lane stores 2 rows x 16 bytes instead of 4 rows x 8: the epilogue is
+    // store-ISSUE bound (MI355X_MICROARCH.md, "attention epilogue store tail").
     if ((d.dbg & 2) && acc[0][0][0] != 12345.f) return;
+    const unsigned hm = 0u - (unsigned)half;          // all ones in the odd lane of a pair
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
+        unsigned w[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = rowb + 16 * r + i;
+            w[i][0] = bf16_bits(acc[r][0][i]) | (bf16_bits(acc[r][1][i]) << 16);
+            w[i][1] = bf16_bits(acc[r][2][i]) | (bf16_bits(acc[r][3][i]) << 16);
+        }
+        // even lane keeps rows 0, 1 and receives the partner's halves of them; odd lane keeps rows 2, 3
+        unsigned send[2][2], recv[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                send[e][h] = (w[e][h] & hm) | (w[2 + e][h] & ~hm);      // v_bfi_b32 (a ?: of array elements becomes a scratch index)
+                recv[e][h] = (unsigned)__builtin_amdgcn_mov_dpp((int)send[e][h], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            }
+        if (!out_ok) continue;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = rowb + 16 * r + 2 * half + e;
             if (row >= d.M) continue;
-            const float o0 = acc[r][0][i], o1 = acc[r][1][i], o2 = acc[r][2][i], o3 = acc[r][3][i];
-            *reinterpret_cast<uint2*>(Y + at0 + (size_t)row * d.P) =
-                make_uint2(bf16_bits(o0) | (bf16_bits(o1) << 16), bf16_bits(o2) | (bf16_bits(o3) << 16));
+            const unsigned own0 = (w[2 + e][0] & hm) | (w[e][0] & ~hm), own1 = (w[2 + e][1] & hm) | (w[e][1] & ~hm);
+            u32x4 o;
+            o[0] = (recv[e][0] & hm) | (own0 & ~hm); o[1] = (recv[e][1] & hm) | (own1 & ~hm);
+            o[2] = (own0 & hm) | (recv[e][0] & ~hm); o[3] = (own1 & hm) | (recv[e][1] & ~hm);
+            *reinterpret_cast<u32x4*>(Y + at0 + (size_t)row * d.P) = o;
         }
     }
 }
 
 inline int rows_per_wave(int nrb) { return nrb > 10 ? 9 : (nrb > 6 ? 5 : 3); }
 
-template <int RB, bool RES, int DX, int DA>
+template <int RB, bool RES, int DX>
 int launch_gemm(const char* Apk, const __hip_bfloat16* X, const __hip_bfloat16* R, __hip_bfloat16* Y, const Dims& d,
                 hipStream_t stream) {
-    constexpr size_t lds = (size_t)DX * kXStage + (size_t)DA * 2 * RB * 1024;
+    constexpr size_t lds = (size_t)DX * kXStage + (size_t)2 * 2 * RB * 1024;
     static bool raised = false;                      // > 64 KB of dynamic LDS needs the attribute, once per instance
     if (lds > 65536 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_gemm<RB, RES, DX, DA>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_gemm<RB, RES, DX>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RK_ERR_LAUNCH;
         raised = true;
     }
     const dim3 grid((unsigned)((d.nunits + 15) / 16), (unsigned)((d.nrb + 2 * RB - 1) / (2 * RB)));
-    hipLaunchKernelGGL((k_pw16_gemm<RB, RES, DX, DA>), grid, dim3(kBlock), lds, stream, Apk, X, R, Y, d);
+    hipLaunchKernelGGL((k_pw16_gemm<RB, RES, DX>), grid, dim3(kBlock), lds, stream, Apk, X, R, Y, d);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// d(weight):  dW[m][k] = sum over pixels of dY[f][m][p] * X[f][k][p].  The reduction index is the contiguous one, so a
+// 16-byte piece of a row (a "unit" = 8 pixels, as above) IS an MFMA fragment lane: both operands go into LDS unit by
+// unit (16-byte loads, two stages ahead in registers; NOT LDS-DMA: the output tiles re-read both operands from L2 and a
+// CU's DMA engine lands only ~25 GB/s, less on 64-byte pieces -- measured 53 us at 288 x 288) and come back with one
+// ds_read_b128 per fragment.  A workgroup owns an output tile of up to 160 x 160
+// (2 x 2 waves of up to 5 x 5 blocks of 16 x 16: at most 100 accumulator registers) and a range of units; a k-step is
+// 4 units = 32 pixels of all the tile's rows of both operands.  LDS slot of (row, unit u of the step) = 4 row +
+// (u ^ ((row >> 2) & 3)): a row's 4 units stay 64 contiguous bytes for the loads, and the 16 rows of a fragment read fall into 16 distinct 16-byte bank groups.  When P % 8 == 4
+// the last unit of a frame repeats 4 pixels of the unit before (see k_pw16_gemm): that half is zeroed in the dY
+// fragment.  Partials go to ws[split][M][K]; k_pw16_reduce sums them in a fixed order.
+struct WDims {
+    int F, K, M, P;
+    int U;
+    long long nunits;
+    int S;                       // splits of the unit sequence
+    int ups;                     // units per split (a multiple of 4)
+    int tilesM, tilesK;          // output tiles
+    int tbM, tbK;                // 16-row blocks per tile
+    int mbT, kbT;                // total blocks: ceil(M / 16), ceil(K / 16)
+};
+
+template <int BM, int BK>
+__global__ __launch_bounds__(kBlock, 2) void k_pw16_wgrad(const __hip_bfloat16* __restrict__ dY,
+                                                          const __hip_bfloat16* __restrict__ X, float* __restrict__ ws,
+                                                          WDims d) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int NL = 5;                            // 16-byte pieces per thread and stage (20 row groups of 16 / 4 waves)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wm = wave & 1, wk = wave >> 1;
+    const int m16 = lane & 15, g = lane >> 4;
+    // workgroup -> (split, tile): the tiles of one split are 8 ids apart, i.e. on the same XCD and dispatched together, so
+    // that the second reader of an operand row finds it in that XCD's L2
+    const int T = d.tilesM * d.tilesK;
+    const int blk8 = blockIdx.x / (8 * T), rem = blockIdx.x - blk8 * 8 * T;
+    const int tile = rem >> 3, split = blk8 * 8 + (rem & 7);
+    if (split >= d.S) return;
+    const int tm = tile / d.tilesK, tk = tile - tm * d.tilesK;
+    const int rowsM = 16 * d.tbM, rowsK = 16 * d.tbK;            // staged rows of dY / X
+    const int nq = (rowsM + rowsK) / 16;                         // row groups of 16 per stage (<= 4 NL)
+    const int stage_bytes = (rowsM + rowsK) * 64;
+    const long long u_lo = (long long)split * d.ups;
+    long long u_hi = u_lo + d.ups;
+    u_hi = u_hi < d.nunits ? u_hi : d.nunits;
+    const int nsteps = (int)((u_hi - u_lo + 3) / 4);
+    const bool odd_tail = (d.P & 7) != 0;
+
+    // load role: piece j of this thread = row group q = wave + 4 j, row 16 q + (lane >> 2), LDS slot lane of the group, i.e.
+    // unit (lane & 3) ^ ((lane >> 4) & 3) of the step (the same unit for every piece)
+    const int du = (lane & 3) ^ ((lane >> 4) & 3);
+    long long dug = u_lo + du;
+    int df, dj;
+    {
+        const long long q = dug < d.nunits ? dug : d.nunits - 1;
+        df = (int)(q / d.U); dj = (int)(q - (long long)df * d.U);
+    }
+    const char* ybase = reinterpret_cast<const char*>(dY);
+    const char* xbase = reinterpret_cast<const char*>(X);
+    long long choff[NL];                                          // byte offset of the piece's channel row in its frame
+    bool pieceY[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        int q = wave + 4 * j;
+        q = q < nq ? q : nq - 1;                                  // (pieces past the stage: a copy, not deposited)
+        const int r = 16 * q + (lane >> 2);
+        pieceY[j] = 16 * q < rowsM;
+        int ch = pieceY[j] ? 16 * d.tbM * tm + r : 16 * d.tbK * tk + (r - rowsM);
+        const int C = pieceY[j] ? d.M : d.K;
+        ch = ch < C ? ch : C - 1;                                 // rows past the operand: a copy, never stored
+        choff[j] = (long long)ch * d.P * 2;
+    }
+    auto fetch = [&](u32x4 (&v)[NL]) {
+        // (units past the end of the tensor re-read its last unit: finite values, zeroed in the dY fragment)
+        const int px = (odd_tail && dj == d.U - 1) ? d.P - 8 : 8 * dj;
+        const long long offY = (((long long)df * d.M) * d.P + px) * 2, offX = (((long long)df * d.K) * d.P + px) * 2;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            v[j] = *reinterpret_cast<const u32x4*>((pieceY[j] ? ybase + offY : xbase + offX) + choff[j]);
+        dug += 4; dj += 4;
+        while (dj >= d.U) { dj -= d.U; df += 1; }
+        if (dug >= d.nunits) { df = (int)((d.nunits - 1) / d.U); dj = (int)((d.nunits - 1) - (long long)df * d.U); }
+    };
+    auto deposit = [&](const u32x4 (&v)[NL], int stage) {
+        char* dst = lds + stage * stage_bytes + lane * 16;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            if (wave + 4 * j < nq) *reinterpret_cast<u32x4*>(dst + (wave + 4 * j) * 1024) = v[j];
+    };
+
+    // compute role: lane (m16, g) reads unit g of rows 16 b + m16; its own running unit index for the masks
+    long long cug = u_lo + g;
+    int cj = (int)(cug % d.U);
+    const int nbm = (d.tbM - wm * BM) < BM ? (d.tbM - wm * BM) : BM;       // blocks of this wave (may be <= 0)
+    const int nbk = (d.tbK - wk * BK) < BK ? (d.tbK - wk * BK) : BK;
+    f32x4 acc[BM][BK];
+#pragma unroll
+    for (int a = 0; a < BM; ++a)
+#pragma unroll
+        for (int b = 0; b < BK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // slot(row, u) = 4 row + (u ^ ((row >> 2) & 3)); row = 16 b + m16 -> (row >> 2) & 3 = (m16 >> 2) & 3
+    const int rdoff = 16 * (4 * m16 + (g ^ ((m16 >> 2) & 3)));
+
+    auto step = [&](int s, u32x4 (&v)[NL]) {
+        const int st = s & 1;
+        deposit(v, st);                                           // stage s (loaded two steps ago) -> LDS[s & 1]
+        __syncthreads();
+        if (s + 2 < nsteps) fetch(v);                             // stage s + 2 into the registers just freed
+        const char* base = lds + st * stage_bytes + rdoff;
+        // mask of this lane's unit: 0 = all of it counts, 1 = only its second half (a frame's last unit), 2 = none
+        const int mask = cug >= u_hi ? 2 : ((odd_tail && cj == d.U - 1) ? 1 : 0);
+        cug += 4; cj += 4;
+        while (cj >= d.U) cj -= d.U;
+        bf16x8 fa[BM], fb[BK];
+#pragma unroll
+        for (int a = 0; a < BM; ++a) {
+            const int ac = a < nbm ? a : 0;
+            u32x4 t = *reinterpret_cast<const u32x4*>(base + (wm * BM + ac) * 1024);
+            if (mask >= 1) { t[0] = 0u; t[1] = 0u; }
+            if (mask == 2) { t[2] = 0u; t[3] = 0u; }
+            fa[a] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int b = 0; b < BK; ++b) {
+            const int bc = b < nbk ? b : 0;
+            fb[b] = *reinterpret_cast<const bf16x8*>(base + rowsM * 64 + (wk * BK + bc) * 1024);
+        }
+#pragma unroll
+        for (int a = 0; a < BM; ++a)
+#pragma unroll
+            for (int b = 0; b < BK; ++b)
+                if (a < nbm && b < nbk) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    };
+
+    u32x4 va[NL], vb[NL];
+    fetch(va);
+    if (1 < nsteps) fetch(vb);
+    else {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) vb[j] = va[j];
+    }
+#pragma nounroll
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, va);
+        if (s + 1 < nsteps) step(s + 1, vb);
+    }
+
+    // acc[a][b][i]: m = 16 (block a) + 4 g + i, k = 16 (block b) + m16
+    float* out = ws + (size_t)split * d.M * d.K;
+#pragma unroll
+    for (int a = 0; a < BM; ++a)
+#pragma unroll
+        for (int b = 0; b < BK; ++b) {
+            if (a >= nbm || b >= nbk) continue;
+            const int k = 16 * (d.tbK * tk + wk * BK + b) + m16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * (d.tbM * tm + wm * BM + a) + 4 * g + i;
+                if (m < d.M && k < d.K) out[(size_t)m * d.K + k] = acc[a][b][i];
+            }
+        }
+}
+
+// out[i] = sum over the S partial matrices, fixed order
+__global__ __launch_bounds__(kBlock) void k_pw16_reduce(const float* __restrict__ in, float* __restrict__ out, int MK, int S) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= MK) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < S; ++c) acc += in[(size_t)c * MK + i];
+    out[i] = acc;
+}
+
+inline int make_wdims(WDims& d, int F, int K, int M, int P) {
+    if (F <= 0 || K <= 0 || M <= 0 || P < 8 || P % 4 != 0) return RK_ERR_BAD_DIMS;
+    if ((long long)F * (K > M ? K : M) * P * 2 >= (1ll << 31)) return RK_ERR_BAD_DIMS;
+    d.F = F; d.K = K; d.M = M; d.P = P;
+    d.U = (P + 7) / 8; d.nunits = (long long)F * d.U;
+    d.mbT = (M + 15) / 16; d.kbT = (K + 15) / 16;
+    d.tilesM = (d.mbT + 9) / 10; d.tilesK = (d.kbT + 9) / 10;
+    d.tbM = (d.mbT + d.tilesM - 1) / d.tilesM; d.tbK = (d.kbT + d.tilesK - 1) / d.tilesK;
+    const int T = d.tilesM * d.tilesK;
+    // splits: about 512 workgroups, at least 12 k-steps each, partial matrices of at most 24 MB in all
+    const char* e = getenv("RK_PW16_WG");
+    long long S = (e ? atoi(e) : 512) / T;
+    const long long by_steps = d.nunits / 48, by_bytes = (24ll << 20) / ((long long)M * K * 4);
+    S = S < by_steps ? S : by_steps;
+    S = S < by_bytes ? S : by_bytes;
+    S = S < 1 ? 1 : S;
+    long long ups = (d.nunits + S - 1) / S;
+    ups = (ups + 3) / 4 * 4;
+    d.ups = (int)ups;
+    d.S = (int)((d.nunits + ups - 1) / ups);
+    return RK_OK;
+}
+
+template <int BM, int BK>
+int launch_wgrad(const __hip_bfloat16* dY, const __hip_bfloat16* X, float* ws, const WDims& d, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (16 * d.tbM + 16 * d.tbK) * 64;          // <= 40 KB
+    const int T = d.tilesM * d.tilesK;
+    const unsigned grid = (unsigned)(((d.S + 7) / 8) * 8 * T);
+    hipLaunchKernelGGL((k_pw16_wgrad<BM, BK>), dim3(grid), dim3(kBlock), lds, stream, dY, X, ws, d);
     return launch_status();
 }
 
@@ -327,12 +554,41 @@ int rk_pw_gemm_packed_bf16(const void* Apk, const void* X_, const void* R_, void
     hipStream_t stream = (hipStream_t)stream_;
     const char* A = (const char*)Apk;
     const int rb = rows_per_wave(d.nrb);
-#define RK_GO(RBV, DXV, DAV) (R ? launch_gemm<RBV, true, DXV, DAV>(A, X, R, Y, d, stream) : launch_gemm<RBV, false, DXV, DAV>(A, X, R, Y, d, stream))
+#define RK_GO(RBV, DXV) (R ? launch_gemm<RBV, true, DXV>(A, X, R, Y, d, stream) : launch_gemm<RBV, false, DXV>(A, X, R, Y, d, stream))
     const bool deep = (d.dbg & 8) != 0;
-    if (rb == 9) return deep ? RK_GO(9, 4, 2) : RK_GO(9, 3, 2);
-    if (rb == 5) return deep ? RK_GO(5, 4, 3) : RK_GO(5, 3, 2);
-    return deep ? RK_GO(3, 4, 3) : RK_GO(3, 3, 2);
+    if (rb == 9) return deep ? RK_GO(9, 4) : RK_GO(9, 3);
+    if (rb == 5) return deep ? RK_GO(5, 4) : RK_GO(5, 3);
+    return deep ? RK_GO(3, 4) : RK_GO(3, 3);
 #undef RK_GO
+}
+
+// d(weight) [M][K] (fp32) = sum_f dY[f] X[f]^T for bf16 activations (dY [F, M, P], X [F, K, P], P % 4 == 0, P >= 8); ws of
+// rk_pw_wgrad16_workspace_bytes() bytes holds the per-split partial matrices.
+size_t rk_pw_wgrad16_workspace_bytes(int F, int K, int M, int P) {
+    WDims d;
+    if (make_wdims(d, F, K, M, P)) return 0;
+    return (size_t)d.S * M * K * sizeof(float);
+}
+int rk_pw_wgrad16_bf16(const void* dY_, const void* X_, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
+                       rk_stream_t stream_) {
+    const __hip_bfloat16* dY = (const __hip_bfloat16*)dY_;
+    const __hip_bfloat16* X = (const __hip_bfloat16*)X_;
+    if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
+    WDims d;
+    if (int rc = make_wdims(d, F, K, M, P)) return rc;
+    if (((uintptr_t)dY & 7) || ((uintptr_t)X & 7)) return RK_ERR_BAD_DIMS;
+    if (!ws || ws_bytes < (size_t)d.S * M * K * sizeof(float)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int bm = (d.tbM + 1) / 2 > 3 ? 5 : 3, bk = (d.tbK + 1) / 2 > 3 ? 5 : 3;
+    int rc;
+    if (bm == 5 && bk == 5) rc = launch_wgrad<5, 5>(dY, X, (float*)ws, d, stream);
+    else if (bm == 5) rc = launch_wgrad<5, 3>(dY, X, (float*)ws, d, stream);
+    else if (bk == 5) rc = launch_wgrad<3, 5>(dY, X, (float*)ws, d, stream);
+    else rc = launch_wgrad<3, 3>(dY, X, (float*)ws, d, stream);
+    if (rc) return rc;
+    const int MK = M * K;
+    hipLaunchKernelGGL(k_pw16_reduce, dim3((MK + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -23,8 +23,23 @@ pack = torch.stack([ka, kb, kb, ka], dim=1).contiguous()
 nb = int(L.rk_pw_wgrad_workspace_bytes(Fr, K, M, P)) if P % 4 == 0 else int(L.rk_pw_wgrad_odd_workspace_bytes(Fr, K, M, P))
 ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
 dw = torch.empty(M, K, device=dev)
+if which in ("gemm16", "gemm16res", "wgrad16"):
+    for d_ in sets:
+        for k_ in d_: d_[k_] = d_[k_].bfloat16()
+    pk = torch.empty(int(L.rk_pw_packed_bytes(M, K)), dtype=torch.uint8, device=dev)
+    _native.check(L.rk_pw_pack_bf16(w.data_ptr(), M, K, pk.data_ptr(), None, st), "pack")
+    nb16 = int(L.rk_pw_wgrad16_workspace_bytes(Fr, K, M, P)); ws16 = torch.empty(max(nb16, 1), dtype=torch.uint8, device=dev)
 for i in range(iters):
     s = sets[i % 3]
+    if which == "gemm16":
+        rc = L.rk_pw_gemm_packed_bf16(pk.data_ptr(), s["x"].data_ptr(), None, s["y"].data_ptr(), Fr, K, M, P, st)
+    elif which == "gemm16res":
+        rc = L.rk_pw_gemm_packed_bf16(pk.data_ptr(), s["x"].data_ptr(), s["g"].data_ptr(), s["y"].data_ptr(), Fr, K, M, P, st)
+    elif which == "wgrad16":
+        rc = L.rk_pw_wgrad16_bf16(s["g"].data_ptr(), s["x"].data_ptr(), dw.data_ptr(), Fr, K, M, P, ws16.data_ptr(), nb16, st)
+    if which in ("gemm16", "gemm16res", "wgrad16"):
+        _native.check(rc, which)
+        continue
     if which == "wgrad":
         rc = L.rk_pw_wgrad_f32(s["g"].data_ptr(), s["x"].data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, st)
     elif which == "wgrad_pro":

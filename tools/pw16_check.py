@@ -26,3 +26,20 @@ for shp in [(8, 288, 288, 14, 14), (5, 72, 72, 12, 12), (3, 144, 144, 28, 28), (
     for res in (False, True):
         run(*shp, res)
     run(*shp, False, True)
+
+def wrun(Fr, K, M, H, W):
+    P = H * W
+    g = torch.Generator(device="cpu").manual_seed(K * 3 + M)
+    x = torch.randn(Fr, K, P, generator=g).bfloat16().to(dev)
+    dy = torch.randn(Fr, M, P, generator=g).bfloat16().to(dev)
+    nb = int(L.rk_pw_wgrad16_workspace_bytes(Fr, K, M, P))
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    dw = torch.full((M, K), float("nan"), device=dev)
+    _native.check(L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, st), "wgrad16")
+    torch.cuda.synchronize()
+    ref = torch.einsum("fmp,fkp->mk", dy.double(), x.double())
+    err = (dw.double() - ref).abs().max().item(); sc = ref.abs().max().item()
+    print("wgrad", (Fr, K, M, H, W), f"max err {err:.3e} scale {sc:.2f} rel {err/sc:.2e}", "OK" if err <= sc * 1e-5 else "FAIL", flush=True)
+for shp in [(8, 288, 288, 14, 14), (5, 72, 72, 12, 12), (3, 144, 144, 28, 28), (2, 70, 50, 6, 10), (4, 288, 576, 14, 14), (3, 576, 288, 14, 14),
+            (1, 32, 16, 2, 4), (3, 40, 24, 3, 4), (2, 64, 64, 4, 5), (7, 100, 330, 6, 6), (256, 288, 288, 14, 14), (32, 72, 144, 56, 56)]:
+    wrun(*shp)

@@ -50,7 +50,10 @@ for (Fr, K, M, H, W) in SHAPES:
     f2 = lambda s: _native.check(L.rk_pw_gemm_packed_bf16(pf.data_ptr(), s["x"].data_ptr(), None, s["y"].data_ptr(), Fr, K, M, P, st), "f2")
     f2r = lambda s: _native.check(L.rk_pw_gemm_packed_bf16(pf.data_ptr(), s["x"].data_ptr(), s["g"].data_ptr(), s["y"].data_ptr(), Fr, K, M, P, st), "f2r")
     d2 = lambda s: _native.check(L.rk_pw_gemm_packed_bf16(pb.data_ptr(), s["g"].data_ptr(), None, s["o"].data_ptr(), Fr, M, K, P, st), "d2")
-    for name, fn, by in (("fwd", fwd, ex + ey), ("fwd+res", fwr, ex + 2 * ey), ("dgrad", dgr, ex + ey), ("wgrad", wgr, ex + ey),
+    nb2 = int(L.rk_pw_wgrad16_workspace_bytes(Fr, K, M, P))
+    ws2 = torch.empty(max(nb2, 1), dtype=torch.uint8, device=dev)
+    w2 = lambda s: _native.check(L.rk_pw_wgrad16_bf16(s["g"].data_ptr(), s["x"].data_ptr(), dw.data_ptr(), Fr, K, M, P, ws2.data_ptr(), nb2, st), "w2")
+    for name, fn, by in (("wgrad/16", w2, ex + ey), ("fwd", fwd, ex + ey), ("fwd+res", fwr, ex + 2 * ey), ("dgrad", dgr, ex + ey), ("wgrad", wgr, ex + ey),
                          ("pack", pck, 0), ("fwd/pk", f2, ex + ey), ("fwd+res/pk", f2r, ex + 2 * ey), ("dgrad/pk", d2, ex + ey)):
         us = timed(fn, sets)
         print(f"{(Fr, K, M, H, W)} {name:10s} {us:8.1f} us  {by / us / 1e6 / 8:6.3f} of 8 TB/s", flush=True)
