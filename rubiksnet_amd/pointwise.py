@@ -32,8 +32,41 @@ def pointwise_mode():
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}      # storage of the activations; weights are fp32
 
 
+_PACKED = {}        # id(weight) -> (version, data_ptr, forward operand, d(input) operand): bf16 MFMA-fragment order
+
+
+def _packed(weight):
+    """The weight of a 1x1 convolution packed for rk_pw_gemm_packed_bf16 (rk_pw16.hip): both operands (W for the forward,
+    W^T for d(input)) in one call, redone when the parameter's version counter moves (an optimizer step)."""
+    key = id(weight)
+    ent = _PACKED.get(key)
+    if ent is not None and ent[0] == weight._version and ent[1] == weight.data_ptr():
+        return ent[2], ent[3]
+    if len(_PACKED) > 1024:
+        _PACKED.clear()
+    L = _native.lib()
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    dev = weight.device
+    with torch.cuda.device(dev):
+        fwd = torch.empty(int(L.rk_pw_packed_bytes(Cout, Cin)), dtype=torch.uint8, device=dev)
+        bwd = torch.empty(int(L.rk_pw_packed_bytes(Cin, Cout)), dtype=torch.uint8, device=dev)
+        _native.check(L.rk_pw_pack_bf16(weight.data_ptr(), Cout, Cin, fwd.data_ptr(), bwd.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream), "rk_pw_pack_bf16")
+    _PACKED[key] = (weight._version, weight.data_ptr(), fwd, bwd)
+    return fwd, bwd
+
+
 def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None):
     dev = x.device
+    if x.dtype == torch.bfloat16 and P >= 8 and a.dim() >= 2 and a.shape[0] == (M if a_is_mk else K):
+        # bf16 activations: the packed-weight kernel (the conv's weight, as it is or transposed)
+        fwd, bwd = _packed(a)
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_pw_gemm_packed_bf16(
+                (fwd if a_is_mk else bwd).data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                out.data_ptr(), Fr, K, M, P, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_pw_gemm_packed_bf16")
+        return out
     fn = getattr(_native.lib(), "rk_pw_gemm_" + _SFX[x.dtype])
     with torch.cuda.device(dev):
         rc = fn(a.data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None, out.data_ptr(),
@@ -55,6 +88,12 @@ def _wgrad(dy, x, weight):
     L = _native.lib()
     dw = torch.empty_like(weight)                       # fp32, whatever the activations' storage type
     with torch.cuda.device(dev):
+        if x.dtype == torch.bfloat16 and H * W >= 8:
+            nbytes = int(L.rk_pw_wgrad16_workspace_bytes(Fr, Cin, Cout, H * W))
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            _native.check(L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W, ws.data_ptr(),
+                                               nbytes, torch.cuda.current_stream(dev).cuda_stream), "rk_pw_wgrad16_bf16")
+            return dw
         nbytes = int(L.rk_pw_wgrad_workspace_bytes(Fr, Cin, Cout, H * W))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         rc = getattr(L, "rk_pw_wgrad_" + _SFX[x.dtype])(
