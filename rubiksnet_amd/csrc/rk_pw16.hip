@@ -39,7 +39,6 @@ struct Dims {
     int nrb, nch;                          // 16-row blocks of the packed operand, 32-channel chunks
     int U;                                 // 16-byte units (8 pixels) per frame row: ceil(P / 8)
     long long nunits;                      // F * U
-    int dbg;
 };
 
 __device__ __forceinline__ unsigned bf16_bits(float f) {
@@ -232,11 +231,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            if (rb0 + rh * RB + r < d.nrb && !(d.dbg & 1)) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(as + r * 1024);
+            // (row blocks past the operand hold copies of its last block and are not stored: no branch per block)
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(as + r * 1024);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q], acc[r][q], 0, 0, 0);
-            }
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q], acc[r][q], 0, 0, 0);
         }
         if (!x_wave && c + 1 < nch) deposit_a(sa);           // sa is already the stage of chunk c + 1 (last read in step c - 1)
     };
@@ -247,7 +245,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     // results: lane (n, g) holds rows 16 rb + 4 g + i, columns 4 n + q of its column group = half a unit.  Lane pairs
     // swap two rows each (DPP) so that every lane stores 2 rows x 16 bytes instead of 4 rows x 8: the epilogue is
     // store-ISSUE bound (MI355X_MICROARCH.md, "attention epilogue store tail").
-    if ((d.dbg & 2) && acc[0][0][0] != 12345.f) return;
     const unsigned hm = 0u - (unsigned)half;          // all ones in the odd lane of a pair
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -427,7 +424,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_wgrad(const __hip_bfloat16* 
         for (int a = 0; a < BM; ++a)
 #pragma unroll
             for (int b = 0; b < BK; ++b)
-                if (a < nbm && b < nbk) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);   // (blocks past the tile: copies, not
+                                                                                                        //  stored; a guard here is a branch per MFMA)
     };
 
     u32x4 va[NL], vb[NL];
@@ -459,14 +457,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_wgrad(const __hip_bfloat16* 
         }
 }
 
-// out[i] = sum over the S partial matrices, fixed order
+// out[i] = sum over the S partial matrices, fixed order: 4 slices of the split range per output (one per wave, 64
+// outputs per workgroup), each summed front to back, then the 4 slice sums added in slice order
 __global__ __launch_bounds__(kBlock) void k_pw16_reduce(const float* __restrict__ in, float* __restrict__ out, int MK, int S) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= MK) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int per = (S + 3) / 4, c0 = slice * per, c1 = (c0 + per) < S ? (c0 + per) : S;
     float acc = 0.f;
+    if (i < MK) {
 #pragma unroll 8
-    for (int c = 0; c < S; ++c) acc += in[(size_t)c * MK + i];
-    out[i] = acc;
+        for (int c = c0; c < c1; ++c) acc += in[(size_t)c * MK + i];
+    }
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && i < MK) out[i] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 inline int make_wdims(WDims& d, int F, int K, int M, int P) {
@@ -550,15 +555,13 @@ int rk_pw_gemm_packed_bf16(const void* Apk, const void* X_, const void* R_, void
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
     d.nrb = (M + 15) / 16; d.nch = (K + kCh - 1) / kCh;
     d.U = (P + 7) / 8; d.nunits = (long long)F * d.U;
-    { const char* e = getenv("RK_PW16_DBG"); d.dbg = e ? atoi(e) : 0; }
     hipStream_t stream = (hipStream_t)stream_;
     const char* A = (const char*)Apk;
     const int rb = rows_per_wave(d.nrb);
 #define RK_GO(RBV, DXV) (R ? launch_gemm<RBV, true, DXV>(A, X, R, Y, d, stream) : launch_gemm<RBV, false, DXV>(A, X, R, Y, d, stream))
-    const bool deep = (d.dbg & 8) != 0;
-    if (rb == 9) return deep ? RK_GO(9, 4) : RK_GO(9, 3);
-    if (rb == 5) return deep ? RK_GO(5, 4) : RK_GO(5, 3);
-    return deep ? RK_GO(3, 4) : RK_GO(3, 3);
+    if (rb == 9) return RK_GO(9, 3);
+    if (rb == 5) return RK_GO(5, 3);
+    return RK_GO(3, 3);
 #undef RK_GO
 }
 
@@ -587,7 +590,7 @@ int rk_pw_wgrad16_bf16(const void* dY_, const void* X_, float* dW, int F, int K,
     else rc = launch_wgrad<3, 3>(dY, X, (float*)ws, d, stream);
     if (rc) return rc;
     const int MK = M * K;
-    hipLaunchKernelGGL(k_pw16_reduce, dim3((MK + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
+    hipLaunchKernelGGL(k_pw16_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
     return launch_status();
 }
 
