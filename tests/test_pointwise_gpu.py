@@ -83,8 +83,9 @@ def test_fused_residual(monkeypatch, mode):
 
 @pytest.mark.parametrize("case", [(5, 54, 54, 8, 8), (2, 54, 108, 28, 28), (3, 216, 432, 6, 6), (3, 72, 144, 8, 8)])
 def test_bf16_activations_fp32_weight(monkeypatch, case):
-    """bf16 storage (autocast): fp32 weight used as it is, fp32 MFMA arithmetic, outputs rounded once, d(weight)
-    in fp32 -- checked against conv2d in fp64 on the bf16-rounded activations."""
+    """bf16 storage (autocast): the fp32 weight is rounded to bf16 once per version (as autocast's cast would), bf16 MFMA
+    with fp32 accumulation, outputs rounded once, d(weight) in fp32 -- checked against conv2d in fp64 on the bf16-rounded
+    activations."""
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", "all")
@@ -111,6 +112,94 @@ def test_bf16_activations_fp32_weight(monkeypatch, case):
     np.testing.assert_allclose(y.float().detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-2, atol=1e-2 * float(yr.abs().max()))
     np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=1e-2 * float(xr.grad.abs().max()))
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=2e-5 * float(wr.grad.abs().max()) * Cin ** 0.5)
+
+
+_PW16 = [(8, 288, 288, 14, 14), (5, 72, 72, 12, 12), (3, 144, 144, 28, 28), (2, 70, 50, 6, 10), (4, 288, 576, 14, 14),
+         (3, 576, 288, 14, 14), (1, 32, 16, 2, 4), (3, 40, 24, 3, 4), (2, 64, 64, 4, 5), (7, 100, 330, 6, 6)]
+
+
+@pytest.mark.parametrize("case", _PW16)
+def test_packed_bf16_gemm_against_fp64(case):
+    """rk_pw_pack_bf16 + rk_pw_gemm_packed_bf16 (rk_pw16.hip) through the C ABI: forward operand, d(input) operand (W^T) and
+    the residual, against the fp64 product of the bf16-rounded operands; the result may differ from it by the one rounding
+    to bf16 (+ the fp32 accumulation).  Shapes: 14x14 planes (P % 8 == 4: a frame's last 16-byte unit overlaps the one
+    before), ragged channel counts, more rows than one workgroup takes (576), tiles that end inside a frame."""
+    from rubiksnet_amd import _native
+
+    L = _native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    Fr, K, M, H, W = case
+    P = H * W
+    g = torch.Generator().manual_seed(7 * K + M)
+    x = torch.randn(Fr, K, P, generator=g).bfloat16()
+    r = torch.randn(Fr, M, P, generator=g).bfloat16()
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    wq = w.bfloat16().double()
+    xd, rd, wd = x.cuda(), r.cuda(), w.cuda()
+    fwd = torch.empty(int(L.rk_pw_packed_bytes(M, K)), dtype=torch.uint8, device="cuda")
+    bwd = torch.empty(int(L.rk_pw_packed_bytes(K, M)), dtype=torch.uint8, device="cuda")
+    _native.check(L.rk_pw_pack_bf16(wd.data_ptr(), M, K, fwd.data_ptr(), bwd.data_ptr(), st), "pack")
+
+    def close(got, ref):
+        err = (got.double().cpu() - ref).abs()
+        bound = ref.abs() * 2.0 ** -8 + 1e-5 * float(ref.abs().max())           # one bf16 rounding + fp32 accumulation
+        assert bool((err <= bound).all()), float((err - bound).max())
+
+    for res in (None, rd):
+        y = torch.full((Fr, M, P), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _native.check(L.rk_pw_gemm_packed_bf16(fwd.data_ptr(), xd.data_ptr(), res.data_ptr() if res is not None else None,
+                                               y.data_ptr(), Fr, K, M, P, st), "gemm")
+        ref = torch.einsum("mk,fkp->fmp", wq, x.double())
+        close(y, ref + r.double() if res is not None else ref)
+    dx = torch.full((Fr, K, P), float("nan"), dtype=torch.bfloat16, device="cuda")       # d(input): W^T applied to [F, M, P]
+    _native.check(L.rk_pw_gemm_packed_bf16(bwd.data_ptr(), rd.data_ptr(), None, dx.data_ptr(), Fr, M, K, P, st), "dgrad")
+    close(dx, torch.einsum("mk,fmp->fkp", wq, r.double()))
+    # in place: R = Y
+    y = rd.clone()
+    _native.check(L.rk_pw_gemm_packed_bf16(fwd.data_ptr(), xd.data_ptr(), y.data_ptr(), y.data_ptr(), Fr, K, M, P, st), "gemm")
+    close(y, torch.einsum("mk,fkp->fmp", wq, x.double()) + r.double())
+
+
+@pytest.mark.parametrize("case", _PW16 + [(256, 288, 288, 14, 14), (32, 72, 144, 56, 56)])
+def test_bf16_wgrad16_against_fp64(case):
+    """rk_pw_wgrad16_bf16: d(weight) of bf16 operands, fp32 accumulation, against the fp64 sum (incl. the full-size Large-AQ
+    layer: 73 splits x 4 output tiles, and a frame's overlapping last unit counted once)."""
+    from rubiksnet_amd import _native
+
+    L = _native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    Fr, K, M, H, W = case
+    P = H * W
+    g = torch.Generator().manual_seed(3 * K + M)
+    x = torch.randn(Fr, K, P, generator=g).bfloat16().cuda()
+    dy = torch.randn(Fr, M, P, generator=g).bfloat16().cuda()
+    nb = int(L.rk_pw_wgrad16_workspace_bytes(Fr, K, M, P))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.full((M, K), float("nan"), device="cuda")
+    _native.check(L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, st), "wgrad16")
+    ref = torch.einsum("fmp,fkp->mk", dy.double(), x.double()).cpu()
+    np.testing.assert_allclose(dw.double().cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    # deterministic: same bits on a second launch
+    dw2 = torch.empty_like(dw)
+    _native.check(L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw2.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, st), "wgrad16")
+    assert torch.equal(dw, dw2)
+    assert L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb - 1, st) != 0   # workspace
+
+
+def test_packed_weight_follows_the_parameter_version(monkeypatch):
+    """The packed copy of a weight is redone when the parameter changes in place (an optimizer step)."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    monkeypatch.setenv("RK_PW", "all")
+    _reload_switches()
+    torch.manual_seed(0)
+    conv = nn.Conv2d(16, 32, 1, bias=False).cuda()
+    x = torch.randn(2, 16, 4, 4, device="cuda").bfloat16()
+    y1 = conv1x1(conv, x).detach().float()
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    y2 = conv1x1(conv, x).detach().float()
+    np.testing.assert_allclose(y2.cpu().numpy(), 2 * y1.cpu().numpy(), rtol=2 ** -7, atol=1e-6)
 
 
 def test_ineligible_layers_take_the_stock_path(monkeypatch):
