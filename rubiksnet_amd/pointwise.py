@@ -221,6 +221,50 @@ def _eligible_s2(conv, x):
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0)
 
 
+class _ConvS2Bf16Func(torch.autograd.Function):
+    """The same projecting shortcut for bf16 activations (autocast): the even pixels are gathered once (a strided copy: a
+    quarter of the elements), and the three GEMMs run on the stride-1 bf16 kernels of rk_pw16.hip on that quarter-size
+    tensor -- which is also what is saved for backward.  d(input) is scattered back into zeros.  MIOpen ran these between
+    NCHW <-> NHWC transposes of the FULL-size tensors: 0.5 / 0.8 ms forward / backward at [256, 72, 112, 112]."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        xs = x[:, :, ::2, ::2].contiguous()
+        y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
+        _gemm(weight, xs, y, Fr, Cin, Cout, (H // 2) * (W // 2), True)
+        ctx.save_for_backward(xs, weight)
+        ctx.full = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != xs.dtype:
+            dy = dy.to(xs.dtype)
+        Fr, Cin, Ho, Wo = xs.shape
+        H, W = ctx.full
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dxs = torch.empty_like(xs)
+            _gemm(weight, dy, dxs, Fr, weight.shape[0], Cin, Ho * Wo, False)
+            dx = torch.zeros(Fr, Cin, H, W, dtype=xs.dtype, device=xs.device)
+            dx[:, :, ::2, ::2] = dxs
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dy, xs, weight)
+        return dx, dw
+
+
+def _eligible_s2_bf16(conv, x):
+    return (pointwise_mode() != "0" and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.numel() > 0
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0 and (x.shape[2] // 2) * (x.shape[3] // 2) >= 8)
+
+
 class _Conv1x1OddFunc(torch.autograd.Function):
     """1x1 / stride-1 convolution (+ residual) on planes with H * W % 4 != 0 -- the 7x7 planes of layer4 -- on the
     LDS-staged HIP GEMM (k_pw_gemm_odd) and the scalar-pixel d(weight) kernel.  MIOpen ran these as NHWC implicit GEMMs
@@ -336,6 +380,8 @@ def conv1x1(conv, x, residual=None):
         conv = conv[-1]
     if residual is None and _eligible_s2(conv, x):
         return _ConvS2Func.apply(x.contiguous(), conv.weight)
+    if residual is None and _eligible_s2_bf16(conv, x):
+        return _ConvS2Bf16Func.apply(x, conv.weight)
     if x.dim() == 4 and x.is_contiguous():
         if residual is None and _eligible_s2_odd(conv, x):
             return _ConvS2OddFunc.apply(x, conv.weight)

@@ -186,6 +186,37 @@ def test_bf16_wgrad16_against_fp64(case):
     assert L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb - 1, st) != 0   # workspace
 
 
+@pytest.mark.parametrize("case", [(4, 72, 144, 8, 8), (3, 24, 24, 12, 8), (2, 144, 288, 28, 28)])
+def test_bf16_strided_shortcut(monkeypatch, case):
+    """1x1 / stride-2 convolution on bf16 activations: even pixels gathered, stride-1 bf16 kernels on the quarter-size tensor,
+    d(input) scattered into zeros -- against conv2d(stride=2) in fp64."""
+    from rubiksnet_amd.pointwise import conv1x1
+
+    monkeypatch.setenv("RK_PW", "all")
+    _reload_switches()
+    Fr, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(Fr, Cin, H, W, generator=g).bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    dy = torch.randn(Fr, Cout, H // 2, W // 2, generator=g).bfloat16()
+    xr, wr = x.double().requires_grad_(True), w.bfloat16().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=2)
+    yr.backward(dy.double())
+    conv = nn.Conv2d(Cin, Cout, 1, stride=2, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xd = x.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv1x1(conv, xd)
+    assert y.dtype == torch.bfloat16 and "ConvS2Bf16Func" in type(y.grad_fn).__name__
+    y.backward(dy.cuda())
+    tol = lambda t: 2.0 ** -7 * float(t.abs().max())
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), yr.detach().numpy(), rtol=0, atol=tol(yr))
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=0, atol=tol(xr.grad))
+    assert float(xd.grad[:, :, 1::2, :].abs().max()) == 0.0 and float(xd.grad[:, :, :, 1::2].abs().max()) == 0.0
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=1e-5 * float(wr.grad.abs().max()))
+
+
 def test_packed_weight_follows_the_parameter_version(monkeypatch):
     """The packed copy of a weight is redone when the parameter changes in place (an optimizer step)."""
     from rubiksnet_amd.pointwise import conv1x1
