@@ -484,8 +484,7 @@ inline int make_wdims(WDims& d, int F, int K, int M, int P) {
     d.tbM = (d.mbT + d.tilesM - 1) / d.tilesM; d.tbK = (d.kbT + d.tilesK - 1) / d.tilesK;
     const int T = d.tilesM * d.tilesK;
     // splits: about 512 workgroups, at least 12 k-steps each, partial matrices of at most 24 MB in all
-    const char* e = getenv("RK_PW16_WG");
-    long long S = (e ? atoi(e) : 512) / T;
+    long long S = 512 / T;
     const long long by_steps = d.nunits / 48, by_bytes = (24ll << 20) / ((long long)M * K * 4);
     S = S < by_steps ? S : by_steps;
     S = S < by_bytes ? S : by_bytes;
