@@ -194,6 +194,55 @@ def tshift_bench(env, iters=60, settle_s=0.2):
     return out
 
 
+def pw16_bench(env, iters=40, settle_s=0.2):
+    """The bf16 1x1 convolution kernels of rk_pw16.hip (SURVEY 8(f) f1 under configs[4]'s autocast) on the layer 70 of
+    Large-AQ's 102 convolutions have, [256, 288 -> 288, 14, 14], through the C ABI: forward, forward + residual, d(input),
+    d(weight).  Algorithmic bytes: one read per operand, one write per result (the weights are L2-resident)."""
+    from rubiksnet_amd import _native
+    L = _native.lib()
+    dev = env.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    Fr, K, M, P = 256, 288, 288, 196
+    sets = [(torch.randn(Fr, K, P, device=dev).bfloat16(), torch.randn(Fr, M, P, device=dev).bfloat16(),
+             torch.empty(Fr, M, P, device=dev, dtype=torch.bfloat16), torch.empty(Fr, K, P, device=dev, dtype=torch.bfloat16))
+            for _ in range(3)]
+    w = torch.randn(M, K, device=dev) / K ** 0.5
+    pf = torch.empty(int(L.rk_pw_packed_bytes(M, K)), dtype=torch.uint8, device=dev)
+    pb = torch.empty(int(L.rk_pw_packed_bytes(K, M)), dtype=torch.uint8, device=dev)
+    _native.check(L.rk_pw_pack_bf16(w.data_ptr(), M, K, pf.data_ptr(), pb.data_ptr(), stream), "rk_pw_pack_bf16")
+    nb = int(L.rk_pw_wgrad16_workspace_bytes(Fr, K, M, P))
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    dw = torch.empty(M, K, device=dev)
+    it = [0]
+
+    def nxt():
+        it[0] += 1
+        return sets[it[0] % 3]
+
+    def fwd():
+        x, g, y, o = nxt()
+        _native.check(L.rk_pw_gemm_packed_bf16(pf.data_ptr(), x.data_ptr(), None, y.data_ptr(), Fr, K, M, P, stream), "gemm")
+
+    def fwd_res():
+        x, g, y, o = nxt()
+        _native.check(L.rk_pw_gemm_packed_bf16(pf.data_ptr(), x.data_ptr(), g.data_ptr(), y.data_ptr(), Fr, K, M, P, stream), "gemm")
+
+    def dgrad():
+        x, g, y, o = nxt()
+        _native.check(L.rk_pw_gemm_packed_bf16(pb.data_ptr(), g.data_ptr(), None, o.data_ptr(), Fr, M, K, P, stream), "dgrad")
+
+    def wgrad():
+        x, g, y, o = nxt()
+        _native.check(L.rk_pw_wgrad16_bf16(g.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, stream), "wgrad")
+
+    e = Fr * K * P * 2
+    out = {"layer": [Fr, K, M, 14, 14], "dtype": "bf16 activations, fp32 accumulation, fp32 d(weight)"}
+    for name, fn, passes in (("fwd", fwd, 2), ("fwd_residual", fwd_res, 3), ("dgrad", dgrad, 2), ("wgrad", wgrad, 2)):
+        t = _steady(fn, iters, settle_s)
+        out[name] = {"us": t * 1e6, "GBps": passes * e / t / 1e9, "frac_of_hbm_peak": passes * e / t / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def op2d_bench(env, iters=60, settle_s=0.3):
     """the 2-D operator of the -aq networks on the same number of elements
     ([256,64,56,56] = 32 clips x 8 frames), fp32 and bf16.  Same method as the 3-D leg: an untimed run-in (the
@@ -590,7 +639,7 @@ def main():
     # ran the 2-D / secondary legs on rank 0 after the last barrier while ranks 1..N-1 were already tearing the RCCL
     # communicator down -- untested on RCCL, flagged by the round-2 review.)  The other ranks idle at the barrier.
     traffic, traffic_src = pmc_traffic("backward")
-    rk2d = secondary = tshift = cpu = None
+    rk2d = secondary = tshift = pw16 = cpu = None
     if env.is_main:
         rk2d = op2d_bench(env)
         secondary = secondary_points(env)
@@ -598,6 +647,10 @@ def main():
             tshift = tshift_bench(env)
         except Exception as exc:
             tshift = {"error": repr(exc)}
+        try:
+            pw16 = pw16_bench(env)
+        except Exception as exc:
+            pw16 = {"error": repr(exc)}
         if not args.no_cpu:                  # after every timed GPU leg
             cpu = cpu_baseline()
     dp.barrier(env)
@@ -639,7 +692,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "rk2d": rk2d,
-            "tshift": tshift,
+            "tshift": tshift, "pw_bf16": pw16,
             "secondary": secondary,
             "model": models.get("tiny-train"),
             "models": models,
