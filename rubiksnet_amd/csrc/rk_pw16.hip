@@ -6,11 +6,10 @@
 //   * forward / d(input) (k_pw16_gemm): a workgroup owns ALL rows of a 128-pixel column tile (up to 288 rows per
 //     workgroup: 144 accumulator registers per lane, 2 workgroups per CU), so X is read once (the first-generation
 //     kernel of rk_pw.hip re-read it once per 64-row tile, 5x at 288 rows).  X is streamed by LDS-DMA in its memory
-//     layout ([32 channels][128 pixels] per chunk, 4-byte pieces so that a tile may straddle frames at any P % 4 ==
-//     0), 3 chunks deep; the channel-major -> k-major transposition a bf16 MFMA operand needs happens in REGISTERS
+//     layout ([32 channels][128 pixels] per chunk, 16-byte units that never span frames), 3 chunks deep; the channel-major -> k-major transposition a bf16 MFMA operand needs happens in REGISTERS
 //     (8 ds_read_b64 + 16 v_perm_b32 per wave and chunk give the 4 B-fragments of a 64-pixel column group; no 2-byte
-//     LDS writes).  The small operand is pre-packed once per weight version (k_pw16_pack) into bf16 MFMA A-fragment
-//     order and DMA'd 16 B per lane, one chunk ahead.  v_mfma_f32_16x16x32_bf16: 16-row blocks fit 72 / 144 / 288
+//     LDS writes).  The small operand is pre-packed (k_pw16_pack, one launch per forward) into bf16 MFMA A-fragment
+//     order and moved 16 B per lane, one chunk ahead.  v_mfma_f32_16x16x32_bf16: 16-row blocks fit 72 / 144 / 288
 //     rows with little padding.
 //   * d(weight) (k_pw16_wgrad): see below.
 //
@@ -47,10 +46,8 @@ __device__ __forceinline__ unsigned bf16_bits(float f) {
 
 // ---- packing: fp32 [M][K] (mk != 0) or [K][M] -> bf16 fragments [chunk][row block][lane][8]; lane (m = l & 15,
 // g = l >> 4) of block rb, chunk c holds rows 16 rb + m, reduction indices 32 c + 8 g .. + 7 (zeros outside) ----
-__global__ __launch_bounds__(kBlock) void k_pw16_pack(const float* __restrict__ A, int M, int K, int mk, int nrb, int nch,
-                                                      uint4* __restrict__ out) {
-    const int u = blockIdx.x * kBlock + threadIdx.x;
-    if (u >= nrb * nch * 64) return;
+__device__ __forceinline__ void pack_unit(const float* __restrict__ A, int M, int K, int mk, int nrb, int u,
+                                          uint4* __restrict__ out) {
     const int lane = u & 63, rb = (u >> 6) % nrb, c = (u >> 6) / nrb;
     const int m = 16 * rb + (lane & 15), k0 = kCh * c + 8 * (lane >> 4);
     unsigned h[8];
@@ -62,6 +59,14 @@ __global__ __launch_bounds__(kBlock) void k_pw16_pack(const float* __restrict__ 
         h[j] = bf16_bits(v);
     }
     out[u] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+// W [Cout][Cin] -> fwd (rows Cout, depth Cin) in the first nf 16-byte units of the launch, bwd (rows Cin, depth Cout: W^T)
+// in the rest; either output may be absent (its unit count 0)
+__global__ __launch_bounds__(kBlock) void k_pw16_pack(const float* __restrict__ W, int Cout, int Cin, int nf, int nb,
+                                                      uint4* __restrict__ fwd, uint4* __restrict__ bwd) {
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u < nf) pack_unit(W, Cout, Cin, 1, (Cout + 15) / 16, u, fwd);
+    else if (u < nf + nb) pack_unit(W, Cin, Cout, 0, (Cin + 15) / 16, u - nf, bwd);
 }
 
 __device__ __forceinline__ const char* uniform_bytes(const char* p) {
@@ -529,16 +534,10 @@ int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_
     if (Cout <= 0 || Cin <= 0) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)fwd & 15) || ((uintptr_t)bwd & 15)) return RK_ERR_BAD_DIMS;
     hipStream_t stream = (hipStream_t)stream_;
-    if (fwd) {
-        const int nrb = (Cout + 15) / 16, nch = (Cin + kCh - 1) / kCh, units = nrb * nch * 64;
-        hipLaunchKernelGGL(k_pw16_pack, dim3((units + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, W, Cout, Cin, 1, nrb, nch,
-                           (uint4*)fwd);
-    }
-    if (bwd) {                                                     // rows = Cin, depth = Cout, element (m, k) = W[k][m]
-        const int nrb = (Cin + 15) / 16, nch = (Cout + kCh - 1) / kCh, units = nrb * nch * 64;
-        hipLaunchKernelGGL(k_pw16_pack, dim3((units + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, W, Cin, Cout, 0, nrb, nch,
-                           (uint4*)bwd);
-    }
+    const int nf = fwd ? ((Cout + 15) / 16) * ((Cin + kCh - 1) / kCh) * 64 : 0;
+    const int nb = bwd ? ((Cin + 15) / 16) * ((Cout + kCh - 1) / kCh) * 64 : 0;
+    hipLaunchKernelGGL(k_pw16_pack, dim3((nf + nb + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, W, Cout, Cin, nf, nb,
+                       (uint4*)fwd, (uint4*)bwd);                  // one launch for both operands
     return launch_status();
 }
 

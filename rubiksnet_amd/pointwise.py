@@ -32,18 +32,10 @@ def pointwise_mode():
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}      # storage of the activations; weights are fp32
 
 
-_PACKED = {}        # id(weight) -> (version, data_ptr, forward operand, d(input) operand): bf16 MFMA-fragment order
-
-
-def _packed(weight):
-    """The weight of a 1x1 convolution packed for rk_pw_gemm_packed_bf16 (rk_pw16.hip): both operands (W for the forward,
-    W^T for d(input)) in one call, redone when the parameter's version counter moves (an optimizer step)."""
-    key = id(weight)
-    ent = _PACKED.get(key)
-    if ent is not None and ent[0] == weight._version and ent[1] == weight.data_ptr():
-        return ent[2], ent[3]
-    if len(_PACKED) > 1024:
-        _PACKED.clear()
+def _pack(weight):
+    """The weight of a 1x1 convolution packed for rk_pw_gemm_packed_bf16 (rk_pw16.hip): both operands -- W for the forward,
+    W^T for d(input) -- in ONE small launch.  Redone on every forward (the d(input) operand rides to the backward in the
+    autograd context): no cache key sees in-place edits made through `.data` (cf. _bn_affine)."""
     L = _native.lib()
     Cout, Cin = weight.shape[0], weight.shape[1]
     dev = weight.device
@@ -52,18 +44,22 @@ def _packed(weight):
         bwd = torch.empty(int(L.rk_pw_packed_bytes(Cin, Cout)), dtype=torch.uint8, device=dev)
         _native.check(L.rk_pw_pack_bf16(weight.data_ptr(), Cout, Cin, fwd.data_ptr(), bwd.data_ptr(),
                                         torch.cuda.current_stream(dev).cuda_stream), "rk_pw_pack_bf16")
-    _PACKED[key] = (weight._version, weight.data_ptr(), fwd, bwd)
     return fwd, bwd
 
 
-def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None):
+def _packed_ok(a, x, K, M, P, a_is_mk):
+    return x.dtype == torch.bfloat16 and P >= 8 and a.dim() >= 2 and a.shape[0] == (M if a_is_mk else K)
+
+
+def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None, packed=None):
     dev = x.device
-    if x.dtype == torch.bfloat16 and P >= 8 and a.dim() >= 2 and a.shape[0] == (M if a_is_mk else K):
-        # bf16 activations: the packed-weight kernel (the conv's weight, as it is or transposed)
-        fwd, bwd = _packed(a)
+    if _packed_ok(a, x, K, M, P, a_is_mk):
+        # bf16 activations: the packed-weight kernel (`packed`: the operand, packed by the caller's forward)
+        if packed is None:
+            packed = _pack(a)[0 if a_is_mk else 1]
         with torch.cuda.device(dev):
             rc = _native.lib().rk_pw_gemm_packed_bf16(
-                (fwd if a_is_mk else bwd).data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                packed.data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None,
                 out.data_ptr(), Fr, K, M, P, torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "rk_pw_gemm_packed_bf16")
         return out
@@ -114,9 +110,13 @@ class _Conv1x1Func(torch.autograd.Function):
     def forward(ctx, x, weight, hip_gemm, residual, hip_dx=None):
         Fr, Cin, H, W = x.shape
         Cout = weight.shape[0]
+        ctx.packed_bwd = None
         if hip_gemm:
             y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
-            _gemm(weight, x, y, Fr, Cin, Cout, H * W, True, residual)      # `+ residual` in the GEMM's epilogue
+            fwd = None
+            if _packed_ok(weight, x, Cin, Cout, H * W, True):
+                fwd, ctx.packed_bwd = _pack(weight)
+            _gemm(weight, x, y, Fr, Cin, Cout, H * W, True, residual, fwd)      # `+ residual` in the GEMM's epilogue
         else:
             y = torch.ops.aten.convolution(x, _as(weight, x.dtype), None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
             if residual is not None:
@@ -137,7 +137,7 @@ class _Conv1x1Func(torch.autograd.Function):
             if ctx.hip_dx:
                 Fr, Cin, H, W = x.shape
                 dx = torch.empty_like(x)
-                _gemm(weight, dy, dx, Fr, weight.shape[0], Cin, H * W, False)     # W read as [K=Cout][M=Cin]
+                _gemm(weight, dy, dx, Fr, weight.shape[0], Cin, H * W, False, None, ctx.packed_bwd)     # W read as [K=Cout][M=Cin]
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, _as(weight, x.dtype), None, *_ATEN_ARGS,
                                                          [True, False, False])[0]
@@ -233,7 +233,8 @@ class _ConvS2Bf16Func(torch.autograd.Function):
         Cout = weight.shape[0]
         xs = x[:, :, ::2, ::2].contiguous()
         y = torch.empty(Fr, Cout, H // 2, W // 2, dtype=x.dtype, device=x.device)
-        _gemm(weight, xs, y, Fr, Cin, Cout, (H // 2) * (W // 2), True)
+        fwd, ctx.packed_bwd = _pack(weight)
+        _gemm(weight, xs, y, Fr, Cin, Cout, (H // 2) * (W // 2), True, None, fwd)
         ctx.save_for_backward(xs, weight)
         ctx.full = (H, W)
         return y
@@ -249,7 +250,7 @@ class _ConvS2Bf16Func(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dxs = torch.empty_like(xs)
-            _gemm(weight, dy, dxs, Fr, weight.shape[0], Cin, Ho * Wo, False)
+            _gemm(weight, dy, dxs, Fr, weight.shape[0], Cin, Ho * Wo, False, None, ctx.packed_bwd)
             dx = torch.zeros(Fr, Cin, H, W, dtype=xs.dtype, device=xs.device)
             dx[:, :, ::2, ::2] = dxs
         if ctx.needs_input_grad[1]:

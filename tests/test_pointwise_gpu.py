@@ -217,8 +217,9 @@ def test_bf16_strided_shortcut(monkeypatch, case):
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=1e-5 * float(wr.grad.abs().max()))
 
 
-def test_packed_weight_follows_the_parameter_version(monkeypatch):
-    """The packed copy of a weight is redone when the parameter changes in place (an optimizer step)."""
+def test_packed_weight_follows_the_parameter(monkeypatch):
+    """The packed copy of a weight is made per forward: in-place edits are seen, also those made through `.data` (which no
+    version counter records)."""
     from rubiksnet_amd.pointwise import conv1x1
 
     monkeypatch.setenv("RK_PW", "all")
@@ -231,6 +232,9 @@ def test_packed_weight_follows_the_parameter_version(monkeypatch):
         conv.weight.mul_(2.0)
     y2 = conv1x1(conv, x).detach().float()
     np.testing.assert_allclose(y2.cpu().numpy(), 2 * y1.cpu().numpy(), rtol=2 ** -7, atol=1e-6)
+    conv.weight.data.mul_(2.0)
+    y4 = conv1x1(conv, x).detach().float()
+    np.testing.assert_allclose(y4.cpu().numpy(), 4 * y1.cpu().numpy(), rtol=2 ** -7, atol=1e-6)
 
 
 def test_ineligible_layers_take_the_stock_path(monkeypatch):
