@@ -198,6 +198,20 @@ RK_DECL_TAP(bf16, void, float)
 #undef RK_DECL_TAP
 
 size_t rk_tshift3_backward_workspace_bytes(int NT, int n_segment, int C, int HW);
+/* The -aq block's training-mode bn1 + ReLU folded into its temporal filter (backbone.py:129 `out = relu(bn1(x))` feeding
+ * attention_shift.py:29-39): y = tshift3(relu(a[c] x + b[c])), ab = [2][C] from rk_bn_stats_finish_*; backward: gy -> dz =
+ * d(relu(a x + b)) masked by the ReLU (x = the block input BEFORE bn1), gtaps, and bred [C][NT / n_segment] = (sum dz,
+ * sum dz xhat) per (channel, clip) for rk_bn_bwd_finish_tiles_f32 (tiles = NT / n_segment) + rk_bn_bwd_dx_pre_*. */
+int rk_tshift3_bn_forward_f32(const float* x, const float* taps, const float* ab, float* y, int NT, int S, int C, int HW,
+                              rk_stream_t stream);
+int rk_tshift3_bn_forward_bf16(const void* x, const float* taps, const float* ab, void* y, int NT, int S, int C, int HW,
+                               rk_stream_t stream);
+int rk_tshift3_bn_backward_f32(const float* gy, const float* x, const float* taps, const float* ab, const float* save_mean,
+                               const float* save_invstd, float* dz, float* gtaps, void* bred, int NT, int S, int C, int HW,
+                               void* ws, size_t ws_bytes, rk_stream_t stream);
+int rk_tshift3_bn_backward_bf16(const void* gy, const void* x, const float* taps, const float* ab, const float* save_mean,
+                                const float* save_invstd, void* dz, float* gtaps, void* bred, int NT, int S, int C, int HW,
+                                void* ws, size_t ws_bytes, rk_stream_t stream);
 
 /* The [C,3] half of AttentionShift (attention_shift.py:29-30): taps = softmax((weight / (std(weight, dim=1) + 1e-6)) / T)
  * over the three taps of a channel (std unbiased), and its backward (gweight from gtaps).  fp32; T is the module's
@@ -395,6 +409,17 @@ int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, flo
 int rk_bn_bwd_dx_pre_f32(const float* dz, const float* x, const float* gamma, const float* save_mean,
                          const float* save_invstd, const float* k12, const float* skip, float* dx, int F, int C, int P,
                          rk_stream_t stream);
+int rk_bn_bwd_dx_pre_bf16(const void* dz, const void* x, const float* gamma, const float* save_mean,
+                          const float* save_invstd, const float* k12, const void* skip, void* dx, int F, int C, int P,
+                          rk_stream_t stream);
+/* the statistics half of the training forward alone: save_mean / save_invstd / ab [2][C] (y = a x + b), running statistics
+ * and *num_batches_tracked as nn.BatchNorm2d's forward; ws of rk_bn_workspace_bytes() bytes */
+int rk_bn_stats_finish_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
+                           long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream);
+int rk_bn_stats_finish_bf16(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
+                            long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream);
 
 /* ---- input side of the network on the device -- widening row f4 of SURVEY 8(f) ----------------------
  * Replaces, per batch instead of per sample on CPU workers, the reference's transform tail

@@ -36,6 +36,10 @@ SIGNATURES = {
     "rk3d_backward_finalize_f32": (_i, [_p, _i, _i, _p, _i, ctypes.c_float, _p]),
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
     "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_tshift3_bn_forward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_tshift3_bn_forward_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_tshift3_bn_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "rk_tshift3_bn_backward_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_soft_taps_forward_f32": (_i, [_p, _p, _p, _i, _p]),
     "rk_soft_taps_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _p]),
     "rk_bn_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -81,6 +85,9 @@ SIGNATURES = {
     "rk_bn_apply_affine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rk_bn_bwd_finish_tiles_f32": (_i, [_p, _i, ctypes.c_longlong, _p, _p, _p, _i, _p]),
     "rk_bn_bwd_dx_pre_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "rk_bn_bwd_dx_pre_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "rk_bn_stats_finish_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _p, _p, _sz, _p]),
+    "rk_bn_stats_finish_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _p, _p, _sz, _p]),
 }
 for _sfx in ("f32", "bf16"):
     SIGNATURES["rk_clip_u8_to_chw_" + _sfx] = (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p])

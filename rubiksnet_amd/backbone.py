@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _native, config
-from .fused_bn import bn_relu, bn_relu_skip
+from .fused_bn import bn_relu, bn_relu_skip, bn_relu_tshift_skip
 from .pointwise import all_frozen, conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 from .train_block import bn_relu_from_stats, fused_train_block
@@ -157,6 +157,16 @@ class RubiksShiftBlock(nn.Module):
             if y is not None:
                 return y
         if isinstance(self.shortcut, nn.Identity):
+            # -aq blocks in training: bn1 + ReLU folded into the AttentionShift in front of conv2 (fused_bn.py)
+            if self.training and isinstance(self.conv2, nn.Sequential) and len(self.conv2) == 2:
+                r = bn_relu_tshift_skip(self.bn1, self.conv2[0], x)
+                if r is not None:
+                    out, shortcut = r
+                    out = bn_relu(self.bn2, conv1x1(self.conv2[1], out))
+                    out = self.as3(out)
+                    if self.se:
+                        out = self.se(out)
+                    return conv1x1(self.conv3, out, residual=shortcut)
             # relu(bn(.)) as one operator on GPU tensors (fused_bn.py); the shortcut's gradient joins inside its backward
             out, shortcut = bn_relu_skip(self.bn1, x)
         else:

@@ -239,6 +239,41 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx(const T* __restrict__ dy, 
     });
 }
 
+// The statistics half of the training forward on its own (for a consumer that normalises in its operand load:
+// rk_tshift3_bn_forward): k_bn_stats' partials -> save_mean / save_invstd / the affine map ab[2][C] and nn.BatchNorm2d's
+// running-statistics bookkeeping, exactly k_bn_apply's arithmetic.  One wave per channel.
+template <typename T>
+__global__ __launch_bounds__(kWave) void k_bn_finish_parts(const T* __restrict__ x, const float* __restrict__ part,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ ab, BnDims d, float eps, float momentum,
+                                                           long long* __restrict__ num_batches_tracked) {
+    __shared__ double sm[1][2];
+    const int c = blockIdx.x;
+    if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    double S[2];
+    channel_sums(part, c, d.G, S, sm);
+    if (threadIdx.x != 0) return;
+    const double M = (double)d.F * d.P;
+    const double ms = S[0] / M;
+    double var = S[1] / M - ms * ms;
+    var = var < 0 ? 0 : var;
+    const float mean = (float)((double)ld(x + (size_t)c * d.P) + ms);
+    const float invstd = 1.0f / sqrtf((float)var + eps);
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    float a, b;
+    affine(gamma[c], beta[c], mean, invstd, a, b);
+    ab[c] = a;
+    ab[d.C + c] = b;
+    if (running_mean) {
+        const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Training-mode fusion with the 1x1 GEMMs (rk_pw.hip, PwTrain): the statistics pass and the backward's reduction pass
 // are done by the GEMM that produces the tensor, one partial per (channel, 128-column wave tile); the kernels below
@@ -482,6 +517,38 @@ int bn_backward(const void* dy_, const void* x_, const float* gamma, const float
     return launch_status();
 }
 
+template <typename T>
+int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
+                    long long* nbt, void* ws, size_t ws_bytes, rk_stream_t stream_) {
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !ab) return RK_ERR_NULL_POINTER;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    if (!ws || ws_bytes < ws_bn(d)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* part = (float*)ws;
+    if (vec4_ok<T>(d, x, x)) hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid_bn(d)), dim3(kBlock), 0, stream, x, part, d);
+    else hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid_bn(d)), dim3(kBlock), 0, stream, x, part, d);
+    hipLaunchKernelGGL((k_bn_finish_parts<T>), dim3(C), dim3(kWave), 0, stream, x, (const float*)part, gamma, beta, running_mean,
+                       running_var, save_mean, save_invstd, ab, d, eps, momentum, nbt);
+    return launch_status();
+}
+template <typename T>
+int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save_mean, const float* save_invstd,
+                  const float* k12, const T* skip, T* dx, int F, int C, int P, rk_stream_t stream) {
+    if (!dz || !x || !gamma || !save_mean || !save_invstd || !k12 || !dx) return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    const dim3 grid(grid_bn(d)), block(kBlock);
+    const bool v4 = vec4_ok<T>(d, x, dz, dx) && !((uintptr_t)skip & (4 * sizeof(T) - 1));
+    if (v4) hipLaunchKernelGGL((k_bn_bwd_dx_pre<T, 4>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
+                               save_invstd, k12, skip, dx, d);
+    else hipLaunchKernelGGL((k_bn_bwd_dx_pre<T, 1>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
+                            save_invstd, k12, skip, dx, d);
+    return launch_status();
+}
+
 }  // namespace bn
 }  // namespace rk
 
@@ -551,16 +618,27 @@ int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, flo
 int rk_bn_bwd_dx_pre_f32(const float* dz, const float* x, const float* gamma, const float* save_mean,
                          const float* save_invstd, const float* k12, const float* skip, float* dx, int F, int C, int P,
                          rk_stream_t stream) {
-    if (!dz || !x || !gamma || !save_mean || !save_invstd || !k12 || !dx) return RK_ERR_NULL_POINTER;
-    BnDims d;
-    if (int rc = make_bn(d, F, C, P)) return rc;
-    const dim3 grid(grid_bn(d)), block(kBlock);
-    const bool v4 = vec4_ok<float>(d, x, dz, dx) && !((uintptr_t)skip & 15);
-    if (v4) hipLaunchKernelGGL((k_bn_bwd_dx_pre<float, 4>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
-                               save_invstd, k12, skip, dx, d);
-    else hipLaunchKernelGGL((k_bn_bwd_dx_pre<float, 1>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
-                            save_invstd, k12, skip, dx, d);
-    return launch_status();
+    return bn_bwd_dx_pre<float>(dz, x, gamma, save_mean, save_invstd, k12, skip, dx, F, C, P, stream);
+}
+int rk_bn_bwd_dx_pre_bf16(const void* dz, const void* x, const float* gamma, const float* save_mean,
+                          const float* save_invstd, const float* k12, const void* skip, void* dx, int F, int C, int P,
+                          rk_stream_t stream) {
+    return bn_bwd_dx_pre<__hip_bfloat16>((const __hip_bfloat16*)dz, (const __hip_bfloat16*)x, gamma, save_mean, save_invstd, k12,
+                                         (const __hip_bfloat16*)skip, (__hip_bfloat16*)dx, F, C, P, stream);
+}
+// the statistics half of the training forward (k_bn_stats + k_bn_finish_parts): save_mean / save_invstd / ab [2][C] (y = a x +
+// b) + the running statistics and *num_batches_tracked as nn.BatchNorm2d's forward; ws of rk_bn_workspace_bytes() bytes
+int rk_bn_stats_finish_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
+                           long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return bn_stats_finish<float>(x, gamma, beta, running_mean, running_var, save_mean, save_invstd, ab, F, C, P, eps, momentum,
+                                  num_batches_tracked, ws, ws_bytes, stream);
+}
+int rk_bn_stats_finish_bf16(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
+                            long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return bn_stats_finish<__hip_bfloat16>((const __hip_bfloat16*)x, gamma, beta, running_mean, running_var, save_mean,
+                                           save_invstd, ab, F, C, P, eps, momentum, num_batches_tracked, ws, ws_bytes, stream);
 }
 
 #define RK_DEF_BN(SFX, TYPE, CTYPE)                                                                               \

@@ -61,14 +61,25 @@ __device__ __forceinline__ bool my_column(const DimsT& d, int& n, int& c, int& e
     return valid;
 }
 
-template <typename T, int VEC>
+// BN: the input is relu(a[c] x + b[c]) of what is stored -- the block's training-mode bn1 + ReLU (rubiksnet/backbone.py:
+// 129: out = relu(bn1(x)) feeds the AttentionShift in front of conv2), applied to each loaded value (the zero padding in
+// t is that of the activation, not transformed); `ab` = [2][C]: a = gamma invstd, b = beta - mean a (rk_bn_stats_finish).
+template <typename T, int VEC, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict__ x,
                                                             const typename Compute<T>::type* __restrict__ taps,
-                                                            T* __restrict__ y, DimsT d) {
+                                                            T* __restrict__ y, DimsT d, const float* __restrict__ ab = nullptr) {
     using CT = typename Compute<T>::type;
     int n, c, e;
     if (!my_column(d, n, c, e)) return;
     const CT s0 = taps[c * 3 + 0], s1 = taps[c * 3 + 1], s2 = taps[c * 3 + 2];
+    CT pa = 1, pb = 0;
+    if constexpr (BN) { pa = (CT)ab[c]; pb = (CT)ab[d.C + c]; }
+    auto act = [&](CT (&v)[VEC]) {
+        if constexpr (BN) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { const CT t = fmaf(pa, v[k], pb); v[k] = t > 0 ? t : 0; }
+        }
+    };
     const size_t tstride = (size_t)d.C * d.HW;
     const size_t base = ((size_t)n * d.S * d.C + c) * d.HW;
     for (int i = e * VEC; i < d.HW; i += d.E * VEC) {
@@ -82,9 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
 #pragma unroll
             for (int t = 0; t < kSeg; ++t) raw[t] = load_raw<T, VEC>(xp + (size_t)t * tstride);
             unpack<T, VEC>(raw[0], cur);
+            act(cur);
 #pragma unroll
             for (int t = 0; t < kSeg; ++t) {
-                if (t + 1 < kSeg) unpack<T, VEC>(raw[t + 1 < kSeg ? t + 1 : 0], nxt);
+                if (t + 1 < kSeg) { unpack<T, VEC>(raw[t + 1 < kSeg ? t + 1 : 0], nxt); act(nxt); }
                 else {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) nxt[k] = 0;
@@ -100,8 +112,9 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
             continue;
         }
         load_pack<T, VEC>(xp, cur);
+        act(cur);
         for (int t = 0; t < d.S; ++t) {
-            if (t + 1 < d.S) load_pack<T, VEC>(xp + (size_t)(t + 1) * tstride, nxt);
+            if (t + 1 < d.S) { load_pack<T, VEC>(xp + (size_t)(t + 1) * tstride, nxt); act(nxt); }
             else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) nxt[k] = 0;
@@ -119,14 +132,25 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
 
 // partials part[c][3][P], P = n_batch.  FUSED (fp32 partials): they are published as {value, tag} granules and the C
 // extra blocks at the end of the grid sum them into gtaps (rk_dma.hpp: the row-sum inside the launch).
-template <typename T, int VEC, bool FUSED>
+// BN (see the forward): x is the block's input BEFORE bn1; the activation relu(a x + b) is recomputed for the tap
+// gradients, and what is written is dz = d(activation) masked by the ReLU -- together with this column's partial sums
+// bred[c][n] = (sum dz, sum dz xhat) of BatchNorm's backward reduction (xhat = (x - mean) invstd), so that the BatchNorm
+// backward is k_bn_bwd_finish_tiles + k_bn_bwd_dx_pre (rk_bn.hip): 3 tensor passes instead of 5.
+struct BnBwdT {
+    const float* ab;            // [2][C]
+    const float* mean;          // [C]
+    const float* invstd;        // [C]
+    float2* bred;               // [C][n_batch]
+};
+template <typename T, int VEC, bool FUSED, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const typename Compute<T>::type* __restrict__ taps,
                                                              T* __restrict__ gx,
                                                              typename Compute<T>::type* __restrict__ part, DimsT d,
-                                                             dma::Fin fin, typename Compute<T>::type* __restrict__ gtaps) {
+                                                             dma::Fin fin, typename Compute<T>::type* __restrict__ gtaps,
+                                                             BnBwdT bn = BnBwdT{nullptr, nullptr, nullptr, nullptr}) {
     using CT = typename Compute<T>::type;
-    __shared__ CT red[3][kBlock / kWave];
+    __shared__ CT red[BN ? 5 : 3][kBlock / kWave];
     if constexpr (FUSED) {
         if ((int)blockIdx.x >= fin.producers) {
             if (threadIdx.x < kWave) {
@@ -142,8 +166,34 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
     int n, c, e;
     const bool valid = my_column(d, n, c, e);
     CT a0 = 0, a1 = 0, a2 = 0;
+    CT z1 = 0, z2 = 0;                                    // BN: sum dz, sum dz xhat
     if (valid) {
         const CT s0 = taps[c * 3 + 0], s1 = taps[c * 3 + 1], s2 = taps[c * 3 + 2];
+        CT pa = 1, pb = 0, mu = 0, iv = 1;
+        if constexpr (BN) { pa = (CT)bn.ab[c]; pb = (CT)bn.ab[d.C + c]; mu = (CT)bn.mean[c]; iv = (CT)bn.invstd[c]; }
+        // BN: v -> activation relu(pa v + pb) in place, hv <- xhat of the stored value
+        auto act = [&](CT (&v)[VEC], CT (&hv)[VEC]) {
+            if constexpr (BN) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    hv[k] = (v[k] - mu) * iv;
+                    const CT t = fmaf(pa, v[k], pb);
+                    v[k] = t > 0 ? t : 0;
+                }
+            }
+        };
+        // BN: out (= d activation at the current t) -> dz, and the two sums
+        auto mask = [&](CT (&out)[VEC], const CT (&xc)[VEC], const CT (&hc)[VEC]) {
+            if constexpr (BN) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const CT dz = xc[k] > 0 ? out[k] : 0;
+                    out[k] = dz;
+                    z1 += dz;
+                    z2 = fmaf(dz, hc[k], z2);
+                }
+            }
+        };
         const size_t tstride = (size_t)d.C * d.HW;
         const size_t base = ((size_t)n * d.S * d.C + c) * d.HW;
         for (int i = e * VEC; i < d.HW; i += d.E * VEC) {
@@ -151,6 +201,9 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
             const T* gp = gy + base + i;
             T* op = gx + base + i;
             CT xprev[VEC], xcur[VEC], xnxt[VEC], gprev[VEC], gcur[VEC], gnxt[VEC], out[VEC];
+            CT hcur[VEC], hnxt[VEC];                      // BN: xhat of the current / next time step
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { hcur[k] = 0; hnxt[k] = 0; }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { xprev[k] = 0; gprev[k] = 0; }
             if (d.S == kSeg) {
@@ -161,11 +214,13 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
                     xr[t] = load_raw<T, VEC>(xp + (size_t)t * tstride);
                 }
                 unpack<T, VEC>(xr[0], xcur);
+                act(xcur, hcur);
                 unpack<T, VEC>(gr[0], gcur);
 #pragma unroll
                 for (int t = 0; t < kSeg; ++t) {
                     if (t + 1 < kSeg) {
                         unpack<T, VEC>(xr[t + 1 < kSeg ? t + 1 : 0], xnxt);
+                        act(xnxt, hnxt);
                         unpack<T, VEC>(gr[t + 1 < kSeg ? t + 1 : 0], gnxt);
                     } else {
 #pragma unroll
@@ -177,7 +232,11 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
                         a0 += gcur[k] * xprev[k];
                         a1 += gcur[k] * xcur[k];
                         a2 += gcur[k] * xnxt[k];
-                        xprev[k] = xcur[k]; xcur[k] = xnxt[k];
+                    }
+                    mask(out, xcur, hcur);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        xprev[k] = xcur[k]; xcur[k] = xnxt[k]; hcur[k] = hnxt[k];
                         gprev[k] = gcur[k]; gcur[k] = gnxt[k];
                     }
                     store_pack<T, VEC>(op + (size_t)t * tstride, out);
@@ -185,10 +244,12 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
                 continue;
             }
             load_pack<T, VEC>(xp, xcur);
+            act(xcur, hcur);
             load_pack<T, VEC>(gp, gcur);
             for (int t = 0; t < d.S; ++t) {
                 if (t + 1 < d.S) {
                     load_pack<T, VEC>(xp + (size_t)(t + 1) * tstride, xnxt);
+                    act(xnxt, hnxt);
                     load_pack<T, VEC>(gp + (size_t)(t + 1) * tstride, gnxt);
                 } else {
 #pragma unroll
@@ -201,12 +262,21 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
                     a0 += gcur[k] * xprev[k];
                     a1 += gcur[k] * xcur[k];
                     a2 += gcur[k] * xnxt[k];
-                    xprev[k] = xcur[k]; xcur[k] = xnxt[k];
+                }
+                mask(out, xcur, hcur);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    xprev[k] = xcur[k]; xcur[k] = xnxt[k]; hcur[k] = hnxt[k];
                     gprev[k] = gcur[k]; gcur[k] = gnxt[k];
                 }
                 store_pack<T, VEC>(op + (size_t)t * tstride, out);
             }
         }
+    }
+    if constexpr (BN) {
+        z1 = group_sum(z1, d.E, red[3]);
+        z2 = group_sum(z2, d.E, red[4]);
+        if (valid && e == 0) bn.bred[(size_t)c * d.NB + n] = make_float2((float)z1, (float)z2);
     }
     a0 = group_sum(a0, d.E, red[0]);
     a1 = group_sum(a1, d.E, red[1]);
@@ -375,6 +445,59 @@ int backwardT(const void* gy_, const void* x_, const typename Compute<T>::type* 
     }
 }
 
+// ---- the same with the block's bn1 + ReLU folded in (k_tshift3_forward / _backward <.., BN = true>) ----
+template <typename T, int VEC>
+int fwd_bn_launch(const T* x, const float* taps, const float* ab, T* y, int NT, int S, int C, int HW, hipStream_t stream) {
+    DimsT d;
+    if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
+    hipLaunchKernelGGL((k_tshift3_forward<T, VEC, true>), dim3(gridT(d)), dim3(kBlock), 0, stream, x, taps, y, d, ab);
+    return launch_status();
+}
+template <typename T, int VEC>
+int bwd_bn_launch(const T* gy, const T* x, const float* taps, const BnBwdT& bn, T* dz, float* gtaps, int NT, int S, int C,
+                  int HW, void* ws, hipStream_t stream) {
+    DimsT d;
+    if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
+    dma::Fin fin;
+    fin.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.tag = dma::next_launch_tag();
+    fin.producers = (int)gridT(d);
+    hipLaunchKernelGGL((k_tshift3_backward<T, VEC, true, true>), dim3(gridT(d) + C), dim3(kBlock), 0, stream, gy, x, taps, dz,
+                       (float*)ws, d, fin, gtaps, bn);
+    return launch_status();
+}
+template <typename T>
+int forward_bnT(const void* x_, const float* taps, const float* ab, void* y_, int NT, int S, int C, int HW,
+                rk_stream_t stream_) {
+    const T* x = (const T*)x_; T* y = (T*)y_;
+    if (!x || !taps || !ab || !y) return RK_ERR_NULL_POINTER;
+    if (HW <= 0) return RK_ERR_BAD_DIMS;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (pick_vec<T>(HW, x, y, nullptr)) {
+        case 8: if constexpr (max_vec<T>() >= 8) return fwd_bn_launch<T, 8>(x, taps, ab, y, NT, S, C, HW, stream);
+        case 4: return fwd_bn_launch<T, 4>(x, taps, ab, y, NT, S, C, HW, stream);
+        case 2: return fwd_bn_launch<T, 2>(x, taps, ab, y, NT, S, C, HW, stream);
+        default: return fwd_bn_launch<T, 1>(x, taps, ab, y, NT, S, C, HW, stream);
+    }
+}
+template <typename T>
+int backward_bnT(const void* gy_, const void* x_, const float* taps, const float* ab, const float* mean, const float* invstd,
+                 void* dz_, float* gtaps, void* bred, int NT, int S, int C, int HW, void* ws, size_t ws_bytes,
+                 rk_stream_t stream_) {
+    const T* gy = (const T*)gy_; const T* x = (const T*)x_; T* dz = (T*)dz_;
+    if (!gy || !x || !taps || !ab || !mean || !invstd || !dz || !gtaps || !bred) return RK_ERR_NULL_POINTER;
+    if (HW <= 0 || S <= 0) return RK_ERR_BAD_DIMS;
+    if (!ws || ws_bytes < rk_tshift3_backward_workspace_bytes(NT, S, C, HW)) return RK_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnBwdT bn{ab, mean, invstd, (float2*)bred};
+    switch (pick_vec<T>(HW, gy, x, dz)) {
+        case 8: if constexpr (max_vec<T>() >= 8) return bwd_bn_launch<T, 8>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
+        case 4: return bwd_bn_launch<T, 4>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
+        case 2: return bwd_bn_launch<T, 2>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
+        default: return bwd_bn_launch<T, 1>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -399,6 +522,29 @@ RK_DEF_TAP(f64, double, double, double)
 RK_DEF_TAP(f16, __half, void, float)
 RK_DEF_TAP(bf16, __hip_bfloat16, void, float)
 #undef RK_DEF_TAP
+
+// y = tshift3(relu(a[c] x + b[c])): the training-mode bn1 + ReLU of a block folded into its temporal 3-tap filter (ab = [2][C]
+// from rk_bn_stats_finish_*); backward: gy -> dz = d(relu(a x + b)) masked by the ReLU (x = the block input before bn1),
+// gtaps, and bred[C][NT / S] = (sum dz, sum dz xhat) per (channel, clip) for rk_bn_bwd_finish_tiles_f32 (tiles = NT / S)
+int rk_tshift3_bn_forward_f32(const float* x, const float* taps, const float* ab, float* y, int NT, int S, int C, int HW,
+                              rk_stream_t stream) {
+    return forward_bnT<float>(x, taps, ab, y, NT, S, C, HW, stream);
+}
+int rk_tshift3_bn_forward_bf16(const void* x, const float* taps, const float* ab, void* y, int NT, int S, int C, int HW,
+                               rk_stream_t stream) {
+    return forward_bnT<__hip_bfloat16>(x, taps, ab, y, NT, S, C, HW, stream);
+}
+int rk_tshift3_bn_backward_f32(const float* gy, const float* x, const float* taps, const float* ab, const float* save_mean,
+                               const float* save_invstd, float* dz, float* gtaps, void* bred, int NT, int S, int C, int HW,
+                               void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return backward_bnT<float>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, bred, NT, S, C, HW, ws, ws_bytes, stream);
+}
+int rk_tshift3_bn_backward_bf16(const void* gy, const void* x, const float* taps, const float* ab, const float* save_mean,
+                                const float* save_invstd, void* dz, float* gtaps, void* bred, int NT, int S, int C, int HW,
+                                void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return backward_bnT<__hip_bfloat16>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, bred, NT, S, C, HW, ws, ws_bytes,
+                                        stream);
+}
 
 int rk_soft_taps_forward_f32(const float* weight, const float* T, float* taps, int C, rk_stream_t stream) {
     if (!weight || !T || !taps) return RK_ERR_NULL_POINTER;

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import _native, config
 
-__all__ = ["bn_relu", "bn_relu_skip", "fused_bn_enabled"]
+__all__ = ["bn_relu", "bn_relu_skip", "bn_relu_tshift_skip", "fused_bn_enabled"]
 
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
 
@@ -87,6 +87,96 @@ class _BNReLUTrain(torch.autograd.Function):
                 int(ctx.relu), ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "rk_bn_relu_backward")
         return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None, None, None
+
+
+class _BNReLUTShiftTrain(torch.autograd.Function):
+    """(tshift3(relu(batch_norm(x)), taps), x): the -aq block's training-mode bn1 + ReLU folded into the temporal 3-tap
+    filter that consumes it (rk_tshift3_bn_*): the activation is never stored.  Forward = statistics pass + one filter
+    pass (instead of statistics, normalise, filter: 5 -> 3 tensor passes); backward = the filter's backward, which also
+    emits the ReLU-masked gradient and BatchNorm's two reduction sums, + the d(x) pass (8 -> 6).  The second output is x
+    for the block's identity shortcut, whose gradient joins inside the d(x) kernel (cf. _BNReLUTrain with_skip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, taps, running_mean, running_var, momentum, eps, n_segment, counter_ptr):
+        L = _native.lib()
+        Fr, C, H, W = x.shape
+        P = H * W
+        dev = x.device
+        sfx = _SFX[x.dtype]
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+        taps32 = taps.detach().float().contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            ws, nbytes = _ws(L, Fr, C, P, dev)
+            _native.check(getattr(L, "rk_bn_stats_finish_" + sfx)(
+                x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var), save_mean.data_ptr(),
+                save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(), nbytes,
+                stream), "rk_bn_stats_finish")
+            _native.check(getattr(L, "rk_tshift3_bn_forward_" + sfx)(
+                x.data_ptr(), taps32.data_ptr(), ab.data_ptr(), y.data_ptr(), Fr, n_segment, C, P, stream),
+                "rk_tshift3_bn_forward")
+        ctx.save_for_backward(x, weight, bias, taps32, save_mean, save_invstd, ab)
+        ctx.n_segment = n_segment
+        ctx.taps_dtype = taps.dtype
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, dskip=None):
+        x, weight, bias, taps32, save_mean, save_invstd, ab = ctx.saved_tensors
+        L = _native.lib()
+        Fr, C, H, W = x.shape
+        P = H * W
+        S = ctx.n_segment
+        dev = x.device
+        sfx = _SFX[x.dtype]
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            if dskip.dtype != x.dtype:
+                dskip = dskip.to(x.dtype)
+        dz = torch.empty_like(x)
+        gtaps = torch.empty_like(taps32)
+        bred = torch.empty(C, Fr // S, 2, dtype=torch.float32, device=dev)
+        k12 = torch.empty(2, C, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nb = int(L.rk_tshift3_backward_workspace_bytes(Fr, S, C, P))
+            ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+            _native.check(getattr(L, "rk_tshift3_bn_backward_" + sfx)(
+                gy.data_ptr(), x.data_ptr(), taps32.data_ptr(), ab.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
+                dz.data_ptr(), gtaps.data_ptr(), bred.data_ptr(), Fr, S, C, P, ws.data_ptr(), nb, stream),
+                "rk_tshift3_bn_backward")
+            _native.check(L.rk_bn_bwd_finish_tiles_f32(bred.data_ptr(), Fr // S, Fr * P, k12.data_ptr(), dgamma.data_ptr(),
+                                                       dbeta.data_ptr(), C, stream), "rk_bn_bwd_finish_tiles_f32")
+            _native.check(getattr(L, "rk_bn_bwd_dx_pre_" + sfx)(
+                dz.data_ptr(), x.data_ptr(), weight.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), k12.data_ptr(),
+                _ptr(dskip), dz.data_ptr(), Fr, C, P, stream), "rk_bn_bwd_dx_pre")            # in place: dz -> d(x)
+        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gtaps.to(ctx.taps_dtype), None, None, None, None, None, None)
+
+
+def bn_relu_tshift_skip(bn, shift, x):
+    """(`shift(relu(bn(x)))`, x) for an -aq block with an identity shortcut in training mode, the activation never stored
+    (`shift`: the block's AttentionShift).  None when it does not apply (the caller then takes bn_relu_skip + shift)."""
+    sw = config.switches()
+    if not (sw.fused_train and _fusable(bn, x) and bn.training and torch.is_grad_enabled() and x.requires_grad):
+        return None
+    w = getattr(shift, "weight", None)
+    S = getattr(shift, "n_segment", 0)
+    if (w is None or not w.is_cuda or w.dim() != 2 or w.shape != (x.shape[1], 3) or S <= 0 or x.shape[0] % S
+            or bn.num_features != x.shape[1]):
+        return None
+    x = x.contiguous()
+    momentum, counter = _count_batch(bn)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNReLUTShiftTrain.apply(x, bn.weight, bn.bias, shift.soft_taps(), rm, rv, momentum, bn.eps, S, _ptr(counter))
 
 
 def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):

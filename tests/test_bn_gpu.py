@@ -171,3 +171,43 @@ def test_skip_gradient_is_added_inside_the_bn_backward():
     np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=0, atol=2e-5 * float(xr.grad.abs().max()))
     np.testing.assert_allclose(dev.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(16, 24, 6, 10, 8), (8, 72, 14, 14, 8), (12, 10, 5, 3, 4), (16, 288, 14, 14, 8)])
+def test_bn_relu_folded_into_the_temporal_filter(dtype, shape):
+    """bn_relu_tshift_skip (the -aq block's training-mode bn1 + ReLU inside its AttentionShift: rk_bn_stats_finish_*,
+    rk_tshift3_bn_*, rk_bn_bwd_finish_tiles_f32, rk_bn_bwd_dx_pre_*) against the unfused pair bn_relu_skip + AttentionShift:
+    outputs, every gradient (incl. the identity shortcut's, the taps' and BatchNorm's), running statistics, the counter."""
+    from rubiksnet_amd.attention_shift import AttentionShift
+    from rubiksnet_amd.fused_bn import bn_relu_skip, bn_relu_tshift_skip
+
+    NT, C, H, W, S = shape
+    torch.manual_seed(sum(shape))
+    x0 = (torch.randn(NT, C, H, W, device="cuda") * 1.5 + 0.3).to(dtype)
+    gy = torch.randn(NT, C, H, W, device="cuda").to(dtype)
+    gs = torch.randn(NT, C, H, W, device="cuda").to(dtype)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        bn = nn.BatchNorm2d(C).cuda().train()
+        shift = AttentionShift(S, C).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            r = bn_relu_tshift_skip(bn, shift, x)
+            assert r is not None
+            y, skip = r
+        else:
+            a, skip = bn_relu_skip(bn, x)
+            y = shift(a)
+        ((y.float() * gy.float()).sum() + 0.01 * (skip.float() * gs.float()).sum()).backward()
+        res.append((y.detach().float(), x.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(), shift.weight.grad.clone(),
+                    bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    f, u = res
+    assert f[7] == u[7] == 1
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -6        # bf16: the unfused pair rounds the activation and d(activation) once more
+    for name, a, b in zip(("y", "dx", "dgamma", "dbeta", "dtaps", "running_mean", "running_var"), f[:7], u[:7]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=tol * max(1e-3, float(b.abs().max())), err_msg=name)

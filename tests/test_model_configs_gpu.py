@@ -15,6 +15,7 @@ scripts/test_installation.py:6-10, scripts/example_finetune.py:85-97.
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -153,6 +154,38 @@ class _Taps:
                                     gx=out[0].detach().cpu(), gsoft=out[1].detach().cpu())
             return out
 
+        # -aq blocks with an identity shortcut in training: bn1 + ReLU folded into the temporal filter (fused_bn.py): counted with
+        # the plain calls, recorded separately (fa_bn / ba_bn) and checked against fp64 PyTorch below
+        from rubiksnet_amd.fused_bn import _BNReLUTShiftTrain as BT
+        btf, btb = BT.forward, BT.backward
+        self.fa_bn, self.ba_bn = {}, {}
+
+        def btfwd(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter):
+            out = btf(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter)
+            taps.calls["fa"] += 1
+            key = (tuple(x.shape), x.dtype)
+            if key not in taps.fa_bn:
+                taps.fa_bn[key] = dict(x=x.detach().cpu(), w=weight.detach().cpu(), b=bias.detach().cpu(), soft=soft.detach().cpu(),
+                                       S=int(n_segment), eps=float(eps), y=out[0].detach().cpu())
+            return out
+
+        def btbwd(ctx, gy, dskip=None):
+            key = (tuple(gy.shape), ctx.saved_tensors[0].dtype)
+            first = key not in taps.ba_bn
+            if first:
+                sx, sw, sb, ssoft = ctx.saved_tensors[:4]          # (blocks share shapes: the record carries its own inputs)
+                rec = dict(gy=gy.detach().cpu(), dskip=None if dskip is None else dskip.detach().cpu(), x=sx.detach().cpu(),
+                           w=sw.detach().cpu(), b=sb.detach().cpu(), soft=ssoft.detach().cpu(), S=int(ctx.n_segment))
+            out = btb(ctx, gy, dskip)
+            taps.calls["ba"] += 1
+            if first:
+                rec.update(dx=out[0].detach().cpu(), dgamma=out[1].detach().cpu(), dbeta=out[2].detach().cpu(),
+                           gsoft=out[3].detach().cpu())
+                taps.ba_bn[key] = rec
+            return out
+
+        monkeypatch.setattr(BT, "forward", staticmethod(btfwd))
+        monkeypatch.setattr(BT, "backward", staticmethod(btbwd))
         monkeypatch.setattr(rc, "rubiks_shift_3d_forward_float", fwd3)
         monkeypatch.setattr(rc, "rubiks_shift_3d_backward_float", bwd3)
         monkeypatch.setattr(rc, "rubiks2d_forward", fwd2)
@@ -291,10 +324,44 @@ def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp)
         np.testing.assert_allclose(r["gs"].float().numpy(), gs_ref, rtol=0, atol=2e-5,
                                    err_msg="2-D d(shift) %s" % (key,))
 
-    # AttentionShift sits in front of conv2: block inputs (C, H) = (w,112), (w,56), (2w,28), (4w,14), (8w,7)
-    assert {(k[0][1], k[0][2]) for k in taps.fa} == {(width, 112), (width, 56), (2 * width, 28), (4 * width, 14),
-                                                     (8 * width, 7)}
-    assert set(taps.fa) == set(taps.ba)
+    # AttentionShift sits in front of conv2: block inputs (C, H) = (w,112), (w,56), (2w,28), (4w,14), (8w,7); the blocks
+    # with an identity shortcut take the bn1-folded form (fa_bn / ba_bn), the 4 projecting ones the plain filter
+    assert {(k[0][1], k[0][2]) for k in list(taps.fa) + list(taps.fa_bn)} == {(width, 112), (width, 56), (2 * width, 28),
+                                                                               (4 * width, 14), (8 * width, 7)}
+    assert set(taps.fa) == set(taps.ba) and set(taps.fa_bn) == set(taps.ba_bn) and len(taps.fa_bn) >= 4
+    def bn_taps_ref(r, eps):
+        x = r["x"].double().requires_grad_(True)
+        w, b, soft = (r[n].double().requires_grad_(True) for n in ("w", "b", "soft"))
+        a = F.relu(F.batch_norm(x, None, None, w, b, True, 0.0, eps))
+        a.retain_grad()
+        NT, C, H, W = a.shape
+        a5 = a.view(NT // r["S"], r["S"], C, H, W)
+        pad = torch.zeros_like(a5[:, :1])
+        s0, s1, s2 = (soft[:, j].view(1, 1, C, 1, 1) for j in range(3))
+        y = (s0 * torch.cat([pad, a5[:, :-1]], 1) + s1 * a5 + s2 * torch.cat([a5[:, 1:], pad], 1)).view(NT, C, H, W)
+        return x, w, b, soft, a, y
+
+    bar = 2.0 ** -6 if st == torch.bfloat16 else 1e-5
+    eps = float(net.backbone.layer0[0].bn1.eps)
+    for key, r in taps.fa_bn.items():                  # ---- bn1 + ReLU + temporal taps as one operator, against fp64 PyTorch
+        y = bn_taps_ref(r, r["eps"])[5].detach()
+        np.testing.assert_allclose(r["y"].double().numpy(), y.numpy(), rtol=0, atol=bar * float(y.abs().max()),
+                                   err_msg="bn1 + taps forward %s" % (key,))
+    for key, g in taps.ba_bn.items():
+        x, w, b, soft, a, y = bn_taps_ref(g, eps)
+        y.backward(g["gy"].double())
+        dx = x.grad + (g["dskip"].double() if g["dskip"] is not None else 0)
+        # d(x) = a (dz - k1 - xhat k2) cancels: its error scales with d(activation), which bf16 storage rounds (in the
+        # unfused kernels as well)
+        scale = max(float(dx.abs().max()), float(w.abs().max()) * float(a.grad.abs().max()) / float(x.detach().std()))
+        # (an element whose pre-activation rounds to the other side of 0 in fp32 than in fp64 takes the other ReLU branch:
+        # a handful per million)
+        off = (g["dx"].double() - dx).abs() > bar * scale
+        assert float(off.double().mean()) < 1e-5, "bn1 + taps d(x) %s: %d elements off" % (key, int(off.sum()))
+        for name, ref in (("dgamma", w.grad), ("dbeta", b.grad), ("gsoft", soft.grad)):
+            np.testing.assert_allclose(g[name].double().numpy(), ref.numpy(), rtol=0,
+                                       atol=(5e-3 if st == torch.bfloat16 else 1e-4) * float(ref.abs().max()),
+                                       err_msg="bn1 + taps %s %s" % (name, key))
     for key, r in taps.fa.items():                     # ---- AttentionShift taps, forward
         assert r["x"].dtype == st and r["soft"].dtype == torch.float32
         y_ref = ao.taps_forward(r["x"].float().numpy(), r["soft"].numpy(), r["S"])
