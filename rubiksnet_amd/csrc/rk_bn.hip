@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restri
     const double K = (double)p[0].x;
     const long long last_n = count - 128LL * (J - 1);
     double s1 = 0, s2 = 0;
-    for (int j = threadIdx.x; j < J; j += kFin) {
+    for (int j = threadIdx.x; j < J; j += (int)blockDim.x) {
         const float4 t = p[j];
         const double n = (j == J - 1) ? (double)last_n : 128.0;
         const double dp = (double)t.x - K;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restri
     __syncthreads();
     if (threadIdx.x == 0) {
         double S1 = 0, S2 = 0;
-        for (int w = 0; w < kFin / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        for (int w = 0; w < (int)blockDim.x / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
         const double M = (double)count;
         const double ms = S1 / M;
         double var = S2 / M - ms * ms;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kFin) void k_bn_bwd_finish_tiles(const float2* __re
     const int c = blockIdx.x;
     const float2* p = bred + (size_t)c * J;
     double s1 = 0, s2 = 0;
-    for (int j = threadIdx.x; j < J; j += kFin) {
+    for (int j = threadIdx.x; j < J; j += (int)blockDim.x) {
         const float2 t = p[j];
         s1 += (double)t.x;
         s2 += (double)t.y;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kFin) void k_bn_bwd_finish_tiles(const float2* __re
     __syncthreads();
     if (threadIdx.x == 0) {
         double S1 = 0, S2 = 0;
-        for (int w = 0; w < kFin / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        for (int w = 0; w < (int)blockDim.x / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
         dbeta[c] = (float)S1;
         dgamma[c] = (float)S2;
         k12[c] = (float)(S1 / (double)count);
@@ -610,8 +610,9 @@ int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, flo
                                int C, rk_stream_t stream) {
     if (!bred || !k12 || !dgamma || !dbeta) return RK_ERR_NULL_POINTER;
     if (C <= 0 || tiles <= 0 || count <= 0) return RK_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(k_bn_bwd_finish_tiles, dim3(C), dim3(kFin), 0, (hipStream_t)stream, (const float2*)bred, tiles,
-                       count, k12, dgamma, dbeta, C);
+    // (few tiles -- the per-clip partials of rk_tshift3_bn_backward: a single wave per channel)
+    hipLaunchKernelGGL(k_bn_bwd_finish_tiles, dim3(C), dim3(tiles <= 256 ? kWave : kFin), 0, (hipStream_t)stream,
+                       (const float2*)bred, tiles, count, k12, dgamma, dbeta, C);
     return launch_status();
 }
 // dx = gamma invstd (dz - k1 - xhat k2) (+ skip): dz already ReLU-masked, k12 from rk_bn_bwd_finish_tiles_f32

@@ -51,12 +51,21 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ A, int M, in
     const int lane = u & 63, rb = (u >> 6) % nrb, c = (u >> 6) / nrb;
     const int m = 16 * rb + (lane & 15), k0 = kCh * c + 8 * (lane >> 4);
     unsigned h[8];
+    if (mk && (K & 3) == 0 && m < M && k0 + 8 <= K) {              // 8 consecutive weights of a row: two 16-byte loads
+        const float4 q0 = *reinterpret_cast<const float4*>(A + (size_t)m * K + k0);
+        const float4 q1 = *reinterpret_cast<const float4*>(A + (size_t)m * K + k0 + 4);
+        h[0] = bf16_bits(q0.x); h[1] = bf16_bits(q0.y); h[2] = bf16_bits(q0.z); h[3] = bf16_bits(q0.w);
+        h[4] = bf16_bits(q1.x); h[5] = bf16_bits(q1.y); h[6] = bf16_bits(q1.z); h[7] = bf16_bits(q1.w);
+    } else {
+        float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + j;
-        const bool ok = m < M && k < K;
-        const float v = ok ? A[mk ? (size_t)m * K + k : (size_t)k * M + m] : 0.f;
-        h[j] = bf16_bits(v);
+        for (int j = 0; j < 8; ++j) {                              // all 8 requested before the first conversion
+            const int k = k0 + j;
+            const bool ok = m < M && k < K;
+            v[j] = ok ? A[mk ? (size_t)m * K + k : (size_t)k * M + m] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = bf16_bits(v[j]);
     }
     out[u] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
 }
