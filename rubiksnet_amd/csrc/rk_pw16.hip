@@ -6,7 +6,8 @@
 //   * forward / d(input) (k_pw16_gemm): a workgroup owns ALL rows of a 128-pixel column tile (up to 288 rows per
 //     workgroup: 144 accumulator registers per lane, 2 workgroups per CU), so X is read once (the first-generation
 //     kernel of rk_pw.hip re-read it once per 64-row tile, 5x at 288 rows).  X is streamed by LDS-DMA in its memory
-//     layout ([32 channels][128 pixels] per chunk, 16-byte units that never span frames), 3 chunks deep; the channel-major -> k-major transposition a bf16 MFMA operand needs happens in REGISTERS
+//     layout ([32 channels][128 pixels] per chunk, 16-byte units that never span frames), 3 chunks deep; the
+//     channel-major -> k-major transposition a bf16 MFMA operand needs happens in REGISTERS
 //     (8 ds_read_b64 + 16 v_perm_b32 per wave and chunk give the 4 B-fragments of a 64-pixel column group; no 2-byte
 //     LDS writes).  The small operand is pre-packed (k_pw16_pack, one launch per forward) into bf16 MFMA A-fragment
 //     order and moved 16 B per lane, one chunk ahead.  v_mfma_f32_16x16x32_bf16: 16-row blocks fit 72 / 144 / 288
