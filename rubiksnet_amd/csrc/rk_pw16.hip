@@ -35,7 +35,6 @@ constexpr int kXStage = (kCh / 4) * kXGroup;    // 8 704 B
 
 struct Dims {
     int F, K, M, P;
-    long long ntot;
     int nrb, nch;                          // 16-row blocks of the packed operand, 32-channel chunks
     int U;                                 // 16-byte units (8 pixels) per frame row: ceil(P / 8)
     long long nunits;                      // F * U
@@ -563,7 +562,7 @@ int rk_pw_gemm_packed_bf16(const void* Apk, const void* X_, const void* R_, void
     if (((uintptr_t)Apk & 15) || ((uintptr_t)X & 7) || ((uintptr_t)Y & 7) || (R && ((uintptr_t)R & 7))) return RK_ERR_BAD_DIMS;
     if ((long long)F * K * P * 2 >= (1ll << 31)) return RK_ERR_BAD_DIMS;             // 32-bit byte offsets in the DMA
     Dims d;
-    d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P;
+    d.F = F; d.K = K; d.M = M; d.P = P;
     d.nrb = (M + 15) / 16; d.nch = (K + kCh - 1) / kCh;
     d.U = (P + 7) / 8; d.nunits = (long long)F * d.U;
     hipStream_t stream = (hipStream_t)stream_;
