@@ -288,3 +288,21 @@ def test_fused_train_block_declines_what_it_cannot_run():
     assert train_block._shift_config(aq.backbone.layer1[1].as3) is None       # 2-D shift + AttentionShift: not this path
     assert train_block._shift_config(blk.as3) is not None
     assert train_block.take_stats(x, 54, x.numel() // 54) is None             # no producer attached statistics
+
+
+def test_bn_tshift_fusion_declines_off_device():
+    """bn_relu_tshift_skip (the -aq block's bn1 + ReLU inside its AttentionShift) applies to CUDA tensors in training only:
+    on the host, in eval mode or without gradients it returns None and the block takes bn_relu_skip + the module."""
+    import torch
+    import torch.nn as nn
+    from rubiksnet_amd.attention_shift import AttentionShift
+    from rubiksnet_amd.fused_bn import bn_relu_tshift_skip
+
+    bn, shift = nn.BatchNorm2d(6), AttentionShift(4, 6)
+    x = torch.randn(8, 6, 3, 3, requires_grad=True)
+    assert bn_relu_tshift_skip(bn, shift, x) is None                   # CPU tensor
+    bn.eval()
+    assert bn_relu_tshift_skip(bn, shift, x) is None                   # eval mode
+    with torch.no_grad():
+        assert bn_relu_tshift_skip(bn.train(), shift, x) is None       # no gradient wanted
+    assert bn_relu_tshift_skip(bn, AttentionShift(4), x) is None       # taps not created yet
