@@ -115,28 +115,49 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     }
     const char* xbase = uniform_bytes(reinterpret_cast<const char*>(X));
     const unsigned xs0 = dma::lds_byte_addr(Xs);
-    auto issue_x = [&](int c, int stage) {
+    // (per chunk the 4 byte offsets of a lane advance by 32 rows: kept in registers and bumped, the row clamp only where
+    // the last chunk is ragged -- recomputing them, with the 64-bit products, was 370 cycles per chunk on the critical path)
+    int xvo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int k = 16 * wave + 4 * i + (lane >> 4);
+        k = k < d.K ? k : d.K - 1;
+        xvo[i] = (int)(xoff0 + (long long)k * d.P * 2);
+    }
+    const int xstep = kCh * d.P * 2;                                // bytes per 32 channel rows
+    const bool k_ragged = (d.K & (kCh - 1)) != 0;
+    auto issue_x = [&](int c, int stage) {                          // (called with c = 0, 1, 2, ... in order)
         const unsigned dst = xs0 + (unsigned)(stage * kXStage + 4 * wave * kXGroup);
+        const bool clamp = k_ragged && c == d.nch - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int k = kCh * c + 16 * wave + 4 * i + (lane >> 4);
-            k = k < d.K ? k : d.K - 1;                               // rows past K: a valid row, masked at the read
-            const int voff = (int)(xoff0 + (long long)k * d.P * 2);
+            int voff = xvo[i];
+            if (clamp) {                                            // rows past K: a valid row, masked at the read
+                int k = kCh * c + 16 * wave + 4 * i + (lane >> 4);
+                k = k < d.K ? k : d.K - 1;
+                voff = (int)(xoff0 + (long long)k * d.P * 2);
+            }
             if (dma_ok) dma::dma16s<false>(xbase, voff, dst + (unsigned)(i * kXGroup));
+            xvo[i] += xstep;
         }
     };
     // A: ordinary 16-byte loads of the packed fragments by waves 2-3 (block w - 2, w, ... of the chunk's 2 RB), written to
     // LDS a chunk ahead.  NOT by LDS-DMA: a CU's DMA engine lands about 25 GB/s (MI355X_MICROARCH.md, ldsdma-fill), and
     // every workgroup re-reads the whole operand from L2 -- 2.2x the bytes of X at 288 rows; measured 19.7 -> see DESIGN.
     u32x4 areg[RB];
-    auto fetch_a = [&](int c) {
-        const u32x4* src0 = reinterpret_cast<const u32x4*>(Apk + (size_t)c * d.nrb * 1024) + lane;
+    int ablk[RB];                                                   // 16-byte index of this lane's piece of block b
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            int blk = rb0 + (wave & 1) + 2 * b;
-            blk = blk < d.nrb ? blk : d.nrb - 1;                     // (blocks past the operand: a copy, never multiplied)
-            areg[b] = src0[(size_t)blk * 64];
-        }
+    for (int b = 0; b < RB; ++b) {
+        int blk = rb0 + (wave & 1) + 2 * b;
+        blk = blk < d.nrb ? blk : d.nrb - 1;                        // (blocks past the operand: a copy, never multiplied)
+        ablk[b] = blk * 64 + lane;
+    }
+    const u32x4* asrc = reinterpret_cast<const u32x4*>(Apk);
+    const int astep = d.nrb * 64;                                   // 16-byte pieces per chunk of the packed operand
+    auto fetch_a = [&](int c) {
+        const u32x4* src0 = asrc + (size_t)c * astep;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) areg[b] = src0[ablk[b]];
     };
     auto deposit_a = [&](int stage) {
         u32x4* dst0 = reinterpret_cast<u32x4*>(As + stage * kAStage) + lane;
