@@ -217,6 +217,59 @@ def test_bf16_strided_shortcut(monkeypatch, case):
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=1e-5 * float(wr.grad.abs().max()))
 
 
+def test_pw16_randomised_shapes():
+    """Seeded sweep over (frames, channels in / out, plane) for the bf16 GEMM (+ residual, d(input)) and d(weight) kernels:
+    odd channel counts, planes with P % 8 == 4 and P % 8 == 0, tiles ending inside frames, more rows than one workgroup
+    takes.  RK_SWEEP_PW16 sets the number of draws (default 40)."""
+    import os
+    from rubiksnet_amd import _native
+
+    L = _native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(20260929)
+    draws = int(os.environ.get("RK_SWEEP_PW16", "40"))
+    for it in range(draws):
+        Fr = int(rng.integers(1, 24))
+        K, M = int(rng.integers(1, 330)), int(rng.integers(1, 330))
+        if it % 7 == 0:
+            M = int(rng.integers(300, 620))
+        H, W = int(rng.integers(1, 15)), 4 * int(rng.integers(1, 8))
+        if rng.integers(0, 2):
+            H, W = W, H
+        P = H * W
+        if P < 8 or P % 4:
+            continue
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(Fr, K, P, generator=g).bfloat16()
+        r = torch.randn(Fr, M, P, generator=g).bfloat16()
+        w = torch.randn(M, K, generator=g) / K ** 0.5
+        wq = w.bfloat16().double()
+        xd, rd, wd = x.cuda(), r.cuda(), w.cuda()
+        fwd = torch.empty(int(L.rk_pw_packed_bytes(M, K)), dtype=torch.uint8, device="cuda")
+        bwd = torch.empty(int(L.rk_pw_packed_bytes(K, M)), dtype=torch.uint8, device="cuda")
+        _native.check(L.rk_pw_pack_bf16(wd.data_ptr(), M, K, fwd.data_ptr(), bwd.data_ptr(), st), "pack")
+        tag = "draw %d: F %d K %d M %d plane %dx%d" % (it, Fr, K, M, H, W)
+
+        def close(got, ref, what):
+            err = (got.double().cpu() - ref).abs()
+            bound = ref.abs() * 2.0 ** -8 + 1e-5 * float(ref.abs().max())
+            assert bool((err <= bound).all()), "%s %s: %g" % (tag, what, float((err - bound).max()))
+
+        y = torch.full((Fr, M, P), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _native.check(L.rk_pw_gemm_packed_bf16(fwd.data_ptr(), xd.data_ptr(), rd.data_ptr(), y.data_ptr(), Fr, K, M, P, st), tag)
+        close(y, torch.einsum("mk,fkp->fmp", wq, x.double()) + r.double(), "forward + residual")
+        dx = torch.full((Fr, K, P), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _native.check(L.rk_pw_gemm_packed_bf16(bwd.data_ptr(), rd.data_ptr(), None, dx.data_ptr(), Fr, M, K, P, st), tag)
+        close(dx, torch.einsum("mk,fmp->fkp", wq, r.double()), "d(input)")
+        nb = int(L.rk_pw_wgrad16_workspace_bytes(Fr, K, M, P))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        dw = torch.full((M, K), float("nan"), device="cuda")
+        _native.check(L.rk_pw_wgrad16_bf16(rd.data_ptr(), xd.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, st), tag)
+        ref = torch.einsum("fmp,fkp->mk", r.double(), x.double())
+        np.testing.assert_allclose(dw.double().cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()) + 1e-12,
+                                   err_msg=tag + " d(weight)")
+
+
 def test_packed_weight_follows_the_parameter(monkeypatch):
     """The packed copy of a weight is made per forward: in-place edits are seen, also those made through `.data` (which no
     version counter records)."""
