@@ -211,3 +211,46 @@ def test_bn_relu_folded_into_the_temporal_filter(dtype, shape):
     tol = 2e-5 if dtype == torch.float32 else 2.0 ** -6        # bf16: the unfused pair rounds the activation and d(activation) once more
     for name, a, b in zip(("y", "dx", "dgamma", "dbeta", "dtaps", "running_mean", "running_var"), f[:7], u[:7]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=tol * max(1e-3, float(b.abs().max())), err_msg=name)
+
+
+@pytest.mark.gpu
+def test_bn_relu_temporal_filter_randomised_shapes():
+    """Seeded sweep of bn_relu_tshift_skip against fp64 PyTorch (batch-norm, ReLU, 3-tap temporal filter, autograd): every
+    vector width of the filter kernels (H*W odd, % 2, % 4, % 8), n_segment 1 .. 8, fp32 and bf16."""
+    import os
+    from rubiksnet_amd.attention_shift import AttentionShift
+    from rubiksnet_amd.fused_bn import bn_relu_tshift_skip
+
+    rng = np.random.default_rng(7)
+    for it in range(int(os.environ.get("RK_SWEEP_BNT", "24"))):
+        S = int(rng.integers(1, 9))
+        NT, C = S * int(rng.integers(1, 5)), int(rng.integers(1, 40))
+        H, W = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        dtype = torch.bfloat16 if it % 2 else torch.float32
+        torch.manual_seed(it)
+        bn = nn.BatchNorm2d(C).cuda().train()
+        shift = AttentionShift(S, C).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        x = (torch.randn(NT, C, H, W, device="cuda") * 1.5 + 0.3).to(dtype).requires_grad_(True)
+        gy = torch.randn(NT, C, H, W, device="cuda").to(dtype)
+        if NT * H * W < 2:
+            continue
+        r = bn_relu_tshift_skip(bn, shift, x)
+        assert r is not None
+        (r[0].float() * gy.float()).sum().backward()
+        soft = shift.soft_taps().detach().double().cpu()
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        w, b = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+        a = F.relu(F.batch_norm(x64, None, None, w, b, True, 0.0, bn.eps))
+        a5 = a.view(NT // S, S, C, H, W)
+        pad = torch.zeros_like(a5[:, :1])
+        s0, s1, s2 = (soft[:, j].view(1, 1, C, 1, 1) for j in range(3))
+        y = (s0 * torch.cat([pad, a5[:, :-1]], 1) + s1 * a5 + s2 * torch.cat([a5[:, 1:], pad], 1)).view(NT, C, H, W)
+        y.backward(gy.double().cpu())
+        tag = "draw %d: NT %d S %d C %d plane %dx%d %s" % (it, NT, S, C, H, W, dtype)
+        bar = 2.0 ** -6 if dtype == torch.bfloat16 else 2e-5
+        for name, got, ref in (("y", r[0].detach(), y.detach()), ("dx", x.grad, x64.grad), ("dgamma", bn.weight.grad, w.grad),
+                               ("dbeta", bn.bias.grad, b.grad)):
+            np.testing.assert_allclose(got.double().cpu().numpy(), ref.numpy(), rtol=0, atol=bar * max(1e-3, float(ref.abs().max())),
+                                       err_msg=tag + " " + name)
