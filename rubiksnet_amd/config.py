@@ -4,7 +4,8 @@
     RK_PW          auto | 0 | all 1x1 convolutions on the HIP MFMA GEMM wherever it can run / never / (same as auto)
     RK_FUSED_EVAL  1 | 0          inference blocks with BN + residual folded into the two GEMMs / layer by layer
     RK_FUSED_TRAIN 1 | 0          training blocks as one autograd node with the BatchNorm statistics / normalisation / backward
-                                  reduction folded into the 1x1 GEMMs (train_block.py) / layer by layer
+                                  reduction folded into the 1x1 GEMMs (train_block.py), -aq blocks' bn1 + ReLU inside the
+                                  temporal filter (fused_bn.bn_relu_tshift_skip) / layer by layer
     RK_WGRAD_OVERLAP 1 | 0        the d(weight) kernels of a fused training block on a second HIP stream, next to the
                                   streaming kernels of the same backward / on the current stream
     RK_F1          0 | 1          inference blocks: shift kernel, then the conv3 GEMM / the 3-D shift inside conv3's operand
