@@ -289,12 +289,6 @@ int rk_pw_wgrad16_bf16(const void* dY, const void* X, float* dW, int F, int K, i
  *                   pro: x' = relu?(ka[k] x + kb[k]) per input channel  (relu(bn1(x)) feeding conv2, backbone.py:129-131)
  *                   epi: y  = relu?(ma[m] y + mb[m]) per output channel (relu(bn2(conv2(.))), BatchNorm in eval mode:
  *                   a = gamma / sqrt(running_var + eps), b = beta - running_mean * a).  NULL pairs switch a stage off. */
-/* SURVEY 8(f) f1 (inference): Y[f] = A RubiksShift3D(X)[f] (+ R[f]) -- the conv3 of a block (backbone.py:133) fed by its
- * as3 shift (:132), the shift's gather done in the GEMM's operand load so that the shifted activation is never stored.
- * X [NT, K, H, W] (NT = clips * T frames), shift [3][K] (rows T, H, W), stride 1 / pad 0, no quantize, W % 4 == 0;
- * bit-identical to rk3d_forward_f32 followed by rk_pw_gemm_f32. */
-int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, const float* R, float* Y, int NT, int T,
-                           int K, int M, int H, int W, rk_stream_t stream);
 /* eval-mode BatchNorm2d folded to y = a x + b per channel (a = gamma / sqrt(running_var + eps), b = beta -
  * running_mean a): the (ka, kb) / (ma, mb) arrays of the fused entry points below, in one launch. */
 int rk_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
@@ -385,6 +379,19 @@ int rk3d_backward_bn_f32(const float* z, const float* abmi, const float* shift, 
                          int stride_H, int stride_W, int pad_T, int pad_H, int pad_W, int normalize_grad, float t_factor,
                          int quantize, void* workspace, size_t workspace_bytes, rk_stream_t stream);
 int rk_pw_tiles(int F, int P);
+/* tiles of the training epilogues of ONE rk_pw_gemm_stats_f32 / rk_pw_gemm_bnbwd_f32 call with these arguments: the
+ * second-generation fp32 kernels (rk_pw2.hip: v_mfma_f32_16x16x4_f32, no LDS) write one partial per 64 columns, the first
+ * generation one per 128; rk_bn_finish_tiles_f32 tells the two apart from (tiles, count). */
+int rk_pw_gemm_tiles(const float* A, int F, int K, int M, int P, int a_is_mk);
+/* tuning / test hooks of the second-generation fp32 1x1 kernels: the operations of rk_pw_gemm_fused_f32 (prologue only) and
+ * rk_pw_wgrad_pro_f32 with the kernel configuration given explicitly (<= 0 / < 0: the planner's choice).  rb: 16-row blocks
+ * per wave (3, 4, 5); amode: 0 = A [M][K] by 16-byte loads, 1 = A [K][M] by dword loads, 2 = LDS image; inst: d(weight)
+ * tile instance (rk_pw2.hip kWInst), stages: LDS ring depth (2, 3), splits: pixel splits.  RK_ERR_UNSUPPORTED: no instance. */
+int rk_pw2_gemm_cfg_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P, int a_is_mk,
+                        const float* ka, const float* kb, int relu_in, int rb, int amode, int ct, rk_stream_t stream);
+size_t rk_pw2_wgrad_workspace_bytes(int F, int K, int M, int P);
+int rk_pw2_wgrad_cfg_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
+                         const float* ka, const float* kb, int relu_in, int inst, int stages, int splits, rk_stream_t stream);
 int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, void* stats, int tiles,
                          rk_stream_t stream);

@@ -56,10 +56,13 @@ SIGNATURES = {
     "rk_pw_s2_forward_fused_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "rk_pw_s2_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_s2_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
-    "rk_pw_gemm_shift3d_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "rk_bn_fold_f32": (_i, [_p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _p]),
     "rk_pw_gemm_fused_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "rk_pw_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    # second-generation fp32 kernels (rk_pw2.hip): tuning / test hooks with an explicit kernel configuration
+    "rk_pw2_gemm_cfg_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_pw2_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_pw2_wgrad_cfg_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p, _p, _i, _i, _i, _i, _p]),
     "rk_pw_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_pw_wgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     # planes with H * W % 4 != 0 (7x7)
@@ -74,6 +77,7 @@ SIGNATURES = {
     "rk3d_backward_bn_workspace_bytes": (_sz, _DIMS3),
     "rk3d_backward_bn_f32": (_i, [_p] * 9 + _DIMS3 + [_i, ctypes.c_float, _i, _p, _sz, _p]),
     "rk_pw_tiles": (_i, [_i, _i]),
+    "rk_pw_gemm_tiles": (_i, [_p, _i, _i, _i, _i, _i]),
     "rk_pw_gemm_stats_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p]),
     "rk_stem_conv3x3s2_stats_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "rk_pw_gemm_bnbwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p]),

@@ -8,13 +8,11 @@
                                   temporal filter (fused_bn.bn_relu_tshift_skip) / layer by layer
     RK_WGRAD_OVERLAP 1 | 0        the d(weight) kernels of a fused training block on a second HIP stream, next to the
                                   streaming kernels of the same backward / on the current stream
-    RK_F1          0 | 1          inference blocks: shift kernel, then the conv3 GEMM / the 3-D shift inside conv3's operand
-                                  load (gather form: bit-identical, never stores the shifted activation,
-                                  but 1.7x slower than the two kernels -- DESIGN 7 -- hence off)
 
 Everything else that used to be tunable from the environment (tile shapes, channel limits, prefetch depths)
 is a constant next to the code it tunes.  The native library has one switch of its own, RK_SHIFT_KERNELS
-(include/rubiks_hip.h).  Tests flip switches with `config.reload()` after changing os.environ.
+(include/rubiks_hip.h), and RK_PW2 = 1 | 0 | 2 (second-generation fp32 1x1 kernels where they are ahead /
+never / wherever they can run).  Tests flip switches with `config.reload()` after changing os.environ.
 """
 import dataclasses
 import os
@@ -27,7 +25,6 @@ class Switches:
     fused_bn: bool = True
     pointwise: str = "auto"          # "auto" | "0" | "all"
     fused_eval: bool = True
-    fused_shift_gemm: bool = False
     fused_train: bool = True
     wgrad_overlap: bool = True
 
@@ -39,7 +36,6 @@ class Switches:
             raise ValueError("RK_PW must be auto, 0 or all (got %r)" % pw)
         return Switches(fused_bn=env.get("RK_FUSED_BN", "1") != "0", pointwise=pw,
                         fused_eval=env.get("RK_FUSED_EVAL", "1") != "0",
-                        fused_shift_gemm=env.get("RK_F1", "0") == "1",
                         fused_train=env.get("RK_FUSED_TRAIN", "1") != "0",
                         wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0")
 

@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "rk_common.hpp"
 #include "rk3d_generic.hpp"
+#include "rk_pw2.hpp"
 
 namespace rk {
 namespace pw {
@@ -57,8 +58,6 @@ struct PwDims {
     int a_is_mk;            // A given as [M][K] row-major (the weight itself), else [K][M]
     int Cin, Hin, Win, Wo;  // STEM mode only: 3x3 / stride 2 / pad 1 convolution, K = 9 Cin, P = Ho * Wo
     int WM, WN;             // waves along M / along N (WM * WN = 4); workgroup tile = 64 WM rows x 128 WN columns
-    const float* shift;     // SHIFT mode only: RubiksShift3D table [3][K]; frames are (n, t), t < T; plane Hin x Win
-    int T;
 };
 
 
@@ -157,12 +156,7 @@ struct AStage {
 // S2 = 2: d(input) of that convolution: the result block of output pixel (ho, wo..wo+3) is scattered to the input-
 // sized tensor at (2 ho, 2 wo ..) with zeros in between and in row 2 ho + 1 (four 16-byte stores, every element of
 // d(input) written once: no memset).
-// SHIFT (inference): the streamed operand is RubiksShift3D(X) (stride 1 / pad 0, W % 4 == 0) computed
-// on the fly -- a lane's 4 consecutive pixels of channel k come from 2 planes x 2 rows x 5 columns of X through the
-// reference's trilinear tree (rk3d_generic.hpp trilerp, contraction off), so the B fragments are bit-identical to what
-// the shift kernels would have written and Y is bit-identical to "shift, then this GEMM"; the shifted activation is
-// never stored.
-template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0, bool SHIFT = false, int EPI = 0>
+template <typename T, int WM, int kKC, bool FUSE, bool STEM = false, int S2 = 0, int EPI = 0>
 __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ? 1 : 2)) void k_pw_gemm(const float* __restrict__ A, const T* __restrict__ X,
                                                     const T* __restrict__ R, T* __restrict__ Y, PwDims d, PwFuse fz,
                                                     PwTrain tr) {
@@ -208,8 +202,6 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             s2o[q] = (2 * hq - 2 * s_ho) * d.Win + 2 * wq - 2 * s_wo;
         }
     }
-    const int sh_h = SHIFT ? p / d.Win : 0, sh_w = SHIFT ? p - sh_h * d.Win : 0;              // SHIFT: (h, w) of pixel 0
-    const int sh_n = SHIFT ? f / d.T : 0, sh_t = SHIFT ? f - sh_n * d.T : 0;
     auto load_b = [&](int k) -> Raw {
         if constexpr (STEM && std::is_same<T, float>::value) {
             const int ci = k / 9, r9 = k - 9 * ci, kh3 = r9 / 3, kw3 = r9 - 3 * kh3;
@@ -222,32 +214,6 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             v.z = ok ? row[wi + 4] : 0.f;
             v.w = ok ? row[wi + 6] : 0.f;
             return v;
-        } else if constexpr (SHIFT && std::is_same<T, float>::value) {
-            if (!(valid && k < d.K)) return make_float4(0.f, 0.f, 0.f, 0.f);
-            const Frac<float> fT = split_shift(d.shift[k]), fH = split_shift(d.shift[d.K + k]),
-                              fW = split_shift(d.shift[2 * d.K + k]);
-            const int t0 = sh_t + fT.fl, h0 = sh_h + fH.fl, w0 = sh_w + fW.fl;
-            float v[2][2][5];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool vt = t0 + j >= 0 && t0 + j < d.T;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool vh = vt && h0 + i >= 0 && h0 + i < d.Hin;
-                    const float* row = X + (((size_t)(sh_n * d.T + (vt ? t0 + j : 0)) * d.K + k) * d.Hin + (vh ? h0 + i : 0)) * d.Win;
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const int w = w0 + c;
-                        v[j][i][c] = (vh && w >= 0 && w < d.Win) ? row[w] : 0.f;
-                    }
-                }
-            }
-            float o[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                o[q] = trilerp(v[0][0][q], v[0][0][q + 1], v[0][1][q], v[0][1][q + 1], v[1][0][q], v[1][0][q + 1],
-                               v[1][1][q], v[1][1][q + 1], fT.r, fH.r, fW.r);
-            return make_float4(o[0], o[1], o[2], o[3]);
         } else if constexpr (S2 == 1 && std::is_same<T, float>::value) {
             const bool ok = valid && k < d.K;
             const float* row = X + (((size_t)f * d.K + (ok ? k : 0)) * d.Hin + 2 * s_ho) * d.Win + 2 * s_wo;
@@ -1388,9 +1354,23 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if (R && ((uintptr_t)R & am)) return RK_ERR_BAD_DIMS;
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0 || K % 2 != 0) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)X & am) || ((uintptr_t)Y & am)) return RK_ERR_BAD_DIMS;
+    if constexpr (std::is_same<T, float>::value) {
+        // second generation (rk_pw2.hip) where it is ahead; its training epilogues use 64-column tiles
+        // (rk_pw_gemm_tiles() tells the caller which count to allocate)
+        if (pw2::gemm_wanted(K, M, P, a_is_mk, A)) {
+            const pw2::GFuse f2 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, fuse->ma, fuse->mb, fuse->relu_in, fuse->relu_out}
+                                       : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
+            const pw2::GTrain t2 = train ? pw2::GTrain{train->stats, train->bred, train->bx, train->bpack, train->J}
+                                         : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};
+            if (epi && (long long)t2.J != ((long long)F * P + pw2::kTileCols - 1) / pw2::kTileCols) return RK_ERR_BAD_DIMS;
+            const int rc = pw2::gemm(A, X, R, Y, F, K, M, P, a_is_mk, &f2, &t2, epi, (hipStream_t)stream_, nullptr);
+            if (rc != RK_ERR_UNSUPPORTED) return rc;
+            if (epi) return rc;                              // (the tile count was promised for this generation)
+        }
+    }
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
-    d.Cin = d.Hin = d.Win = d.Wo = 0; d.shift = nullptr; d.T = 0;
+    d.Cin = d.Hin = d.Win = d.Wo = 0;
     // rows per workgroup tile = 64 wm.  Above 128 rows 64-row tiles win although the streamed operand is then
     // re-read once per tile (L2 / Infinity Cache absorb it; 288 rows: 101 us against 141 / 179 us with 128 / 256-row
     // tiles, which also pad 288 to 384 / 512)
@@ -1421,9 +1401,9 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if constexpr (std::is_same<T, float>::value) {
         if (epi) {                                           // training epilogues (fp32): statistics of Y / BN-backward sums
             if (epi == 1 ? !tr.stats : !(tr.bred && tr.bx && tr.bpack)) return RK_ERR_NULL_POINTER;
-            if (fz.ma || (long long)tr.J * 128 < d.ntot) return RK_ERR_BAD_DIMS;
+            if (fz.ma || (long long)tr.J != (d.ntot + 127) / 128) return RK_ERR_BAD_DIMS;
             if (epi == 2 && (((uintptr_t)tr.bx & am) || ((uintptr_t)tr.bpack & 15))) return RK_ERR_BAD_DIMS;
-#define RK_PW_EP(WMV, KCV, FU, EP) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, FU, false, 0, false, EP>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
+#define RK_PW_EP(WMV, KCV, FU, EP) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, FU, false, 0, EP>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
 #define RK_PW_EK(WMV, FU, EP) do { if (kc == 12) RK_PW_EP(WMV, 12, FU, EP); else RK_PW_EP(WMV, 16, FU, EP); } while (0)
 #define RK_PW_EW(FU, EP) do { if (wm == 1) RK_PW_EK(1, FU, EP); else RK_PW_EK(2, FU, EP); } while (0)
             if (epi == 1) { if (fused) RK_PW_EW(true, 1); else RK_PW_EW(false, 1); }
@@ -1450,6 +1430,13 @@ int pw_wgrad(const void* dY_, const void* X_, float* dW, int F, int K, int M, in
              rk_stream_t stream_, const float* ka = nullptr, const float* kb = nullptr, int relu_in = 0) {
     const T* dY = (const T*)dY_; const T* X = (const T*)X_;
     if (!dY || !X || !dW) return RK_ERR_NULL_POINTER;
+    if constexpr (std::is_same<T, float>::value) {
+        if (pw2::wgrad_wanted(P) && F > 0 && K > 0 && M > 0) {         // second generation: LDS-DMA stages, 16 x 16 x 4 MFMA
+            const int rc = pw2::wgrad((const float*)dY_, (const float*)X_, dW, F, K, M, P, ws, ws_bytes, ka, kb, relu_in,
+                                      (hipStream_t)stream_, nullptr);
+            if (rc != RK_ERR_UNSUPPORTED) return rc;
+        }
+    }
     WgDims d;
     // the wide (shared-tile) kernel for > 64 channels; bf16 activations keep the bf16-MFMA kernel
     const bool wide = use_wide(M, K) && !std::is_same<T, __hip_bfloat16>::value;
@@ -1493,7 +1480,9 @@ extern "C" {
 size_t rk_pw_wgrad_workspace_bytes(int F, int K, int M, int P) {
     WgDims d, w;
     if (make_wg(d, F, K, M, P) || make_wg_wide(w, F, K, M, P)) return 0;
-    return (size_t)((d.S > w.S ? d.S : w.S) + kRed) * M * K * sizeof(float);      // whichever kernel is chosen
+    const size_t v1 = (size_t)((d.S > w.S ? d.S : w.S) + kRed) * M * K * sizeof(float);      // whichever kernel is chosen
+    const size_t v2 = pw2::wgrad_workspace_bytes(F, K, M, P);
+    return v1 > v2 ? v1 : v2;
 }
 
 // Y[f] = A X[f] (+ R[f]).  a_is_mk != 0: A is [M][K] row-major; else [K][M] (always fp32).  X [F,K,P], Y / R [F,M,P]
@@ -1514,7 +1503,7 @@ static int stem_conv(const float* W, const float* X, float* Y, int F, int Cin, i
     if (F <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || Hin % 2 || Win % 8 || 9 * Cin > 64) return RK_ERR_BAD_DIMS;
     if ((uintptr_t)Y & 15) return RK_ERR_BAD_DIMS;
     PwDims d;
-    d.F = F; d.K = 9 * Cin; d.M = Cout; d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0;
+    d.F = F; d.K = 9 * Cin; d.M = Cout; d.Cin = Cin; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
     d.P = (Hin / 2) * d.Wo; d.ntot = (long long)F * d.P; d.a_is_mk = 1;
     const int wm = Cout <= 64 ? 1 : (Cout <= 128 ? 2 : 4);
     d.WM = wm; d.WN = 4 / wm;
@@ -1526,8 +1515,8 @@ static int stem_conv(const float* W, const float* X, float* Y, int F, int Cin, i
     if (stats) {                                          // + the statistics of Y for the first block's bn1 (PwTrain)
         if ((long long)J * 128 < d.ntot) return RK_ERR_BAD_DIMS;
         const PwTrain tr{stats, nullptr, nullptr, nullptr, J};
-        if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true, 0, false, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
-        else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true, 0, false, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
+        if (wm == 1) hipLaunchKernelGGL((k_pw_gemm<float, 1, 16, false, true, 0, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
+        else if (wm == 2) hipLaunchKernelGGL((k_pw_gemm<float, 2, 12, false, true, 0, 1>), grid, block, 0, stream, W, X, R, Y, d, fz, tr);
         else return RK_ERR_BAD_DIMS;
         return launch_status();
     }
@@ -1585,7 +1574,7 @@ static int pw_s2(const float* A, const float* X, float* Y, int F, int K, int M, 
     if (((Hin / 2) * (Win / 2)) % 4) return RK_ERR_BAD_DIMS;          // output planes of whole 4-pixel groups (Win % 8 == 0: one row each)
     if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15)) return RK_ERR_BAD_DIMS;
     PwDims d;
-    d.F = F; d.K = K; d.M = M; d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0;
+    d.F = F; d.K = K; d.M = M; d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2;
     d.P = (Hin / 2) * d.Wo; d.ntot = (long long)F * d.P; d.a_is_mk = a_is_mk;
     const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
     d.WM = wm; d.WN = 4 / wm;
@@ -1656,31 +1645,6 @@ int rk_pw_s2_wgrad_pro_f32(const float* dY, const float* X, float* dW, int F, in
     if (!ka || !kb) return RK_ERR_NULL_POINTER;
     return pw_s2_wgrad(dY, X, dW, F, Cin, Cout, Hin, Win, ws, ws_bytes, stream, ka, kb, relu_in);
 }
-// SURVEY 8(f) f1, inference: Y[f] = A RubiksShift3D(X)[f] (+ R[f]) with the shift (stride 1 / pad 0, no quantize) applied
-// in the operand load -- the conv3 of a block fed by its as3 shift, plus the residual.  X [N*T, K, H, W], shift [3][K],
-// W % 4 == 0, K even; bit-identical to rk3d_forward_f32 followed by rk_pw_gemm_f32.
-int rk_pw_gemm_shift3d_f32(const float* A, const float* X, const float* shift, const float* R, float* Y, int NT, int T,
-                           int K, int M, int H, int W, rk_stream_t stream_) {
-    if (!A || !X || !shift || !Y) return RK_ERR_NULL_POINTER;
-    if (NT <= 0 || T <= 0 || NT % T || K <= 0 || M <= 0 || H <= 0 || W <= 0 || W % 4 || K % 2) return RK_ERR_BAD_DIMS;
-    if (((uintptr_t)Y & 15) || (R && ((uintptr_t)R & 15))) return RK_ERR_BAD_DIMS;
-    PwDims d;
-    d.F = NT; d.K = K; d.M = M; d.P = H * W; d.ntot = (long long)NT * d.P; d.a_is_mk = 1;
-    d.Cin = 0; d.Hin = H; d.Win = W; d.Wo = 0; d.shift = shift; d.T = T;
-    const int wm = M <= 64 ? 1 : (M <= 128 ? 2 : 1);
-    d.WM = wm; d.WN = 4 / wm;
-    const int mt = 64 * wm;
-    const dim3 grid((unsigned)((d.ntot + 128 * d.WN - 1) / (128 * d.WN)), (unsigned)((M + mt - 1) / mt)), block(kBlock);
-    hipStream_t stream = (hipStream_t)stream_;
-    const PwFuse fz{nullptr, nullptr, nullptr, nullptr, 0, 0};
-    const int kc = ((K + 11) / 12 * 12 <= (K + 15) / 16 * 16) ? 12 : 16;       // the plain GEMM's choice: same k order
-    const PwTrain tr{nullptr, nullptr, nullptr, nullptr, 0};
-#define RK_SH_GO(WMV, KCV) hipLaunchKernelGGL((k_pw_gemm<float, WMV, KCV, false, false, 0, true>), grid, block, 0, stream, A, X, R, Y, d, fz, tr)
-    if (wm == 1) { if (kc == 12) RK_SH_GO(1, 12); else RK_SH_GO(1, 16); }
-    else { if (kc == 12) RK_SH_GO(2, 12); else RK_SH_GO(2, 16); }
-#undef RK_SH_GO
-    return launch_status();
-}
 int rk_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                    float* a, float* b, int C, rk_stream_t stream) {
     if (!gamma || !beta || !running_mean || !running_var || !a || !b) return RK_ERR_NULL_POINTER;
@@ -1706,7 +1670,7 @@ static int pw_gemm_odd(const float* A, const float* X, const float* R, float* Y,
     if (mode == 0 && (K % 4 || ((uintptr_t)X & 15))) return RK_ERR_BAD_DIMS;            // aligned frame chunks
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;
-    d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.shift = nullptr; d.T = 0; d.WM = 1; d.WN = 4;
+    d.Cin = 0; d.Hin = Hin; d.Win = Win; d.Wo = Win / 2; d.WM = 1; d.WN = 4;
     constexpr int NCB = 1, kFr = 6;                          // 128 columns per workgroup (k_pw_gemm_odd)
     const size_t lds = (size_t)(2 * kOddKC * 64 + 2 * kFr * kOddKC * P) * sizeof(float);      // <= 57 KB at P = 64
     const dim3 grid((unsigned)((d.ntot + 128 * NCB - 1) / (128 * NCB)), (unsigned)((M + 63) / 64)), block(kBlock);
@@ -1783,6 +1747,13 @@ int rk_pw_s2_wgrad_odd_f32(const float* dY, const float* X, float* dW, int F, in
 int rk_pw_tiles(int F, int P) {
     if (F <= 0 || P <= 0) return 0;
     return (int)(((long long)F * P + 127) / 128);
+}
+// tile count of the training epilogues of ONE GEMM call (rk_pw_gemm_stats_f32 / rk_pw_gemm_bnbwd_f32 with these
+// arguments): the second-generation kernels (rk_pw2.hip) write one partial per 64 columns, the first per 128.
+int rk_pw_gemm_tiles(const float* A, int F, int K, int M, int P, int a_is_mk) {
+    if (F <= 0 || P <= 0 || K <= 0 || M <= 0) return 0;
+    const int w = pw2::gemm_wanted(K, M, P, a_is_mk, A) ? pw2::kTileCols : 128;
+    return (int)(((long long)F * P + w - 1) / w);
 }
 // forward of a block's conv2 / conv3 in training: Y[f] = A relu?(ka x + kb)(X[f]) (+ R[f]), and the tile statistics of Y
 // (float4 [M][tiles]) for the BatchNorm that consumes Y.  ka / kb NULL: no prologue.

@@ -20,7 +20,6 @@ from . import _native, config
 _S2_CMAX = 320              # 1x1 / stride-2 shortcuts (fp32)
 _FUSED_EVAL_CMAX = 320      # inference fusion: channel limit of rk_pw_gemm_fused_f32's register tile
 _FUSED_EVAL_PMIN = 196      # ... and smallest plane it pays for
-_F1_WMIN = 28               # shift-in-GEMM (f1): smallest plane width it is used for
 
 __all__ = ["conv1x1", "stem_conv", "pointwise_mode", "fused_eval_block", "all_frozen"]
 
@@ -451,32 +450,6 @@ def _eval_bn(bn):
             and bn.running_mean is not None and bn.weight.dtype == torch.float32)
 
 
-def _gemm_shift3d(conv, x, as3, residual):
-    """conv(as3(x)) + residual in ONE launch when `as3` is the 3-D shift wrapper (stride 1 / pad 0, no quantize, fp32
-    table, W % 4 == 0): SURVEY 8(f) f1 -- the gather of the shift runs in the GEMM's operand load and the shifted
-    activation is never written.  None when the layer does not qualify."""
-    shift3d = getattr(as3, "rubiks3d", None)
-    n_segment = getattr(as3, "n_segment", None)
-    if shift3d is None or n_segment is None or not config.switches().fused_shift_gemm:
-        return None
-    Fr, Cin, H, W = x.shape
-    one = lambda v, k: tuple(int(e) for e in ((v,) * k if isinstance(v, int) else v))      # noqa: E731
-    if (one(shift3d.stride, 3) != (1, 1, 1) or one(shift3d.padding, 3) != (0, 0, 0) or shift3d.quantize
-            or shift3d.shift.dtype != torch.float32 or tuple(shift3d.shift.shape) != (3, Cin)
-            or W % 4 or Fr % n_segment or W < _F1_WMIN):
-        return None
-    Cout = conv.out_channels
-    y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
-    dev = x.device
-    shift = shift3d.shift.detach().contiguous()
-    with torch.cuda.device(dev):
-        rc = _native.lib().rk_pw_gemm_shift3d_f32(
-            conv.weight.data_ptr(), x.data_ptr(), shift.data_ptr(), residual.data_ptr() if residual is not None else None,
-            y.data_ptr(), Fr, n_segment, Cin, Cout, H, W, torch.cuda.current_stream(dev).cuda_stream)
-    _native.check(rc, "rk_pw_gemm_shift3d_f32")
-    return y
-
-
 def _strided_shortcut_ok(conv, x):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
@@ -596,9 +569,6 @@ def fused_eval_block(block, x):
     else:
         shortcut = _gemm_fused(block.shortcut, x, pro=pro)
     mid = _gemm_fused(block.conv2, x, pro=pro, epi=_bn_affine(block.bn2))
-    fused = _gemm_shift3d(block.conv3, mid, block.as3, shortcut)      # f1: the shift inside conv3's operand load
-    if fused is not None:
-        return fused
     mid = block.as3(mid)
     return _gemm_fused(block.conv3, mid.contiguous(), residual=shortcut)
 

@@ -58,8 +58,9 @@ def take_stats(x, channels, count):
     st = getattr(x, "_rk_stats", None)
     if st is None:
         return None
-    tiles = (count + 127) // 128
-    if st.shape != (channels, tiles, 4) or st.device != x.device or getattr(x, "_rk_stats_version", None) != x._version:
+    # (one partial per 128 columns from rk_pw.hip's GEMM epilogue, per 64 from rk_pw2.hip's: rk_pw_gemm_tiles)
+    if (st.dim() != 3 or st.shape[0] != channels or st.shape[1] not in ((count + 127) // 128, (count + 63) // 64)
+            or st.shape[2] != 4 or st.device != x.device or getattr(x, "_rk_stats_version", None) != x._version):
         return None
     return st
 
@@ -175,7 +176,7 @@ class _FusedTrainBlock(torch.autograd.Function):
                                   "rk_pw_gemm_fused_f32")
             # conv2 on relu(bn1(x)), + the statistics of its output for bn2
             z = torch.empty(Fr, Cmid, H, W, dtype=x.dtype, device=dev)
-            J = int(L.rk_pw_tiles(Fr, P))
+            J = int(L.rk_pw_gemm_tiles(w2.data_ptr(), Fr, Cin, Cmid, P, 1))
             stats2 = torch.empty(Cmid, J, 4, dtype=torch.float32, device=dev)
             _native.check(L.rk_pw_gemm_stats_f32(w2.data_ptr(), x.data_ptr(), None, z.data_ptr(), Fr, Cin, Cmid, P, 1,
                                                  bn1[2].data_ptr(), bn1[3].data_ptr(), 1, stats2.data_ptr(), J, st),
@@ -200,7 +201,7 @@ class _FusedTrainBlock(torch.autograd.Function):
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)      # the projection is complete
             out = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
-            Jo = int(L.rk_pw_tiles(Fr, Po))
+            Jo = int(L.rk_pw_gemm_tiles(w3.data_ptr(), Fr, Cmid, Cout, Po, 1))
             stats_out = torch.empty(Cout, Jo, 4, dtype=torch.float32, device=dev)
             _native.check(L.rk_pw_gemm_stats_f32(w3.data_ptr(), s.data_ptr(), short.data_ptr(), out.data_ptr(), Fr, Cmid,
                                                  Cout, Po, 1, None, None, 0, stats_out.data_ptr(), Jo, st),
@@ -319,7 +320,7 @@ class _FusedTrainBlock(torch.autograd.Function):
                 _native.check(L.rk_pw_wgrad_pro_f32(dz.data_ptr(), x.data_ptr(), dw2.data_ptr(), Fr, Cin, Cmid, P,
                                                     bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb, wg_stream()),
                               "rk_pw_wgrad_pro_f32")
-            J = int(L.rk_pw_tiles(Fr, P))
+            J = int(L.rk_pw_gemm_tiles(w2.data_ptr(), Fr, Cmid, Cin, P, 0))
             bred = torch.empty(Cin, J, 2, dtype=torch.float32, device=dev)
             dzm = res if res is not None else torch.empty_like(x)             # (the residual may alias the result)
             _native.check(L.rk_pw_gemm_bnbwd_f32(w2.data_ptr(), dz.data_ptr(), _ptr(res), dzm.data_ptr(), Fr, Cmid, Cin, P,

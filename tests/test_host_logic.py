@@ -195,14 +195,14 @@ def test_switches_are_read_once_into_a_frozen_object(monkeypatch):
     from rubiksnet_amd import config, fused_bn, pointwise
 
     sw = config.reload({})
-    assert sw == config.Switches(True, "auto", True, False) and config.switches() is sw
+    assert sw == config.Switches(True, "auto", True) and config.switches() is sw
     with pytest.raises(dataclasses.FrozenInstanceError):
         sw.fused_bn = False
     monkeypatch.setenv("RK_PW", "0")
     assert pointwise.pointwise_mode() == "auto"            # not re-read per call
     assert config.reload().pointwise == "0" and pointwise.pointwise_mode() == "0"
-    assert config.reload({"RK_FUSED_BN": "0", "RK_FUSED_EVAL": "0", "RK_PW": "all", "RK_F1": "1"}) == config.Switches(
-        False, "all", False, True)
+    assert config.reload({"RK_FUSED_BN": "0", "RK_FUSED_EVAL": "0", "RK_PW": "all"}) == config.Switches(
+        False, "all", False)
     assert fused_bn.fused_bn_enabled() is False
     with pytest.raises(ValueError):
         config.reload({"RK_PW": "sometimes"})

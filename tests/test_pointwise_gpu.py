@@ -431,71 +431,3 @@ def test_strided_shortcut_conv(shape):
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=0,
                                atol=1e-4 * float(wr.grad.abs().max()))
 
-
-@pytest.mark.parametrize("shape", [(16, 54, 54, 56, 56), (8, 10, 70, 12, 28), (24, 144, 130, 28, 28)])
-@pytest.mark.parametrize("kind", ["generic", "wide", "integer"])
-def test_f1_shift_inside_the_gemm_is_bit_identical(shape, kind):
-    """SURVEY 8(f) f1 (gather form): rk_pw_gemm_shift3d_f32 = rk3d_forward_f32 followed by rk_pw_gemm_f32, bit for bit,
-    without ever storing the shifted activation."""
-    from _util import special_shifts
-    from rubiksnet_amd import _native
-    from rubiksnet_amd.shiftlib.rubiks3d.primitive import rubiks_shift_3d_forward
-
-    NT, K, M, H, W = shape
-    T = 8
-    L = _native.lib()
-    g = torch.Generator().manual_seed(sum(shape))
-    x = torch.randn(NT, K, H, W, generator=g).cuda()
-    r = torch.randn(NT, M, H, W, generator=g).cuda()
-    wt = (torch.randn(M, K, generator=g) * 0.1).cuda()
-    sh = torch.from_numpy(special_shifts(np.random.default_rng(sum(shape)), 3, K, np.float32, kind)).cuda()
-    st = torch.cuda.current_stream().cuda_stream
-    xs = rubiks_shift_3d_forward(x.view(NT // T, T, K, H, W), sh, 1, 0).view(NT, K, H, W).contiguous()
-    y1, y2 = torch.empty(NT, M, H, W, device="cuda"), torch.empty(NT, M, H, W, device="cuda")
-    for res in (r, None):
-        rp = res.data_ptr() if res is not None else None
-        _native.check(L.rk_pw_gemm_f32(wt.data_ptr(), xs.data_ptr(), rp, y1.data_ptr(), NT, K, M, H * W, 1, st), "gemm")
-        _native.check(L.rk_pw_gemm_shift3d_f32(wt.data_ptr(), x.data_ptr(), sh.data_ptr(), rp, y2.data_ptr(), NT, T, K, M, H, W,
-                                               st), "f1")
-        assert torch.equal(y1, y2)
-
-
-@pytest.mark.parametrize("shape", [(16, 54, 54, 56, 56), (8, 10, 70, 12, 28)])
-def test_f1_against_the_oracle_shift_and_an_fp64_convolution(oracle, shape):
-    """The same fused kernel against the REFERENCE arithmetic (round-2 review: the test above compares it with two other
-    HIP kernels): the oracle's RubiksShift3D forward (K1) in fp32, then F.conv2d + residual in fp64 on the CPU."""
-    from _util import special_shifts
-    from rubiksnet_amd import _native
-
-    NT, K, M, H, W = shape
-    T = 8
-    L = _native.lib()
-    g = torch.Generator().manual_seed(sum(shape) + 1)
-    x = torch.randn(NT, K, H, W, generator=g)
-    r = torch.randn(NT, M, H, W, generator=g)
-    wt = torch.randn(M, K, generator=g) * 0.1
-    sh = special_shifts(np.random.default_rng(sum(shape)), 3, K, np.float32, "wide")
-    xs = oracle.rk3d_forward(x.view(NT // T, T, K, H, W).numpy(), sh, 1, 0).reshape(NT, K, H, W)
-    ref = F.conv2d(torch.from_numpy(xs).double(), wt.double().view(M, K, 1, 1)) + r.double()
-    y = torch.empty(NT, M, H, W, device="cuda")
-    xd, rd, wd, sd = x.cuda(), r.cuda(), wt.cuda(), torch.from_numpy(sh).cuda()
-    _native.check(L.rk_pw_gemm_shift3d_f32(wd.data_ptr(), xd.data_ptr(), sd.data_ptr(), rd.data_ptr(), y.data_ptr(), NT, T, K, M,
-                                           H, W, torch.cuda.current_stream().cuda_stream), "f1")
-    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6 * K ** 0.5 * float(ref.abs().max()))
-
-
-def test_f1_switch_gives_the_same_logits(monkeypatch):
-    """RK_F1=1 routes the inference blocks' conv3 through the fused kernel: same logits, bit for bit."""
-    from rubiksnet_amd import RubiksNet
-
-    torch.manual_seed(0)
-    net = RubiksNet("tiny", 174, variant="rubiks3d", verbose=False).cuda().eval()
-    clips = torch.randn(2, 8, 3, 224, 224, device="cuda")
-    with torch.no_grad():
-        monkeypatch.setenv("RK_F1", "0")
-        _reload_switches()
-        a = net(clips)
-        monkeypatch.setenv("RK_F1", "1")
-        _reload_switches()
-        b = net(clips)
-    assert torch.equal(a, b)

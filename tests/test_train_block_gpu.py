@@ -192,7 +192,7 @@ def test_gemm_statistics_epilogue(shape, K, M, relu_in):
     y_ref = torch.einsum("mk,fkp->fmp", w.double(), xin) + r.double()
     xd, wd, rd, kad, kbd = (t.to(DEV).contiguous() for t in (x, w, r, ka, kb))
     y = torch.empty(Fr, M, P, device=DEV)
-    J = int(L.rk_pw_tiles(Fr, P))
+    J = int(L.rk_pw_gemm_tiles(wd.data_ptr(), Fr, K, M, P, 1))     # 128- or 64-column tiles: the kernel generation's choice
     stats = torch.zeros(M, J, 4, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     _native.check(L.rk_pw_gemm_stats_f32(wd.data_ptr(), xd.data_ptr(), rd.data_ptr(), y.data_ptr(), Fr, K, M, P, 1,
@@ -216,10 +216,11 @@ def test_gemm_statistics_epilogue(shape, K, M, relu_in):
     np.testing.assert_allclose(rm.cpu().double().numpy(), (0.1 * mean).numpy(), rtol=1e-6)
     assert int(nbt) == 1
     # the stand-alone tile-statistics kernel produces the same partial format
-    stats2 = torch.zeros(M, J, 4, device=DEV)
+    J2 = int(L.rk_pw_tiles(Fr, P))                                  # (its tiles are 128 columns wide whatever the GEMM's are)
+    stats2 = torch.zeros(M, J2, 4, device=DEV)
     _native.check(L.rk_bn_tile_stats_f32(y.data_ptr(), stats2.data_ptr(), Fr, M, P, st), "tile_stats")
     out2 = torch.empty(4, M, device=DEV)
-    _native.check(L.rk_bn_finish_tiles_f32(stats2.data_ptr(), J, Fr * P, gamma.data_ptr(), beta.data_ptr(), None, None,
+    _native.check(L.rk_bn_finish_tiles_f32(stats2.data_ptr(), J2, Fr * P, gamma.data_ptr(), beta.data_ptr(), None, None,
                                            out2[0].data_ptr(), out2[1].data_ptr(), out2[2].data_ptr(), out2[3].data_ptr(),
                                            None, M, 1e-5, 0.1, None, st), "finish")
     np.testing.assert_allclose(out2[:2].cpu().numpy(), out[:2].cpu().numpy(), rtol=3e-6)
@@ -256,7 +257,7 @@ def test_dgrad_with_bn_backward_epilogue_and_prologue_wgrad(shape, K, M):
     d = lambda t: t.float().to(DEV).contiguous()                                         # noqa: E731
     xd, wd, dzd, sd, ad, bd, md, ivd, gd = d(x), d(w), d(dz2), d(skip), d(a), d(b), d(mean), d(inv), d(gamma)
     st = torch.cuda.current_stream().cuda_stream
-    J = int(L.rk_pw_tiles(Fr, P))
+    J = int(L.rk_pw_gemm_tiles(wd.data_ptr(), Fr, K, C, P, 0))
     bred = torch.zeros(C, J, 2, device=DEV)
     dzm = torch.empty(Fr, C, P, device=DEV)
     pack = torch.stack([ad, bd, md, ivd], dim=1).contiguous()
