@@ -243,6 +243,101 @@ def pw16_bench(env, iters=40, settle_s=0.2):
     return out
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_* at 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def pw32_bench(env, iters=30, settle_s=0.2):
+    """The fp32 1x1 convolution kernels (rk_pw.hip / rk_pw2.hip behind the public entry points, whichever the dispatch
+    picks) on the layer 70 of RubiksNet-Large's 102 convolutions have, [256, 288 -> 288, 14, 14], and on the 28x28 stage's
+    [256, 144 -> 144, 28, 28]: forward, forward + residual + the next BatchNorm's tile statistics (conv3 of a fused
+    training block), d(input), d(weight).  MFMA-bound at fp32: fraction of the 157.3 TFLOP/s f32 MFMA peak."""
+    from rubiksnet_amd import _native
+    L = _native.lib()
+    dev = env.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "dtype": "f32 in, f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)"}
+    for Fr, K, M, H in ((256, 288, 288, 14), (256, 144, 144, 28)):
+        P = H * H
+        sets = [(torch.randn(Fr, K, P, device=dev), torch.randn(Fr, M, P, device=dev), torch.empty(Fr, M, P, device=dev),
+                 torch.empty(Fr, K, P, device=dev)) for _ in range(2)]
+        w = torch.randn(M, K, device=dev) / K ** 0.5
+        nb = int(L.rk_pw_wgrad_workspace_bytes(Fr, K, M, P))
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        dw = torch.empty(M, K, device=dev)
+        J = int(L.rk_pw_gemm_tiles(w.data_ptr(), Fr, K, M, P, 1))
+        stats = torch.empty(M, J, 4, device=dev)
+        it = [0]
+
+        def nxt():
+            it[0] += 1
+            return sets[it[0] % 2]
+
+        def fwd():
+            x, g, y, o = nxt()
+            _native.check(L.rk_pw_gemm_f32(w.data_ptr(), x.data_ptr(), None, y.data_ptr(), Fr, K, M, P, 1, stream), "gemm")
+
+        def fwd_res_stats():
+            x, g, y, o = nxt()
+            _native.check(L.rk_pw_gemm_stats_f32(w.data_ptr(), x.data_ptr(), g.data_ptr(), y.data_ptr(), Fr, K, M, P, 1, None,
+                                                 None, 0, stats.data_ptr(), J, stream), "gemm_stats")
+
+        def dgrad():
+            x, g, y, o = nxt()
+            _native.check(L.rk_pw_gemm_f32(w.data_ptr(), g.data_ptr(), None, o.data_ptr(), Fr, M, K, P, 0, stream), "dgrad")
+
+        def wgrad():
+            x, g, y, o = nxt()
+            _native.check(L.rk_pw_wgrad_f32(g.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, K, M, P, ws.data_ptr(), nb, stream),
+                          "wgrad")
+        flop = 2.0 * Fr * P * K * M
+        leg = {"layer": [Fr, K, M, H, H], "GFLOP": flop / 1e9}
+        for name, fn in (("fwd", fwd), ("fwd_residual_stats", fwd_res_stats), ("dgrad", dgrad), ("wgrad", wgrad)):
+            t = _steady(fn, iters, settle_s)
+            leg[name] = {"us": t * 1e6, "TFLOPs": flop / t / 1e12, "frac_of_mfma_peak": flop / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        out["%dx%d_%dch" % (H, H, K)] = leg
+        del sets, ws
+    return out
+
+
+def bn_bench(env, iters=40, settle_s=0.2):
+    """BatchNorm's remaining d(x) pass of a fused training block (rk_bn_bwd_dx_pre_f32: dx = gamma invstd (dz - k1 -
+    xhat k2) (+ skip)), the top kernel of the fp32 train steps by time.  Algorithmic bytes: dz, x (, skip) read, dx written."""
+    from rubiksnet_amd import _native
+    L = _native.lib()
+    dev = env.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for Fr, C, H in ((256, 288, 14), (256, 72, 56)):
+        P = H * H
+        sets = [(torch.randn(Fr, C, P, device=dev), torch.randn(Fr, C, P, device=dev), torch.randn(Fr, C, P, device=dev),
+                 torch.empty(Fr, C, P, device=dev)) for _ in range(3)]
+        gamma, mean, inv = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+        k12 = torch.randn(2, C, device=dev) * 0.01
+        it = [0]
+
+        def nxt():
+            it[0] += 1
+            return sets[it[0] % 3]
+
+        def plain():
+            dz, x, sk, dx = nxt()
+            _native.check(L.rk_bn_bwd_dx_pre_f32(dz.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                                 k12.data_ptr(), None, dx.data_ptr(), Fr, C, P, stream), "dx_pre")
+
+        def with_skip():
+            dz, x, sk, dx = nxt()
+            _native.check(L.rk_bn_bwd_dx_pre_f32(dz.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                                 k12.data_ptr(), sk.data_ptr(), dx.data_ptr(), Fr, C, P, stream), "dx_pre")
+        e = 4.0 * Fr * C * P
+        leg = {"tensor": [Fr, C, H, H]}
+        for name, fn, passes in (("dx", plain, 3), ("dx_plus_skip", with_skip, 4)):
+            t = _steady(fn, iters, settle_s)
+            leg[name] = {"us": t * 1e6, "GBps": passes * e / t / 1e9, "frac_of_hbm_peak": passes * e / t / 1e9 / HBM_PEAK_GBS}
+        out["%dx%d_%dch" % (H, H, C)] = leg
+        del sets
+    return out
+
+
 def op2d_bench(env, iters=60, settle_s=0.3):
     """the 2-D operator of the -aq networks on the same number of elements
     ([256,64,56,56] = 32 clips x 8 frames), fp32 and bf16.  Same method as the 3-D leg: an untimed run-in (the
@@ -451,7 +546,8 @@ def run_in(env, step, min_s=1.5, max_s=12.0):
     while True:
         ts = time.perf_counter()
         step()
-        torch.cuda.synchronize()
+        if env.device.type == "cuda":
+            torch.cuda.synchronize()
         times.append(time.perf_counter() - ts)
         elapsed = time.perf_counter() - t0
         settled = False
@@ -569,17 +665,44 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def dry_model_leg(env, steps):
+    """The model legs' control flow on a stub (no GPU): a DDP-wrapped linear model whose ranks are deliberately out of
+    step, run_in()'s collective stop decision (every rank must leave after the SAME number of steps: a DDP step is a
+    collective), then timed_region()'s barrier + max-over-ranks bracket."""
+    import torch.distributed as dist
+
+    torch.manual_seed(0)
+    model = dp.wrap_ddp(torch.nn.Linear(16, 4), env)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    x, y = torch.randn(8, 16), torch.randint(0, 4, (8,))
+
+    def step():
+        time.sleep(0.002 * (1 + 2 * env.rank))                      # rank r settles at a different step time
+        dp.train_step(model, opt, x, y)
+    n = run_in(env, step, min_s=0.15, max_s=4.0)
+    counts = [n]
+    if env.distributed:
+        t = torch.tensor([float(n)])
+        gathered = [torch.zeros(1) for _ in range(env.world_size)]
+        dist.all_gather(gathered, t)
+        counts = [int(g.item()) for g in gathered]
+    dt = dp.timed_region(env, step, steps)
+    slowest = 0.002 * (1 + 2 * (env.world_size - 1))
+    return {"run_in_steps": counts, "ms_per_step": 1e3 * dt / steps, "slowest_rank_sleep_ms": 1e3 * slowest}
+
+
 def dry_run(env, args):
     """No GPU: everything of the N-rank path that is not the product kernel."""
     probe = allreduce_probe(env, mbytes=4, iters=3)
     dt = dp.timed_region(env, lambda: None, args.steps)
+    stub = dry_model_leg(env, args.steps)
     if env.is_main:
         print(json.dumps({
             "metric": "RubiksShift3D fwd+bwd GB/s vs HBM roofline", "value": None, "unit": "GB/s",
             "n_gpus": env.world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dry_run": True, "backend": env.backend, "rccl_ranks": env.world_size, "allreduce_probe": probe,
-            "empty_timed_region_s": dt,
+            "empty_timed_region_s": dt, "model_leg_stub": stub,
             "config": {"workload": "dry run on %s: launcher + rendezvous + barrier/max timing + all-reduce only "
                                    "(the operator has no CPU path)" % env.backend},
         }), flush=True)
@@ -639,7 +762,7 @@ def main():
     # ran the 2-D / secondary legs on rank 0 after the last barrier while ranks 1..N-1 were already tearing the RCCL
     # communicator down -- untested on RCCL, flagged by the round-2 review.)  The other ranks idle at the barrier.
     traffic, traffic_src = pmc_traffic("backward")
-    rk2d = secondary = tshift = pw16 = cpu = None
+    rk2d = secondary = tshift = pw16 = pw32 = bnleg = cpu = None
     if env.is_main:
         rk2d = op2d_bench(env)
         secondary = secondary_points(env)
@@ -651,6 +774,14 @@ def main():
             pw16 = pw16_bench(env)
         except Exception as exc:
             pw16 = {"error": repr(exc)}
+        try:
+            pw32 = pw32_bench(env)
+        except Exception as exc:
+            pw32 = {"error": repr(exc)}
+        try:
+            bnleg = bn_bench(env)
+        except Exception as exc:
+            bnleg = {"error": repr(exc)}
         if not args.no_cpu:                  # after every timed GPU leg
             cpu = cpu_baseline()
     dp.barrier(env)
@@ -692,7 +823,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "rk2d": rk2d,
-            "tshift": tshift, "pw_bf16": pw16,
+            "tshift": tshift, "pw_bf16": pw16, "pw_f32": pw32, "bn_bwd_dx": bnleg,
             "secondary": secondary,
             "model": models.get("tiny-train"),
             "models": models,

@@ -229,7 +229,9 @@ class RubiksNetBackbone(nn.Module):
             with all_frozen(self):          # eval with grad mode on: one parameter walk per forward, not one per block
                 for stage in (self.layer0, self.layer1, self.layer2, self.layer3, self.layer4):
                     x = stage(x)
-        y = bn_relu_from_stats(self.bn_last, x) if self.training else None     # statistics from the last conv3's epilogue
+        # statistics from the last conv3's epilogue when the last block ran fused (inputs whose last planes have H * W % 4 == 0;
+        # at 224 x 224 they are 7 x 7, the block runs layer by layer and bn_last keeps its own statistics pass)
+        y = bn_relu_from_stats(self.bn_last, x) if self.training else None
         x = y if y is not None else bn_relu(self.bn_last, x)
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))

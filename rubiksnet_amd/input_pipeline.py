@@ -11,6 +11,8 @@ clips (1 byte per element over PCIe) and `stacked_u8_to_clips` does transpose + 
 stream and transformed there, double buffered, so the copy and the transform of batch i+1 overlap the step on
 batch i.  (Dataset indexing, JPEG decoding and the PIL crops stay out of scope)
 """
+import os
+
 import torch
 
 from . import _native
@@ -63,6 +65,56 @@ def stacked_u8_to_clips(stacked, n_frames, mean=IMAGENET_MEAN, std=IMAGENET_STD,
     return out.view(B, n_frames, 3, H, W)
 
 
+def _gpu_numa_cpus(device):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), or None when that cannot be told."""
+    try:
+        props = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus or None
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+class _near_gpu:
+    """Run the enclosed host allocations on the GPU's own NUMA node.  Pinned memory is placed where the allocating thread
+    runs (first touch); a loader built after the process has wandered to the other socket got buffers whose H2D copies ran
+    at half the PCIe rate (24 instead of 56 GB/s: the round-3 feeder read 20 k clips/s against round 2's 39 k)."""
+
+    def __init__(self, device):
+        self.cpus = _gpu_numa_cpus(device)
+        self.saved = None
+
+    def __enter__(self):
+        if self.cpus and hasattr(os, "sched_setaffinity"):
+            try:
+                self.saved = os.sched_getaffinity(0)
+                allowed = self.saved & self.cpus
+                if allowed:
+                    os.sched_setaffinity(0, allowed)
+                else:
+                    self.saved = None
+            except OSError:
+                self.saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            try:
+                os.sched_setaffinity(0, self.saved)
+            except OSError:
+                pass
+        return False
+
+
 class SyntheticClipLoader:
     """Endless iterator of (clips [B, T, 3, H, W] normalised, labels [B]) on `device`.
 
@@ -77,9 +129,10 @@ class SyntheticClipLoader:
             raise RuntimeError("SyntheticClipLoader feeds a GPU (no CPU path)")
         g = torch.Generator().manual_seed(seed)
         self.n_frames, self.dtype = n_frames, dtype
-        self._host = [torch.randint(0, 256, (batch, size, size, 3 * n_frames), dtype=torch.uint8, generator=g).pin_memory()
-                      for _ in range(depth)]
-        self._labels = [torch.randint(0, num_classes, (batch,), generator=g).pin_memory() for _ in range(depth)]
+        with _near_gpu(self.device):
+            self._host = [torch.randint(0, 256, (batch, size, size, 3 * n_frames), dtype=torch.uint8, generator=g).pin_memory()
+                          for _ in range(depth)]
+            self._labels = [torch.randint(0, num_classes, (batch,), generator=g).pin_memory() for _ in range(depth)]
         self._stage = [torch.empty_like(h, device=self.device) for h in self._host]
         self._out = [torch.empty(batch, 3 * n_frames, size, size, dtype=dtype, device=self.device) for _ in range(depth)]
         self._lab = [torch.empty_like(l, device=self.device) for l in self._labels]

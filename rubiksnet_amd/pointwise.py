@@ -46,8 +46,18 @@ def _pack(weight):
     return fwd, bwd
 
 
+_PW16_BYTES = 1 << 31          # rk_pw16.hip addresses an activation tensor with 32-bit byte offsets
+
+
+def _pw16_fits(Fr, C, P):
+    return Fr * C * P * 2 < _PW16_BYTES
+
+
 def _packed_ok(a, x, K, M, P, a_is_mk):
-    return x.dtype == torch.bfloat16 and P >= 8 and a.dim() >= 2 and a.shape[0] == (M if a_is_mk else K)
+    # (tensors of 2 GiB and more -- ~150 clips of 8 x 72 x 112 x 112 in bf16 -- keep the first-generation kernel, which
+    # indexes with size_t)
+    return (x.dtype == torch.bfloat16 and P >= 8 and a.dim() >= 2 and a.shape[0] == (M if a_is_mk else K)
+            and _pw16_fits(x.shape[0], K, P))
 
 
 def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None, packed=None):
@@ -83,7 +93,7 @@ def _wgrad(dy, x, weight):
     L = _native.lib()
     dw = torch.empty_like(weight)                       # fp32, whatever the activations' storage type
     with torch.cuda.device(dev):
-        if x.dtype == torch.bfloat16 and H * W >= 8:
+        if x.dtype == torch.bfloat16 and H * W >= 8 and _pw16_fits(Fr, max(Cin, Cout), H * W):
             nbytes = int(L.rk_pw_wgrad16_workspace_bytes(Fr, Cin, Cout, H * W))
             ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
             _native.check(L.rk_pw_wgrad16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W, ws.data_ptr(),
@@ -262,7 +272,8 @@ def _eligible_s2_bf16(conv, x):
             and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-            and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0 and (x.shape[2] // 2) * (x.shape[3] // 2) >= 8)
+            and ((x.shape[2] // 2) * (x.shape[3] // 2)) % 4 == 0 and (x.shape[2] // 2) * (x.shape[3] // 2) >= 8
+            and _pw16_fits(x.shape[0], max(conv.in_channels, conv.out_channels), (x.shape[2] // 2) * (x.shape[3] // 2)))
 
 
 class _Conv1x1OddFunc(torch.autograd.Function):

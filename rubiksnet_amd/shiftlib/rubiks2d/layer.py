@@ -9,20 +9,21 @@ __all__ = ["RubiksShift2D", "init_shift_group"]
 
 
 def init_shift_group(shift, kernel_size):
-    """Fill `shift` [2, C] in place with the integer offsets of a K x K window, one window position
-    per channel, cycling over the channels (the zero-FLOP "group shift" init of layer.py:6-15).
-    Channel c gets `c mod K - K//2` in row 0 (H) and `(c div K) mod K - K//2` in row 1 (W), the
-    reference's order.  Every channel then sits on the integer-shift
-    branch of d(shift) (rubiks2d_kernels.cu:189-253)."""
+    """Fill `shift` [2, C] in place with the integer offsets of a K x K window, one window position per channel, cycling
+    over the channels (the zero-FLOP "group shift" init of layer.py:6-15).  The offsets are r = -(K//2) .. K//2 -- 2 (K//2) + 1
+    of them, i.e. K for an odd window and K + 1 for an even one, exactly as the reference builds them: row 0 (H) cycles
+    through r, row 1 (W) holds each entry of r K times, both tiled K * (C // K^2) (resp. C // K^2) times.  When the
+    tiled length is not C the reference's assignment raises (every even K except the accidental C = K (K + 1) (C // K^2)),
+    and so does this.  Every channel then sits on the integer-shift branch of d(shift) (rubiks2d_kernels.cu:189-253)."""
     K = int(kernel_size)
     C = shift.size(1)
-    covered = (C // (K * K)) * K * K
-    if covered != C:
-        # the reference's `repeat` raises on the size mismatch as well
-        raise RuntimeError("init_shift_group: %d channels are not a multiple of %d x %d" % (C, K, K))
-    c = torch.arange(C)
-    shift[0] = (c % K - K // 2).to(shift.dtype)
-    shift[1] = ((c // K) % K - K // 2).to(shift.dtype)
+    n_off = 2 * (K // 2) + 1
+    length = n_off * K * (C // (K * K))
+    if length != C:
+        raise RuntimeError("init_shift_group: a %d x %d window tiles to %d offsets, the layer has %d channels" % (K, K, length, C))
+    i = torch.arange(C)
+    shift[0] = (i % n_off - K // 2).to(shift.dtype)
+    shift[1] = ((i // K) % n_off - K // 2).to(shift.dtype)
 
 
 def _fill_shift(shift, how):

@@ -19,12 +19,34 @@ Qualifies: training mode, fp32 CUDA tensors, the 3-D shift variant, no SE layer,
 sides of the shift (every block of the networks except the two that touch 7x7 planes).  Anything else: None, and the
 caller runs the layer-by-layer path.  `RK_FUSED_TRAIN=0` switches it off.
 """
+import logging
+
 import torch
 
 from . import _native, config, rubiksnet_cuda
 from .fused_bn import _count_batch
 
-__all__ = ["fused_train_block", "take_stats", "bn_relu_from_stats"]
+__all__ = ["fused_train_block", "take_stats", "bn_relu_from_stats", "stats_fallbacks"]
+
+_LOG = logging.getLogger("rubiksnet_amd")
+_FALLBACKS = [0]
+
+
+def stats_fallbacks():
+    """How many fused blocks of this process had to run their own statistics pass over x because the producer's tile
+    statistics did not arrive with the tensor (see _note_fallback)."""
+    return _FALLBACKS[0]
+
+
+def _note_fallback(shape):
+    """The tile statistics travel as an attribute of the producing block's output tensor; anything between two blocks
+    that makes a new tensor object (a DDP / checkpoint hook, `.contiguous()` on a view, an in-place edit) drops them and
+    this block pays one extra read of x.  Correct, but a silent performance cliff -- so it is counted, and said once."""
+    _FALLBACKS[0] += 1
+    if _FALLBACKS[0] == 1:
+        _LOG.warning("rubiksnet_amd: a fused training block received x %s without its producer's BatchNorm tile statistics "
+                     "and runs a statistics pass of its own (logged once; train_block.stats_fallbacks() counts them)",
+                     tuple(shape))
 
 _CMAX = 320          # register tile of the GEMM kernels (as the inference fusion)
 
@@ -148,64 +170,71 @@ class _FusedTrainBlock(torch.autograd.Function):
         P, Po = H * W, Ho * Wo
         s3, pd = [1, plan.stride, plan.stride], [0, 0, 0]
         with torch.cuda.device(dev):
-            st = _stream(dev)
-            if stats_in is None:
-                stats_in = _tile_stats(L, x, Fr, Cin, P)
-            bn1 = _finish(L, blk.bn1, stats_in, Fr * P, dev)                       # mean, invstd, a, b
-            # shortcut branch: x itself, or the projection of relu(bn1(x)) (prologue in the operand load).  The projection
-            # has no consumer before conv3's epilogue: it runs on the second stream next to conv2 and the shift.
             side = None
-            if plan.identity:
-                short = x
-            else:
-                side = _side_stream(dev)
-                cur = torch.cuda.current_stream(dev)
-                sst = st
-                if side is not None:
-                    side.wait_stream(cur)
-                    sst = side.cuda_stream
-                if plan.stride == 2:
-                    short = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
-                    _native.check(L.rk_pw_s2_forward_fused_f32(wsc.data_ptr(), x.data_ptr(), short.data_ptr(), Fr, Cin, Cout,
-                                                               H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, sst),
-                                  "rk_pw_s2_forward_fused_f32")
+            try:
+                st = _stream(dev)
+                if stats_in is None:
+                    _note_fallback(x.shape)
+                    stats_in = _tile_stats(L, x, Fr, Cin, P)
+                bn1 = _finish(L, blk.bn1, stats_in, Fr * P, dev)                       # mean, invstd, a, b
+                # shortcut branch: x itself, or the projection of relu(bn1(x)) (prologue in the operand load).  The projection
+                # has no consumer before conv3's epilogue: it runs on the second stream next to conv2 and the shift.
+                if plan.identity:
+                    short = x
                 else:
-                    short = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=dev)
-                    _native.check(L.rk_pw_gemm_fused_f32(wsc.data_ptr(), x.data_ptr(), None, short.data_ptr(), Fr, Cin, Cout,
-                                                         P, 1, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, None, None, 0, sst),
-                                  "rk_pw_gemm_fused_f32")
-            # conv2 on relu(bn1(x)), + the statistics of its output for bn2
-            z = torch.empty(Fr, Cmid, H, W, dtype=x.dtype, device=dev)
-            J = int(L.rk_pw_gemm_tiles(w2.data_ptr(), Fr, Cin, Cmid, P, 1))
-            stats2 = torch.empty(Cmid, J, 4, dtype=torch.float32, device=dev)
-            _native.check(L.rk_pw_gemm_stats_f32(w2.data_ptr(), x.data_ptr(), None, z.data_ptr(), Fr, Cin, Cmid, P, 1,
-                                                 bn1[2].data_ptr(), bn1[3].data_ptr(), 1, stats2.data_ptr(), J, st),
-                          "rk_pw_gemm_stats_f32")
-            bn2 = _finish(L, blk.bn2, stats2, Fr * P, dev)
-            # the shift of relu(bn2(z)), on [N, T, C, H, W] views of the same memory.  Fused (the kernels normalise the
-            # landed planes in LDS: the activation is never stored) where a fused kernel exists, else normalise + shift.
-            N = Fr // plan.T
-            s = torch.empty(Fr, Cmid, Ho, Wo, dtype=x.dtype, device=dev)
-            shift_c = shift.detach().contiguous()
-            abmi2 = bn2[4:].view(Cmid, 4)
-            a2 = None
-            rc = rubiksnet_cuda.rubiks_shift_3d_forward_bn_float(z.view(N, plan.T, Cmid, H, W), abmi2, shift_c, s3, pd,
+                    side = _side_stream(dev)
+                    cur = torch.cuda.current_stream(dev)
+                    sst = st
+                    if side is not None:
+                        side.wait_stream(cur)
+                        sst = side.cuda_stream
+                    if plan.stride == 2:
+                        short = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
+                        _native.check(L.rk_pw_s2_forward_fused_f32(wsc.data_ptr(), x.data_ptr(), short.data_ptr(), Fr, Cin, Cout,
+                                                                   H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, sst),
+                                      "rk_pw_s2_forward_fused_f32")
+                    else:
+                        short = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=dev)
+                        _native.check(L.rk_pw_gemm_fused_f32(wsc.data_ptr(), x.data_ptr(), None, short.data_ptr(), Fr, Cin, Cout,
+                                                             P, 1, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, None, None, 0, sst),
+                                      "rk_pw_gemm_fused_f32")
+                # conv2 on relu(bn1(x)), + the statistics of its output for bn2
+                z = torch.empty(Fr, Cmid, H, W, dtype=x.dtype, device=dev)
+                J = int(L.rk_pw_gemm_tiles(w2.data_ptr(), Fr, Cin, Cmid, P, 1))
+                stats2 = torch.empty(Cmid, J, 4, dtype=torch.float32, device=dev)
+                _native.check(L.rk_pw_gemm_stats_f32(w2.data_ptr(), x.data_ptr(), None, z.data_ptr(), Fr, Cin, Cmid, P, 1,
+                                                     bn1[2].data_ptr(), bn1[3].data_ptr(), 1, stats2.data_ptr(), J, st),
+                              "rk_pw_gemm_stats_f32")
+                bn2 = _finish(L, blk.bn2, stats2, Fr * P, dev)
+                # the shift of relu(bn2(z)), on [N, T, C, H, W] views of the same memory.  Fused (the kernels normalise the
+                # landed planes in LDS: the activation is never stored) where a fused kernel exists, else normalise + shift.
+                N = Fr // plan.T
+                s = torch.empty(Fr, Cmid, Ho, Wo, dtype=x.dtype, device=dev)
+                shift_c = shift.detach().contiguous()
+                abmi2 = bn2[4:].view(Cmid, 4)
+                a2 = None
+                rc = rubiksnet_cuda.rubiks_shift_3d_forward_bn_float(z.view(N, plan.T, Cmid, H, W), abmi2, shift_c, s3, pd,
+                                                                     bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
+                if rc == rubiksnet_cuda.UNSUPPORTED:
+                    a2 = torch.empty_like(z)
+                    _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(), a2.data_ptr(),
+                                                           Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
+                    rubiksnet_cuda.rubiks_shift_3d_forward_float(a2.view(N, plan.T, Cmid, H, W), shift_c, s3, pd,
                                                                  bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
-            if rc == rubiksnet_cuda.UNSUPPORTED:
-                a2 = torch.empty_like(z)
-                _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(), a2.data_ptr(),
-                                                       Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
-                rubiksnet_cuda.rubiks_shift_3d_forward_float(a2.view(N, plan.T, Cmid, H, W), shift_c, s3, pd,
-                                                             bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
-            # conv3 + shortcut, + the statistics of the block's output for whoever normalises it next
-            if side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side)      # the projection is complete
-            out = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
-            Jo = int(L.rk_pw_gemm_tiles(w3.data_ptr(), Fr, Cmid, Cout, Po, 1))
-            stats_out = torch.empty(Cout, Jo, 4, dtype=torch.float32, device=dev)
-            _native.check(L.rk_pw_gemm_stats_f32(w3.data_ptr(), s.data_ptr(), short.data_ptr(), out.data_ptr(), Fr, Cmid,
-                                                 Cout, Po, 1, None, None, 0, stats_out.data_ptr(), Jo, st),
-                          "rk_pw_gemm_stats_f32")
+                # conv3 + shortcut, + the statistics of the block's output for whoever normalises it next
+                if side is not None:
+                    torch.cuda.current_stream(dev).wait_stream(side)      # the projection is complete
+                out = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
+                Jo = int(L.rk_pw_gemm_tiles(w3.data_ptr(), Fr, Cmid, Cout, Po, 1))
+                stats_out = torch.empty(Cout, Jo, 4, dtype=torch.float32, device=dev)
+                _native.check(L.rk_pw_gemm_stats_f32(w3.data_ptr(), s.data_ptr(), short.data_ptr(), out.data_ptr(), Fr, Cmid,
+                                                     Cout, Po, 1, None, None, 0, stats_out.data_ptr(), Jo, st),
+                              "rk_pw_gemm_stats_f32")
+            finally:
+                # an exception between the fork and the join must not let the allocator hand out buffers the side
+                # stream still uses: the join always runs
+                if side is not None:
+                    torch.cuda.current_stream(dev).wait_stream(side)
         ctx.plan = plan
         ctx.has_a2 = a2 is not None
         ctx.save_for_backward(x, z, a2 if a2 is not None else z, s, bn1, bn2, g1, g2, b2, w2, w3,
@@ -243,104 +272,106 @@ class _FusedTrainBlock(torch.autograd.Function):
                 side.wait_stream(cur)
                 return side.cuda_stream
 
-            # conv3: d(s) = W3^T dout, d(W3) = dout s^T
-            ds = torch.empty_like(s)
-            _native.check(L.rk_pw_gemm_f32(w3.data_ptr(), dout.data_ptr(), None, ds.data_ptr(), Fr, Cout, Cmid, Po, 0, st),
-                          "rk_pw_gemm_f32")
-            dw3 = None
-            if need[8]:
-                dw3 = torch.empty_like(w3)
-                ws, nb = wgrad_ws(Cmid, Cout, Po)
-                _native.check(L.rk_pw_wgrad_f32(dout.data_ptr(), s.data_ptr(), dw3.data_ptr(), Fr, Cmid, Cout, Po,
-                                                ws.data_ptr(), nb, wg_stream()), "rk_pw_wgrad_f32")
-            # the shift and bn2: d(shift), and d(z) = bn2 + ReLU backward of d(a2).  Fused: the shift backward reads z,
-            # masks its d(x) with the ReLU and reduces bn2's sums in the same launch (dg2, db2, k12); one d(x) pass finishes.
-            N = Fr // plan.T
-            dshift = torch.empty_like(shift)
-            dz = torch.empty_like(z)
-            dg2 = torch.empty(Cmid, dtype=torch.float32, device=dev)
-            db2 = torch.empty(Cmid, dtype=torch.float32, device=dev)
-            rc = rubiksnet_cuda.UNSUPPORTED
-            if not ctx.has_a2:
-                k12b = torch.empty(2, Cmid, dtype=torch.float32, device=dev)
-                dzm = dz                                  # masked d(a2) first, finished in place by the d(x) pass
-                rc = rubiksnet_cuda.rubiks_shift_3d_backward_bn_float(
-                    z.view(N, plan.T, Cmid, H, W), bn2[4:].view(Cmid, 4), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
-                    dzm.view(N, plan.T, Cmid, H, W), dshift, k12b, dg2, db2, plan.layer.normalize_grad, plan.t_factor,
-                    bool(plan.layer.quantize))
-                if rc == 0:
-                    _native.check(L.rk_bn_bwd_dx_pre_f32(dzm.data_ptr(), z.data_ptr(), g2.data_ptr(), bn2[0].data_ptr(),
-                                                         bn2[1].data_ptr(), k12b.data_ptr(), None, dz.data_ptr(), Fr, Cmid,
-                                                         P, st), "rk_bn_bwd_dx_pre_f32")
-                else:                                     # (no fused backward for a shape the forward took: recompute a2)
-                    a2 = torch.empty_like(z)
-                    _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(),
-                                                           a2.data_ptr(), Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
-            if rc != 0:
-                da2 = torch.empty_like(a2)
-                rubiksnet_cuda.rubiks_shift_3d_backward_float(
-                    a2.view(N, plan.T, Cmid, H, W), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
-                    da2.view(N, plan.T, Cmid, H, W), dshift, plan.layer.normalize_grad, plan.t_factor,
-                    bool(plan.layer.quantize))
-                nbn = int(L.rk_bn_workspace_bytes(Fr, Cmid, P))
-                wsb = torch.empty(max(nbn, 1), dtype=torch.uint8, device=dev)
-                _native.check(L.rk_bn_relu_backward_f32(da2.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
-                                                        bn2[0].data_ptr(), bn2[1].data_ptr(), None, dz.data_ptr(),
-                                                        dg2.data_ptr(), db2.data_ptr(), Fr, Cmid, P, 1, wsb.data_ptr(), nbn,
-                                                        st), "rk_bn_relu_backward_f32")
-                del da2
-            if not need[7]:
-                dshift = None
-            # the projecting shortcut's share of d(relu(bn1(x))), handed to conv2's d(input) GEMM as its residual
-            res, dwsc = None, None
-            if not plan.identity:
-                res = torch.empty_like(x)
-                if plan.stride == 2:
-                    _native.check(L.rk_pw_s2_dgrad_f32(wsc.data_ptr(), dout.data_ptr(), res.data_ptr(), Fr, Cin, Cout, H, W,
-                                                       st), "rk_pw_s2_dgrad_f32")
-                else:
-                    _native.check(L.rk_pw_gemm_f32(wsc.data_ptr(), dout.data_ptr(), None, res.data_ptr(), Fr, Cout, Cin, P,
-                                                   0, st), "rk_pw_gemm_f32")
-                if need[9]:
-                    dwsc = torch.empty_like(wsc)
-                    ws, nb = wgrad_ws(Cin, Cout, Po)
+            try:
+                # conv3: d(s) = W3^T dout, d(W3) = dout s^T
+                ds = torch.empty_like(s)
+                _native.check(L.rk_pw_gemm_f32(w3.data_ptr(), dout.data_ptr(), None, ds.data_ptr(), Fr, Cout, Cmid, Po, 0, st),
+                              "rk_pw_gemm_f32")
+                dw3 = None
+                if need[8]:
+                    dw3 = torch.empty_like(w3)
+                    ws, nb = wgrad_ws(Cmid, Cout, Po)
+                    _native.check(L.rk_pw_wgrad_f32(dout.data_ptr(), s.data_ptr(), dw3.data_ptr(), Fr, Cmid, Cout, Po,
+                                                    ws.data_ptr(), nb, wg_stream()), "rk_pw_wgrad_f32")
+                # the shift and bn2: d(shift), and d(z) = bn2 + ReLU backward of d(a2).  Fused: the shift backward reads z,
+                # masks its d(x) with the ReLU and reduces bn2's sums in the same launch (dg2, db2, k12); one d(x) pass finishes.
+                N = Fr // plan.T
+                dshift = torch.empty_like(shift)
+                dz = torch.empty_like(z)
+                dg2 = torch.empty(Cmid, dtype=torch.float32, device=dev)
+                db2 = torch.empty(Cmid, dtype=torch.float32, device=dev)
+                rc = rubiksnet_cuda.UNSUPPORTED
+                if not ctx.has_a2:
+                    k12b = torch.empty(2, Cmid, dtype=torch.float32, device=dev)
+                    dzm = dz                                  # masked d(a2) first, finished in place by the d(x) pass
+                    rc = rubiksnet_cuda.rubiks_shift_3d_backward_bn_float(
+                        z.view(N, plan.T, Cmid, H, W), bn2[4:].view(Cmid, 4), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
+                        dzm.view(N, plan.T, Cmid, H, W), dshift, k12b, dg2, db2, plan.layer.normalize_grad, plan.t_factor,
+                        bool(plan.layer.quantize))
+                    if rc == 0:
+                        _native.check(L.rk_bn_bwd_dx_pre_f32(dzm.data_ptr(), z.data_ptr(), g2.data_ptr(), bn2[0].data_ptr(),
+                                                             bn2[1].data_ptr(), k12b.data_ptr(), None, dz.data_ptr(), Fr, Cmid,
+                                                             P, st), "rk_bn_bwd_dx_pre_f32")
+                    else:                                     # (no fused backward for a shape the forward took: recompute a2)
+                        a2 = torch.empty_like(z)
+                        _native.check(L.rk_bn_apply_affine_f32(z.data_ptr(), bn2[2].data_ptr(), bn2[3].data_ptr(),
+                                                               a2.data_ptr(), Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
+                if rc != 0:
+                    da2 = torch.empty_like(a2)
+                    rubiksnet_cuda.rubiks_shift_3d_backward_float(
+                        a2.view(N, plan.T, Cmid, H, W), shift, ds.view(N, plan.T, Cmid, Ho, Wo), s3, pd,
+                        da2.view(N, plan.T, Cmid, H, W), dshift, plan.layer.normalize_grad, plan.t_factor,
+                        bool(plan.layer.quantize))
+                    nbn = int(L.rk_bn_workspace_bytes(Fr, Cmid, P))
+                    wsb = torch.empty(max(nbn, 1), dtype=torch.uint8, device=dev)
+                    _native.check(L.rk_bn_relu_backward_f32(da2.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
+                                                            bn2[0].data_ptr(), bn2[1].data_ptr(), None, dz.data_ptr(),
+                                                            dg2.data_ptr(), db2.data_ptr(), Fr, Cmid, P, 1, wsb.data_ptr(), nbn,
+                                                            st), "rk_bn_relu_backward_f32")
+                    del da2
+                if not need[7]:
+                    dshift = None
+                # the projecting shortcut's share of d(relu(bn1(x))), handed to conv2's d(input) GEMM as its residual
+                res, dwsc = None, None
+                if not plan.identity:
+                    res = torch.empty_like(x)
                     if plan.stride == 2:
-                        _native.check(L.rk_pw_s2_wgrad_pro_f32(dout.data_ptr(), x.data_ptr(), dwsc.data_ptr(), Fr, Cin, Cout,
-                                                               H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(),
-                                                               nb, wg_stream()), "rk_pw_s2_wgrad_pro_f32")
+                        _native.check(L.rk_pw_s2_dgrad_f32(wsc.data_ptr(), dout.data_ptr(), res.data_ptr(), Fr, Cin, Cout, H, W,
+                                                           st), "rk_pw_s2_dgrad_f32")
                     else:
-                        _native.check(L.rk_pw_wgrad_pro_f32(dout.data_ptr(), x.data_ptr(), dwsc.data_ptr(), Fr, Cin, Cout, P,
-                                                            bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb,
-                                                            wg_stream()), "rk_pw_wgrad_pro_f32")
-            # conv2: d(W2) from (dz, relu(bn1(x)) recomputed); d(input) masked by the ReLU, + bn1's reduction sums
-            dw2 = None
-            if need[4]:
-                dw2 = torch.empty_like(w2)
-                ws, nb = wgrad_ws(Cin, Cmid, P)
-                _native.check(L.rk_pw_wgrad_pro_f32(dz.data_ptr(), x.data_ptr(), dw2.data_ptr(), Fr, Cin, Cmid, P,
-                                                    bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb, wg_stream()),
-                              "rk_pw_wgrad_pro_f32")
-            J = int(L.rk_pw_gemm_tiles(w2.data_ptr(), Fr, Cmid, Cin, P, 0))
-            bred = torch.empty(Cin, J, 2, dtype=torch.float32, device=dev)
-            dzm = res if res is not None else torch.empty_like(x)             # (the residual may alias the result)
-            _native.check(L.rk_pw_gemm_bnbwd_f32(w2.data_ptr(), dz.data_ptr(), _ptr(res), dzm.data_ptr(), Fr, Cmid, Cin, P,
-                                                 0, x.data_ptr(), bn1[4].data_ptr(), bred.data_ptr(), J, st),
-                          "rk_pw_gemm_bnbwd_f32")
-            k12 = torch.empty(2, Cin, dtype=torch.float32, device=dev)
-            dg1 = torch.empty(Cin, dtype=torch.float32, device=dev)
-            db1 = torch.empty(Cin, dtype=torch.float32, device=dev)
-            _native.check(L.rk_bn_bwd_finish_tiles_f32(bred.data_ptr(), J, Fr * P, k12.data_ptr(), dg1.data_ptr(),
-                                                       db1.data_ptr(), Cin, st), "rk_bn_bwd_finish_tiles_f32")
-            dx = None
-            if need[0]:
-                dx = torch.empty_like(x)
-                skip = dout if plan.identity else None                        # identity shortcut: out = ... + x
-                _native.check(L.rk_bn_bwd_dx_pre_f32(dzm.data_ptr(), x.data_ptr(), g1.data_ptr(), bn1[0].data_ptr(),
-                                                     bn1[1].data_ptr(), k12.data_ptr(), _ptr(skip), dx.data_ptr(), Fr, Cin,
-                                                     P, st), "rk_bn_bwd_dx_pre_f32")
-            if side is not None:
-                cur.wait_stream(side)                       # gradients complete before autograd touches them
-            del keep
+                        _native.check(L.rk_pw_gemm_f32(wsc.data_ptr(), dout.data_ptr(), None, res.data_ptr(), Fr, Cout, Cin, P,
+                                                       0, st), "rk_pw_gemm_f32")
+                    if need[9]:
+                        dwsc = torch.empty_like(wsc)
+                        ws, nb = wgrad_ws(Cin, Cout, Po)
+                        if plan.stride == 2:
+                            _native.check(L.rk_pw_s2_wgrad_pro_f32(dout.data_ptr(), x.data_ptr(), dwsc.data_ptr(), Fr, Cin, Cout,
+                                                                   H, W, bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(),
+                                                                   nb, wg_stream()), "rk_pw_s2_wgrad_pro_f32")
+                        else:
+                            _native.check(L.rk_pw_wgrad_pro_f32(dout.data_ptr(), x.data_ptr(), dwsc.data_ptr(), Fr, Cin, Cout, P,
+                                                                bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb,
+                                                                wg_stream()), "rk_pw_wgrad_pro_f32")
+                # conv2: d(W2) from (dz, relu(bn1(x)) recomputed); d(input) masked by the ReLU, + bn1's reduction sums
+                dw2 = None
+                if need[4]:
+                    dw2 = torch.empty_like(w2)
+                    ws, nb = wgrad_ws(Cin, Cmid, P)
+                    _native.check(L.rk_pw_wgrad_pro_f32(dz.data_ptr(), x.data_ptr(), dw2.data_ptr(), Fr, Cin, Cmid, P,
+                                                        bn1[2].data_ptr(), bn1[3].data_ptr(), 1, ws.data_ptr(), nb, wg_stream()),
+                                  "rk_pw_wgrad_pro_f32")
+                J = int(L.rk_pw_gemm_tiles(w2.data_ptr(), Fr, Cmid, Cin, P, 0))
+                bred = torch.empty(Cin, J, 2, dtype=torch.float32, device=dev)
+                dzm = res if res is not None else torch.empty_like(x)             # (the residual may alias the result)
+                _native.check(L.rk_pw_gemm_bnbwd_f32(w2.data_ptr(), dz.data_ptr(), _ptr(res), dzm.data_ptr(), Fr, Cmid, Cin, P,
+                                                     0, x.data_ptr(), bn1[4].data_ptr(), bred.data_ptr(), J, st),
+                              "rk_pw_gemm_bnbwd_f32")
+                k12 = torch.empty(2, Cin, dtype=torch.float32, device=dev)
+                dg1 = torch.empty(Cin, dtype=torch.float32, device=dev)
+                db1 = torch.empty(Cin, dtype=torch.float32, device=dev)
+                _native.check(L.rk_bn_bwd_finish_tiles_f32(bred.data_ptr(), J, Fr * P, k12.data_ptr(), dg1.data_ptr(),
+                                                           db1.data_ptr(), Cin, st), "rk_bn_bwd_finish_tiles_f32")
+                dx = None
+                if need[0]:
+                    dx = torch.empty_like(x)
+                    skip = dout if plan.identity else None                        # identity shortcut: out = ... + x
+                    _native.check(L.rk_bn_bwd_dx_pre_f32(dzm.data_ptr(), x.data_ptr(), g1.data_ptr(), bn1[0].data_ptr(),
+                                                         bn1[1].data_ptr(), k12.data_ptr(), _ptr(skip), dx.data_ptr(), Fr, Cin,
+                                                         P, st), "rk_bn_bwd_dx_pre_f32")
+            finally:
+                if side is not None:
+                    cur.wait_stream(side)                   # always: gradients complete (and the side stream's buffers
+                del keep                                    # released) even when a launch raised in between
         return (dx, None, dg1, db1, dw2, dg2, db2, dshift, dw3, dwsc if not plan.identity else None, None)
 
 

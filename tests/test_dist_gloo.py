@@ -155,3 +155,8 @@ def test_bench_launches_itself_for_two_ranks_dry_run():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry_run"] is True and out["backend"] == "gloo"
     assert out["allreduce_probe"]["ranks"] == 2 and out["allreduce_probe"]["bus_GBps"] > 0
     assert out["steps"] == 2 and out["scaling"] == "weak" and out["metric"].startswith("RubiksShift3D")
+    # the model legs' control flow on a stub model: both ranks left run_in() after the same number of (collective) steps
+    # although their step times differ, and the timed bracket reports the SLOWEST rank's time
+    stub = out["model_leg_stub"]
+    assert len(stub["run_in_steps"]) == 2 and stub["run_in_steps"][0] == stub["run_in_steps"][1] >= 12
+    assert stub["ms_per_step"] >= stub["slowest_rank_sleep_ms"]
