@@ -280,11 +280,12 @@ __global__ __launch_bounds__(kWave) void k_bn_finish_parts(const T* __restrict__
 // finish them.  One workgroup per channel, fp64 combination in a fixed order (deterministic).
 //
 // forward: stats[c][j] = (pivot_j, sum(y - pivot_j), sum((y - pivot_j)^2), -) over the n_j columns of tile j
-// (n_j = the tile width -- 128 columns for rk_pw.hip's GEMM, 64 for rk_pw2.hip's -- except in the last tile).  With K = pivot_0:  sum(y - K) = s_j + n_j (p_j - K),
+// (n_j travels in the fourth component: 128 columns for rk_pw.hip's GEMM, 64 for rk_pw2.hip's, a column split of a
+// workgroup for rk_pw3.hip's; the tiles of a channel add up to `count`).  With K = pivot_0:  sum(y - K) = s_j + n_j (p_j - K),
 // sum((y - K)^2) = q_j + 2 (p_j - K) s_j + n_j (p_j - K)^2 -- then exactly k_bn_apply's arithmetic: mean, biased variance,
 // invstd, the affine map (a, b) of y = a x + b, and nn.BatchNorm2d's running-statistics bookkeeping.
 constexpr int kFin = 1024;               // threads of a finisher block: one block per channel, J tiles to sweep
-__global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restrict__ stats, int J, int width, long long count,
+__global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restrict__ stats, int J, long long count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
@@ -295,11 +296,10 @@ __global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restri
     const int c = blockIdx.x;
     const float4* p = stats + (size_t)c * J;
     const double K = (double)p[0].x;
-    const long long last_n = count - (long long)width * (J - 1);
     double s1 = 0, s2 = 0;
     for (int j = threadIdx.x; j < J; j += (int)blockDim.x) {
         const float4 t = p[j];
-        const double n = (j == J - 1) ? (double)last_n : (double)width;
+        const double n = (double)t.w;                            // columns of tile j: every producer writes it
         const double dp = (double)t.x - K;
         s1 += (double)t.y + n * dp;
         s2 += (double)t.z + 2.0 * dp * (double)t.y + n * dp * dp;
@@ -437,7 +437,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_tile_stats(const float* __restric
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    if (lane == 0) stats[(size_t)c * J + j] = make_float4(piv, s1, s2, 0.f);
+    const long long nl = count - 128 * j;
+    if (lane == 0) stats[(size_t)c * J + j] = make_float4(piv, s1, s2, (float)(nl < 128 ? nl : 128));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -573,12 +574,9 @@ int rk_bn_finish_tiles_f32(const void* stats, int tiles, long long count, const 
     if (!stats || !gamma || !beta || !save_mean || !save_invstd || !a || !b) return RK_ERR_NULL_POINTER;
     if ((running_mean == nullptr) != (running_var == nullptr)) return RK_ERR_NULL_POINTER;
     if (C <= 0 || tiles <= 0) return RK_ERR_BAD_DIMS;
-    // tile width from (tiles, count): 64-column tiles (rk_pw2.hip) iff count <= 64 tiles -- the two readings cannot both
-    // hold for tiles >= 2, and with one tile n = count either way
-    const int width = count <= 64LL * tiles ? 64 : 128;
-    if (count <= (long long)width * (tiles - 1) || count > (long long)width * tiles) return RK_ERR_BAD_DIMS;
+    if (count <= 0) return RK_ERR_BAD_DIMS;
     if ((uintptr_t)abmi & 15) return RK_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(k_bn_finish_tiles, dim3(C), dim3(kFin), 0, (hipStream_t)stream, (const float4*)stats, tiles, width, count,
+    hipLaunchKernelGGL(k_bn_finish_tiles, dim3(C), dim3(kFin), 0, (hipStream_t)stream, (const float4*)stats, tiles, count,
                        gamma, beta, running_mean, running_var, save_mean, save_invstd, a, b, (float4*)abmi, eps, momentum,
                        num_batches_tracked);
     return launch_status();

@@ -19,6 +19,7 @@
 #include "rk_common.hpp"
 #include "rk3d_generic.hpp"
 #include "rk_pw2.hpp"
+#include "rk_pw3.hpp"
 
 namespace rk {
 namespace pw {
@@ -326,7 +327,10 @@ __global__ __launch_bounds__(kBlock, ((WM == 2 && kKC == 16 && sizeof(T) == 4) ?
             const int rr = l31 >> 1;
             const int gmi = m0 + wm * 64 + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
             if ((l31 & 1) == 0 && gmi < d.M && tile_on) {
-                if constexpr (EPI == 1) tr.stats[(size_t)gmi * tr.J + tj] = make_float4(mypiv, sv[0], other, 0.f);
+                if constexpr (EPI == 1) {
+                    const long long nl = d.ntot - tj * 128;          // columns of this tile (the finisher's n_j)
+                    tr.stats[(size_t)gmi * tr.J + tj] = make_float4(mypiv, sv[0], other, (float)(nl < 128 ? nl : 128));
+                }
                 else tr.bred[(size_t)gmi * tr.J + tj] = make_float2(sv[0], other);
             }
         }
@@ -1357,6 +1361,15 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if constexpr (std::is_same<T, float>::value) {
         // second generation (rk_pw2.hip) where it is ahead; its training epilogues use 64-column tiles
         // (rk_pw_gemm_tiles() tells the caller which count to allocate)
+        // third kernel (rk_pw3.hip): the LDS-tiled GEMM of the 288-row layers, one workgroup per CU
+        if (pw3::tiles(F, K, M, P) > 0 && !(fuse && fuse->ma) && ((uintptr_t)A & 15) == 0) {
+            const pw2::GFuse f3 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, nullptr, nullptr, fuse->relu_in, 0}
+                                       : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
+            const pw2::GTrain t3 = train ? pw2::GTrain{train->stats, train->bred, train->bx, train->bpack, train->J}
+                                         : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};
+            const int rc = pw3::gemm(A, X, R, Y, F, K, M, P, a_is_mk, &f3, &t3, epi, (hipStream_t)stream_);
+            if (rc != RK_ERR_UNSUPPORTED || epi) return rc;
+        }
         if (pw2::gemm_wanted(K, M, P, a_is_mk, A)) {
             const pw2::GFuse f2 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, fuse->ma, fuse->mb, fuse->relu_in, fuse->relu_out}
                                        : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
@@ -1752,6 +1765,10 @@ int rk_pw_tiles(int F, int P) {
 // arguments): the second-generation kernels (rk_pw2.hip) write one partial per 64 columns, the first per 128.
 int rk_pw_gemm_tiles(const float* A, int F, int K, int M, int P, int a_is_mk) {
     if (F <= 0 || P <= 0 || K <= 0 || M <= 0) return 0;
+    if (((uintptr_t)A & 15) == 0) {
+        const int t3 = pw3::tiles(F, K, M, P);
+        if (t3 > 0) return t3;
+    }
     const int w = pw2::gemm_wanted(K, M, P, a_is_mk, A) ? pw2::kTileCols : 128;
     return (int)(((long long)F * P + w - 1) / w);
 }

@@ -80,15 +80,16 @@ def take_stats(x, channels, count):
     st = getattr(x, "_rk_stats", None)
     if st is None:
         return None
-    # (one partial per 128 columns from rk_pw.hip's GEMM epilogue, per 64 from rk_pw2.hip's: rk_pw_gemm_tiles)
-    if (st.dim() != 3 or st.shape[0] != channels or st.shape[1] not in ((count + 127) // 128, (count + 63) // 64)
-            or st.shape[2] != 4 or st.device != x.device or getattr(x, "_rk_stats_version", None) != x._version):
+    # (tiles of 128 / 64 columns or a workgroup's column halves, by kernel generation: every tile carries its own count)
+    if (st.dim() != 3 or st.shape[0] != channels or st.shape[1] < 1 or st.shape[2] != 4 or st.device != x.device
+            or getattr(x, "_rk_stats_count", None) != count or getattr(x, "_rk_stats_version", None) != x._version):
         return None
     return st
 
 
 def _attach_stats(t, stats):
     t._rk_stats = stats
+    t._rk_stats_count = t.numel() // t.shape[1]        # elements per channel the tiles add up to
     t._rk_stats_version = t._version       # an in-place edit of the tensor invalidates them
     return t
 
