@@ -130,7 +130,12 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
             if (tile3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
         }
     }
-    if (gshift && col3d::supported(d, quantize)) return finish(col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream));
+    if (gshift && col3d::supported(d, quantize)) {
+        // one-call form (fp32): row-sum + K5 inside the launch; two-phase form / fp64: partials, then k3d_finalize
+        const int P = col3d::launch_backward<T>(x, shift, gy, gx, (T*)ws, d, stream, P_out ? nullptr : gshift, normalize_grad,
+                                                t_factor);
+        return P < 0 ? launch_status() : finish(P);
+    }
 
     if (gx) {       // rubiks.cpp:363-376
         set_group(d, d.H * d.W);

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "rk3d_generic.hpp"
+#include "rk3d_dma.hpp"
 
 namespace rk {
 namespace col3d {
@@ -128,10 +129,20 @@ __global__ __launch_bounds__(kBlock) void k3d_forward_column(const T* __restrict
 // Same arithmetic per element, bit-identical: [32,8,54,112,112] stride (1,2,2) 585 -> 373 us, [32,8,108,56,56]
 // 365 -> 240 us.  (The forward is the other way round -- its big stream is the GATHERED one, and consecutive
 // outputs per thread spread a wave's tap loads over 8x the cache lines: 213 -> 330 us; it stays element-strided.)
-template <typename T, bool WRITE_GX, int kM, bool SINGLE, bool VEC = false>
+// FUSED (fp32): the row-sum over the partials and K5 run inside this launch -- the partials are published as granule
+// pairs (rk_dma.hpp, fin_publish) and the C extra workgroups at the end of the grid finish a channel each -- so the 7x7
+// planes and the 28 -> 14 / 14 -> 7 strided layers no longer pay a second launch (4.3 us + a dependent-launch boundary
+// on a 28 us kernel at [32,8,576,7,7]).
+template <typename T, bool WRITE_GX, int kM, bool SINGLE, bool VEC = false, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restrict__ x, const T* __restrict__ shift,
                                                               const T* __restrict__ gy, T* __restrict__ gx,
-                                                              T* __restrict__ part, CDims cd) {
+                                                              T* __restrict__ part, CDims cd, dma3d::Fin3 fin = dma3d::Fin3{}) {
+    if constexpr (FUSED) {
+        if ((int)blockIdx.x >= fin.f.producers) {
+            if (threadIdx.x < kWave) dma3d::finalizer_wave<3>(fin, (int)blockIdx.x - fin.f.producers, cd.d.C, cd.d.N * cd.nchunks);
+            return;
+        }
+    }
     __shared__ T red[3][kBlock / kWave];
     const Dims3& d = cd.d;
     int e;
@@ -336,10 +347,15 @@ __global__ __launch_bounds__(kBlock) void k3d_backward_column(const T* __restric
     accW = group_sum(accW, cd.E, red[2]);
     if (id.valid && e == 0) {
         const int P = d.N * cd.nchunks;
-        T* o = part + (size_t)id.c * 3 * P + (size_t)id.n * cd.nchunks + id.chunk;
-        o[0] = accT;
-        o[P] = accH;
-        o[2 * P] = accW;
+        const size_t at = (size_t)id.c * 3 * P + (size_t)id.n * cd.nchunks + id.chunk;
+        if constexpr (FUSED && std::is_same<T, float>::value) {
+            dma::fin_publish(fin.f, at, accT); dma::fin_publish(fin.f, at + P, accH); dma::fin_publish(fin.f, at + 2 * (size_t)P, accW);
+        } else {
+            T* o = part + at;
+            o[0] = accT;
+            o[P] = accH;
+            o[2 * P] = accW;
+        }
     }
 }
 
@@ -382,21 +398,39 @@ inline int launch_forward(const T* x, const T* shift, T* y, const Dims3& d, hipS
     return launch_status();
 }
 
-// returns P (partials per channel)
+// returns P (partials per channel).  gshift != nullptr (fp32): row-sum + K5 inside the launch (ws = granule pairs);
+// nullptr: plain partials ws[C][3][P] for k3d_finalize / the two-phase ABI
 template <typename T>
 inline int launch_backward(const T* x, const T* shift, const T* gy, T* gx, T* ws, const Dims3& d,
-                           hipStream_t stream) {
+                           hipStream_t stream, T* gshift = nullptr, int normalize = 0, T t_factor = 1) {
     const CDims cd = make_cdims(d, d.H * d.W);
     const bool single = d.sH >= 2 && d.sW >= 2;
     const bool vec = cd.M == 4 && vec_ok<T>(d.H * d.W, x, gx);
-#define RK_COL_BWD(GX, MM, SG, VC) hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG, VC>), dim3(grid_of(cd)), dim3(kBlock), \
-                                                      0, stream, x, shift, gy, gx, ws, cd)
+    dma3d::Fin3 fin{};
+    bool fused = false;
+    if constexpr (std::is_same<T, float>::value) {
+        if (gshift && streaming_kernels_on()) {
+            fused = true;
+            fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+            fin.f.tag = dma::next_launch_tag();
+            fin.f.producers = (int)grid_of(cd);
+            fin.gshift = gshift;
+            fin.normalize = normalize;
+            fin.t_factor = t_factor;
+        }
+    }
+    const unsigned grid = grid_of(cd) + (fused ? (unsigned)d.C : 0u);
+#define RK_COL_BWD(GX, MM, SG, VC) do { \
+        if constexpr (std::is_same<T, float>::value) { \
+            if (fused) { hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG, VC, true>), dim3(grid), dim3(kBlock), 0, stream, x, shift, gy, gx, ws, cd, fin); break; } \
+        } \
+        hipLaunchKernelGGL((k3d_backward_column<T, GX, MM, SG, VC>), dim3(grid), dim3(kBlock), 0, stream, x, shift, gy, gx, ws, cd, fin); } while (0)
 #define RK_COL_SG(GX, MM, VC) do { if (single) RK_COL_BWD(GX, MM, true, VC); else RK_COL_BWD(GX, MM, false, VC); } while (0)
     if (gx) { if (cd.M == 1) RK_COL_SG(true, 1, false); else if (vec) RK_COL_SG(true, 4, true); else RK_COL_SG(true, 4, false); }
     else { if (cd.M == 1) RK_COL_SG(false, 1, false); else if (vec) RK_COL_SG(false, 4, true); else RK_COL_SG(false, 4, false); }
 #undef RK_COL_SG
 #undef RK_COL_BWD
-    return d.N * cd.nchunks;
+    return fused ? -(d.N * cd.nchunks) : d.N * cd.nchunks;       // negative: finished inside the launch
 }
 
 }  // namespace col3d

@@ -15,7 +15,7 @@ the same block -- same modules, parameters, buffers, state-dict, same gradients 
     the identity shortcut's gradient is added inside bn1's d(x) pass,
   * the residual add is conv3's epilogue.
 
-Qualifies: training mode, fp32 CUDA tensors, the 3-D shift variant, no SE layer, planes with H*W % 4 == 0 on both
+Qualifies: training mode, fp32 CUDA tensors, the 3-D shift variant (with or without the Small tier's SE gate), planes with H*W % 4 == 0 on both
 sides of the shift (every block of the networks except the two that touch 7x7 planes).  Anything else: None, and the
 caller runs the layer-by-layer path.  `RK_FUSED_TRAIN=0` switches it off.
 """
@@ -164,7 +164,7 @@ class _Plan:
 
 class _FusedTrainBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats_in, g1, b1, w2, g2, b2, shift, w3, wsc, plan):
+    def forward(ctx, x, stats_in, g1, b1, w2, g2, b2, shift, w3, wsc, wse1, wse2, plan):
         L = _native.lib()
         blk, dev = plan.block, x.device
         Fr, Cin, H, W, Cmid, Cout, Ho, Wo = plan.Fr, plan.Cin, plan.H, plan.W, plan.Cmid, plan.Cout, plan.Ho, plan.Wo
@@ -222,13 +222,25 @@ class _FusedTrainBlock(torch.autograd.Function):
                                                            Fr, Cmid, P, 1, st), "rk_bn_apply_affine_f32")
                     rubiksnet_cuda.rubiks_shift_3d_forward_float(a2.view(N, plan.T, Cmid, H, W), shift_c, s3, pd,
                                                                  bool(plan.layer.quantize), s.view(N, plan.T, Cmid, Ho, Wo))
+                # SE gate (Small tier, backbone.py:56-71, :131-132): squeeze = one pass over s, the two tiny Linear layers in
+                # PyTorch (no autograd here: their backward is written out below), scale = one pass
+                se_q = se_h = se_g = s_in = None
+                if wse1 is not None:
+                    se_q = torch.empty(Fr, Cmid, dtype=torch.float32, device=dev)
+                    _native.check(L.rk_se_squeeze_f32(s.data_ptr(), se_q.data_ptr(), Fr, Cmid, Po, st), "rk_se_squeeze_f32")
+                    se_h = torch.relu(se_q @ wse1.t())
+                    se_g = torch.sigmoid(se_h @ wse2.t()).contiguous()
+                    s_in = torch.empty_like(s)
+                    _native.check(L.rk_se_scale_f32(s.data_ptr(), se_g.data_ptr(), s_in.data_ptr(), Fr, Cmid, Po, st),
+                                  "rk_se_scale_f32")
+                conv3_in = s_in if s_in is not None else s
                 # conv3 + shortcut, + the statistics of the block's output for whoever normalises it next
                 if side is not None:
                     torch.cuda.current_stream(dev).wait_stream(side)      # the projection is complete
                 out = torch.empty(Fr, Cout, Ho, Wo, dtype=x.dtype, device=dev)
                 Jo = int(L.rk_pw_gemm_tiles(w3.data_ptr(), Fr, Cmid, Cout, Po, 1))
                 stats_out = torch.empty(Cout, Jo, 4, dtype=torch.float32, device=dev)
-                _native.check(L.rk_pw_gemm_stats_f32(w3.data_ptr(), s.data_ptr(), short.data_ptr(), out.data_ptr(), Fr, Cmid,
+                _native.check(L.rk_pw_gemm_stats_f32(w3.data_ptr(), conv3_in.data_ptr(), short.data_ptr(), out.data_ptr(), Fr, Cmid,
                                                      Cout, Po, 1, None, None, 0, stats_out.data_ptr(), Jo, st),
                               "rk_pw_gemm_stats_f32")
             finally:
@@ -238,15 +250,21 @@ class _FusedTrainBlock(torch.autograd.Function):
                     torch.cuda.current_stream(dev).wait_stream(side)
         ctx.plan = plan
         ctx.has_a2 = a2 is not None
+        ctx.has_se = wse1 is not None
+        se_saved = (s_in, se_q, se_h, se_g, wse1, wse2) if ctx.has_se else ()
         ctx.save_for_backward(x, z, a2 if a2 is not None else z, s, bn1, bn2, g1, g2, b2, w2, w3,
-                              wsc if wsc is not None else w3, shift_c)
+                              wsc if wsc is not None else w3, shift_c, *se_saved)
         ctx.mark_non_differentiable(stats_out)
         return out, stats_out
 
     @staticmethod
     def backward(ctx, dout, _dstats):
         plan = ctx.plan
-        x, z, a2, s, bn1, bn2, g1, g2, b2, w2, w3, wsc, shift = ctx.saved_tensors
+        x, z, a2, s, bn1, bn2, g1, g2, b2, w2, w3, wsc, shift = ctx.saved_tensors[:13]
+        s_in = se_q = se_h = se_g = wse1 = wse2 = None
+        if ctx.has_se:
+            s_in, se_q, se_h, se_g, wse1, wse2 = ctx.saved_tensors[13:]
+        dwse1 = dwse2 = None
         L = _native.lib()
         dev = x.device
         Fr, Cin, H, W, Cmid, Cout, Ho, Wo = plan.Fr, plan.Cin, plan.H, plan.W, plan.Cmid, plan.Cout, plan.Ho, plan.Wo
@@ -282,8 +300,21 @@ class _FusedTrainBlock(torch.autograd.Function):
                 if need[8]:
                     dw3 = torch.empty_like(w3)
                     ws, nb = wgrad_ws(Cmid, Cout, Po)
-                    _native.check(L.rk_pw_wgrad_f32(dout.data_ptr(), s.data_ptr(), dw3.data_ptr(), Fr, Cmid, Cout, Po,
-                                                    ws.data_ptr(), nb, wg_stream()), "rk_pw_wgrad_f32")
+                    _native.check(L.rk_pw_wgrad_f32(dout.data_ptr(), (s_in if ctx.has_se else s).data_ptr(), dw3.data_ptr(), Fr,
+                                                    Cmid, Cout, Po, ws.data_ptr(), nb, wg_stream()), "rk_pw_wgrad_f32")
+                if ctx.has_se:
+                    # SE backward: ds (so far d(s * gate)) -> d(s) = ds gate + d(squeeze) / HW, d(gate) = sum_hw(ds s) in one
+                    # pass over (ds, s); the two Linear layers and their activations by hand (a few [F, C]-sized kernels)
+                    dsg = torch.empty_like(s)
+                    dgate = torch.empty_like(se_g)
+                    _native.check(L.rk_se_scale_backward_f32(ds.data_ptr(), s.data_ptr(), se_g.data_ptr(), dsg.data_ptr(),
+                                                             dgate.data_ptr(), Fr, Cmid, Po, st), "rk_se_scale_backward_f32")
+                    dpre2 = dgate * se_g * (1.0 - se_g)
+                    dwse2 = dpre2.t() @ se_h
+                    dpre1 = (dpre2 @ wse2) * (se_h > 0).to(dpre2.dtype)
+                    dwse1 = dpre1.t() @ se_q
+                    dq = dpre1 @ wse1
+                    ds = dsg.view(Fr, Cmid, Po).add_((dq / float(Po)).unsqueeze(-1)).view_as(s)
                 # the shift and bn2: d(shift), and d(z) = bn2 + ReLU backward of d(a2).  Fused: the shift backward reads z,
                 # masks its d(x) with the ReLU and reduces bn2's sums in the same launch (dg2, db2, k12); one d(x) pass finishes.
                 N = Fr // plan.T
@@ -373,7 +404,7 @@ class _FusedTrainBlock(torch.autograd.Function):
                 if side is not None:
                     cur.wait_stream(side)                   # always: gradients complete (and the side stream's buffers
                 del keep                                    # released) even when a launch raised in between
-        return (dx, None, dg1, db1, dw2, dg2, db2, dshift, dw3, dwsc if not plan.identity else None, None)
+        return (dx, None, dg1, db1, dw2, dg2, db2, dshift, dw3, dwsc if not plan.identity else None, dwse1, dwse2, None)
 
 
 def fused_train_block(block, x):
@@ -383,8 +414,17 @@ def fused_train_block(block, x):
         return None
     if not (block.training and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
         return None
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0) or block.se is not None:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0):
         return None
+    se1 = se2 = None
+    if block.se is not None:                # the stock SELayer (two bias-free Linear layers, ReLU, Sigmoid) only
+        fc = getattr(block.se, "fc", None)
+        if not (isinstance(fc, torch.nn.Sequential) and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear)
+                and isinstance(fc[1], torch.nn.ReLU) and isinstance(fc[2], torch.nn.Linear)
+                and isinstance(fc[3], torch.nn.Sigmoid) and fc[0].bias is None and fc[2].bias is None
+                and fc[0].weight.dtype == torch.float32 and fc[0].weight.is_cuda):
+            return None
+        se1, se2 = fc[0].weight, fc[2].weight
     cfg = _shift_config(block.as3)
     if cfg is None:
         return None
@@ -411,7 +451,7 @@ def fused_train_block(block, x):
     plan = _Plan(block, x, cfg)
     out, stats_out = _FusedTrainBlock.apply(
         x, stats_in, block.bn1.weight, block.bn1.bias, block.conv2.weight, block.bn2.weight, block.bn2.bias,
-        cfg[0].shift, block.conv3.weight, None if identity else block.shortcut.weight, plan)
+        cfg[0].shift, block.conv3.weight, None if identity else block.shortcut.weight, se1, se2, plan)
     return _attach_stats(out, stats_out)
 
 

@@ -40,21 +40,30 @@ def _reference_block(block, x, dout, T, oracle):
     layer = ref.as3.rubiks3d
     stride = int(layer.stride[1])
     xr = x.detach().cpu().double().requires_grad_(True)
-    a1 = F.relu(ref.bn1(xr))
+    pre1 = ref.bn1(xr)
+    a1 = F.relu(pre1)
     short = xr if isinstance(ref.shortcut, nn.Identity) else ref.shortcut(a1)
-    a2 = F.relu(ref.bn2(ref.conv2(a1)))
+    pre2 = ref.bn2(ref.conv2(a1))
+    a2 = F.relu(pre2)
+    kink = ((pre1.detach().abs() < 1e-4) | (pre2.detach().abs() < 1e-4).any(dim=1, keepdim=True)) \
+        if pre1.shape[2:] == pre2.shape[2:] else None
     Fr, C, H, W = a2.shape
     t = layer.normalize_t_factor
     s = _OracleShift3D.apply(a2.view(Fr // T, T, C, H, W), layer.shift, stride, layer.normalize_grad,
                              T / H if t == "auto" else float(t), oracle)
     s = s.view(Fr, C, s.shape[3], s.shape[4])
+    if ref.se is not None:                                          # the Small tier's gate (stock modules, fp64)
+        s = s * ref.se.fc(s.mean(dim=(2, 3))).view(Fr, C, 1, 1)
     out = ref.conv3(s) + short
     out.backward(dout.detach().cpu().double())
     grads = {n: p.grad for n, p in ref.named_parameters()}
+    # elements whose ReLU sits within 1e-4 of its kink in fp64: there an fp32 evaluation may pick the other side, and d(x)
+    # at the pixel (bn2: every input channel through conv2's d(input); bn1: the element) differs by a whole gradient term
+    ref._near_kink = kink
     return out.detach(), xr.grad, grads, ref
 
 
-def _make_block(cin, cout, stride, T, seed, width=None):
+def _make_block(cin, cout, stride, T, seed, width=None, use_se=False):
     from rubiksnet_amd import RubiksNet
     from rubiksnet_amd.backbone import RubiksShiftBlock
 
@@ -65,8 +74,8 @@ def _make_block(cin, cout, stride, T, seed, width=None):
         normalize_grad = True
         quantize = False
         init_shift = "uniform"
-        use_se = False
 
+    Parent.use_se = use_se
     block = RubiksShiftBlock(cin, cout, stride=stride, parent=Parent())
     from rubiksnet_amd.models import _Rubiks3DWrap
     block.as3 = _Rubiks3DWrap(block.as3, n_segment=T)
@@ -90,15 +99,21 @@ CASES = [
     (54, 54, 1, (1, 8, 28, 28)),        # Tiny's layer2 shape (one clip)
     (72, 144, 2, (1, 8, 56, 56)),       # Large's first layer2 block (one clip): > 128 output rows
     (24, 48, 2, (2, 4, 28, 28)),        # 28 -> 14: output rows of 14 pixels (4-pixel groups wrap rows in the shortcut)
+    (288, 288, 1, (32, 8, 14, 14)),     # Large's layer3 block at the bench's per-GPU batch: 256 frames (the 12-wave GEMM of
+                                        # rk_pw3.hip, 512 statistics tiles per channel, d(weight) over 50 176 pixels)
+]
+SE_CASES = [
+    (24, 24, 1, (2, 4, 14, 14), 12),    # Small-tier block: SE gate after the shift (reduction 12), identity shortcut
+    (36, 72, 2, (2, 4, 28, 28), 12),    # ... downsampling block with a projecting shortcut
 ]
 
 
-@pytest.mark.parametrize("cin,cout,stride,dims", CASES)
-def test_fused_train_block_matches_fp64_reference(oracle, cin, cout, stride, dims):
+@pytest.mark.parametrize("cin,cout,stride,dims,se", [c + (False,) for c in CASES] + SE_CASES)
+def test_fused_train_block_matches_fp64_reference(oracle, cin, cout, stride, dims, se):
     from rubiksnet_amd import train_block
 
     N, T, H, W = dims
-    block = _make_block(cin, cout, stride, T, seed=cin + cout + H)
+    block = _make_block(cin, cout, stride, T, seed=cin + cout + H, use_se=se)
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(N * T, cin, H, W, generator=g) * 1.3 + torch.randn(1, cin, 1, 1, generator=g)).to(DEV)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -120,13 +135,21 @@ def test_fused_train_block_matches_fp64_reference(oracle, cin, cout, stride, dim
 
     K = max(cin, block.conv2.out_channels)
     close(out, out_ref, 4e-6 * K ** 0.5, "out")
-    close(xg.grad, dx_ref, 2e-5 * K ** 0.5, "d(x)")
+    big = N * T * H * W > 20000                # 14.4 M activations: a handful of them sit on a ReLU kink to fp32 round-off
+    dxg = xg.grad
+    if big and ref._near_kink is not None:
+        keep = ~ref._near_kink
+        assert float((~keep).double().mean()) < 0.03
+        dxg = xg.grad.detach().cpu().double() * keep
+        dx_ref = dx_ref * keep
+    close(dxg, dx_ref, 2e-5 * K ** 0.5, "d(x)")
     for name, p in block.named_parameters():
         assert p.grad is not None, name
         if name.endswith("shift"):
             close(p.grad, g_ref[name], 1e-4, name)                    # unit vectors after K5
         else:
-            close(p.grad, g_ref[name], 3e-5 * K ** 0.5, name)
+            # (big: every parameter gradient sums over all elements, flipped kink elements included: 1e-3 class)
+            close(p.grad, g_ref[name], (5e-3 if big else 3e-5 * K ** 0.5), name)
     # nn.BatchNorm2d's bookkeeping: running statistics (unbiased variance) and num_batches_tracked
     for bn, rbn in ((block.bn1, ref.bn1), (block.bn2, ref.bn2)):
         close(bn.running_mean, rbn.running_mean, 1e-5, "running_mean")
