@@ -535,6 +535,61 @@ int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* ru
                        running_var, save_mean, save_invstd, ab, d, eps, momentum, nbt);
     return launch_status();
 }
+// The same map as a FLAT sweep of memory.  The per-channel form above gives a workgroup 8 192 elements of ONE channel, i.e.
+// (at 14 x 14) 42 pieces of 784 bytes 225 KB apart -- tools/stream_pattern_probe.hip: pieces below ~6 KB collapse the
+// achieved bandwidth -- although nothing here needs a channel to itself: the map is elementwise with per-channel
+// constants.  Here a workgroup owns 8 192 CONTIGUOUS elements (32 KB of every tensor; consecutive lanes, consecutive
+// 16-byte cells), and the constants of the <= 8 192 / P + 2 planes it touches sit in LDS, indexed by plane.
+// Same expression per element: bit-identical to k_bn_bwd_dx_pre.
+constexpr int kFlatElems = 8192;
+constexpr int kFlatPlanes = 2048;          // planes of P >= 4 elements a chunk can touch, + 1
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre_flat(const T* __restrict__ dz, const T* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                               const float* __restrict__ save_invstd, const float* __restrict__ k12,
+                                                               const T* __restrict__ skip, T* __restrict__ dx, int C, int P,
+                                                               long long total) {
+    __shared__ float4 coef[kFlatPlanes + 2];               // (mean, invstd, a, k1) ... and k2 in a second table
+    __shared__ float coef2[kFlatPlanes + 2];
+    const long long e0 = (long long)blockIdx.x * kFlatElems;
+    const long long plane0 = e0 / P;                        // first (frame, channel) plane of the chunk
+    long long eend = e0 + kFlatElems;
+    eend = eend < total ? eend : total;
+    const int nplanes = (int)((eend - 1) / P - plane0) + 1;
+    for (int i = threadIdx.x; i < nplanes; i += kBlock) {
+        const int c = (int)((plane0 + i) % C);
+        const float invstd = save_invstd[c];
+        coef[i] = make_float4(save_mean[c], invstd, gamma[c] * invstd, k12[c]);
+        coef2[i] = k12[C + c];
+    }
+    __syncthreads();
+    const int r0 = (int)(e0 - plane0 * P);                  // offset of the chunk inside its first plane
+#pragma unroll 4
+    for (int u = 0; u < kFlatElems / (4 * kBlock); ++u) {
+        const int rel = 4 * ((int)threadIdx.x + kBlock * u);
+        const long long e = e0 + rel;
+        if (e >= eend) break;
+        const int li = (r0 + rel) / P;                      // plane of this cell (P % 4 == 0: a cell never straddles planes)
+        const float4 cf = coef[li];
+        const float k2 = coef2[li];
+        float xv[4], gv[4];
+        Pack<T, 4>::load(x + e, xv);
+        Pack<T, 4>::load(dz + e, gv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (xv[q] - cf.x) * cf.y;
+            gv[q] = cf.z * (gv[q] - cf.w - xh * k2);
+        }
+        if (skip) {
+            float sv[4];
+            Pack<T, 4>::load(skip + e, sv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gv[q] += sv[q];
+        }
+        Pack<T, 4>::store(dx + e, gv);
+    }
+}
+
 template <typename T>
 int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save_mean, const float* save_invstd,
                   const float* k12, const T* skip, T* dx, int F, int C, int P, rk_stream_t stream) {
@@ -543,6 +598,12 @@ int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save
     if (int rc = make_bn(d, F, C, P)) return rc;
     const dim3 grid(grid_bn(d)), block(kBlock);
     const bool v4 = vec4_ok<T>(d, x, dz, dx) && !((uintptr_t)skip & (4 * sizeof(T) - 1));
+    const long long total = (long long)F * C * P;
+    if (v4 && kFlatElems / P + 2 <= kFlatPlanes) {
+        hipLaunchKernelGGL((k_bn_bwd_dx_pre_flat<T>), dim3((unsigned)((total + kFlatElems - 1) / kFlatElems)), block, 0,
+                           (hipStream_t)stream, dz, x, gamma, save_mean, save_invstd, k12, skip, dx, C, P, total);
+        return launch_status();
+    }
     if (v4) hipLaunchKernelGGL((k_bn_bwd_dx_pre<T, 4>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
                                save_invstd, k12, skip, dx, d);
     else hipLaunchKernelGGL((k_bn_bwd_dx_pre<T, 1>), grid, block, 0, (hipStream_t)stream, dz, x, gamma, save_mean,
