@@ -118,7 +118,7 @@ if what == "one":            # one case, e.g.: one gemm 256 288 288 196 1 rb am 
     if sys.argv[2] == "gemm":
         gemm_case(a[0], a[1], a[2], a[3], a[4], cfgs=((a[5], a[6], a[7]),))
     else:
-        wgrad_case(a[0], a[1], a[2], a[3], cfgs=((a[4], a[5], a[6]),))
+        wgrad_case(a[0], a[1], a[2], a[3], cfgs=((a[4], a[5] if a[5] > 0 else 0, a[6]),))
 if what in ("gemm", "all"):
     gemm_case(256, 288, 288, 196, 1, cfgs=((0, -1, 0), (3, -1, 1), (4, -1, 1), (5, -1, 1), (3, 2, 1)))
     gemm_case(256, 288, 288, 196, 0, cfgs=((0, -1, 0), (4, -1, 1), (5, -1, 1)))
