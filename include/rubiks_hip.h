@@ -389,6 +389,14 @@ int rk_pw_gemm_tiles(const float* A, int F, int K, int M, int P, int a_is_mk);
  * tile instance (rk_pw2.hip kWInst), stages: LDS ring depth (2, 3), splits: pixel splits.  RK_ERR_UNSUPPORTED: no instance. */
 int rk_pw2_gemm_cfg_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P, int a_is_mk,
                         const float* ka, const float* kb, int relu_in, int rb, int amode, int ct, rk_stream_t stream);
+/* rk_pw4.hip: the streaming GEMM of the shallow layers (54 -> 54 / 72 -> 72 channels; operand in registers, everything else
+ * through a per-wave LDS-DMA record ring) regardless of the size threshold of the dispatch -- test / probe hook.
+ * epi 0: Y = A relu?(ka x + kb)(X) (+ R); 1: + statistics tiles (stats [M][tiles] float4, as rk_pw_gemm_stats_f32);
+ * 2: the BatchNorm-backward epilogue of rk_pw_gemm_bnbwd_f32 (bx, bpack [M][4], bred [M][tiles] float2); tiles =
+ * ceil(F P / 64).  RK_ERR_UNSUPPORTED: no instance for (K, M). */
+int rk_pw4_gemm_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P, int a_is_mk,
+                    const float* ka, const float* kb, int relu_in, int epi, void* stats, const float* bx, const float* bpack,
+                    void* bred, int tiles, rk_stream_t stream);
 size_t rk_pw2_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw2_wgrad_cfg_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
                          const float* ka, const float* kb, int relu_in, int inst, int stages, int splits, rk_stream_t stream);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "rk_pw_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     # second-generation fp32 kernels (rk_pw2.hip): tuning / test hooks with an explicit kernel configuration
     "rk_pw2_gemm_cfg_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_pw4_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p]),
     "rk_pw2_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_pw2_wgrad_cfg_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p, _p, _i, _i, _i, _i, _p]),
     "rk_pw_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),

@@ -18,8 +18,10 @@
 #include <type_traits>
 #include "rk_common.hpp"
 #include "rk3d_generic.hpp"
+#include <cstdio>
 #include "rk_pw2.hpp"
 #include "rk_pw3.hpp"
+#include "rk_pw4.hpp"
 
 namespace rk {
 namespace pw {
@@ -1359,6 +1361,10 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0 || K % 2 != 0) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)X & am) || ((uintptr_t)Y & am)) return RK_ERR_BAD_DIMS;
     if constexpr (std::is_same<T, float>::value) {
+        static const bool trace = getenv("RK_PW_TRACE") != nullptr;      // debugging aid: one line per call
+        if (trace) fprintf(stderr, "pw_gemm F=%d K=%d M=%d P=%d mk=%d epi=%d R=%d pro=%d outaff=%d p3=%d p4=%d p2=%d\n", F, K, M, P, a_is_mk, epi,
+                           R != nullptr, fuse && fuse->ka, fuse && fuse->ma, pw3::tiles(F, K, M, P), (int)pw4::tiles(F, K, M, P, epi, false),
+                           (int)pw2::gemm_wanted(K, M, P, a_is_mk, A));
         // second generation (rk_pw2.hip) where it is ahead; its training epilogues use 64-column tiles
         // (rk_pw_gemm_tiles() tells the caller which count to allocate)
         // third kernel (rk_pw3.hip): the LDS-tiled GEMM of the 288-row layers, one workgroup per CU
@@ -1368,6 +1374,16 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
             const pw2::GTrain t3 = train ? pw2::GTrain{train->stats, train->bred, train->bx, train->bpack, train->J}
                                          : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};
             const int rc = pw3::gemm(A, X, R, Y, F, K, M, P, a_is_mk, &f3, &t3, epi, (hipStream_t)stream_);
+            if (rc != RK_ERR_UNSUPPORTED || epi) return rc;
+        }
+        // streaming kernel of the shallow layers (rk_pw4.hip): operand in registers, records through a per-wave LDS ring;
+        // its tile records are the 64-column ones of rk_pw2.hip
+        if (pw4::tiles(F, K, M, P, epi, false) > 0 && !(fuse && fuse->ma) && !(epi == 2 && R)) {
+            const pw2::GFuse f4 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, nullptr, nullptr, fuse->relu_in, 0}
+                                       : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
+            const pw2::GTrain t4 = train ? pw2::GTrain{train->stats, train->bred, train->bx, train->bpack, train->J}
+                                         : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};
+            const int rc = pw4::gemm(A, X, R, Y, F, K, M, P, a_is_mk, &f4, &t4, epi, (hipStream_t)stream_, false);
             if (rc != RK_ERR_UNSUPPORTED || epi) return rc;
         }
         if (pw2::gemm_wanted(K, M, P, a_is_mk, A)) {
@@ -1769,6 +1785,8 @@ int rk_pw_gemm_tiles(const float* A, int F, int K, int M, int P, int a_is_mk) {
         const int t3 = pw3::tiles(F, K, M, P);
         if (t3 > 0) return t3;
     }
+    const long long t4 = pw4::tiles(F, K, M, P, 1, false);       // (same policy for both training epilogues; 64-column tiles)
+    if (t4 > 0) return (int)t4;
     const int w = pw2::gemm_wanted(K, M, P, a_is_mk, A) ? pw2::kTileCols : 128;
     return (int)(((long long)F * P + w - 1) / w);
 }
