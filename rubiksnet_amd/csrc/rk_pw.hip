@@ -1363,7 +1363,7 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
     if constexpr (std::is_same<T, float>::value) {
         static const bool trace = getenv("RK_PW_TRACE") != nullptr;      // debugging aid: one line per call
         if (trace) fprintf(stderr, "pw_gemm F=%d K=%d M=%d P=%d mk=%d epi=%d R=%d pro=%d outaff=%d p3=%d p4=%d p2=%d\n", F, K, M, P, a_is_mk, epi,
-                           R != nullptr, fuse && fuse->ka, fuse && fuse->ma, pw3::tiles(F, K, M, P), (int)pw4::tiles(F, K, M, P, epi, false),
+                           R != nullptr, fuse && fuse->ka, fuse && fuse->ma, pw3::tiles(F, K, M, P), (int)pw4::tiles(F, K, M, P, epi, R != nullptr, false),
                            (int)pw2::gemm_wanted(K, M, P, a_is_mk, A));
         // second generation (rk_pw2.hip) where it is ahead; its training epilogues use 64-column tiles
         // (rk_pw_gemm_tiles() tells the caller which count to allocate)
@@ -1378,7 +1378,7 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
         }
         // streaming kernel of the shallow layers (rk_pw4.hip): operand in registers, records through a per-wave LDS ring;
         // its tile records are the 64-column ones of rk_pw2.hip
-        if (pw4::tiles(F, K, M, P, epi, false) > 0 && !(fuse && fuse->ma) && !(epi == 2 && R)) {
+        if (pw4::tiles(F, K, M, P, epi, R != nullptr, false) > 0 && !(fuse && fuse->ma) && !(epi == 2 && R)) {
             const pw2::GFuse f4 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, nullptr, nullptr, fuse->relu_in, 0}
                                        : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
             const pw2::GTrain t4 = train ? pw2::GTrain{train->stats, train->bred, train->bx, train->bpack, train->J}
@@ -1785,7 +1785,9 @@ int rk_pw_gemm_tiles(const float* A, int F, int K, int M, int P, int a_is_mk) {
         const int t3 = pw3::tiles(F, K, M, P);
         if (t3 > 0) return t3;
     }
-    const long long t4 = pw4::tiles(F, K, M, P, 1, false);       // (same policy for both training epilogues; 64-column tiles)
+    // (the streaming kernel's records are 64-column ones like rk_pw2.hip's; where it takes only some of a shape's epilogues,
+    // rk_pw2.hip takes the others with the same count -- except the [M][K] 54-channel layers, which it takes entirely)
+    const long long t4 = pw4::tiles(F, K, M, P, 1, 0, false);
     if (t4 > 0) return (int)t4;
     const int w = pw2::gemm_wanted(K, M, P, a_is_mk, A) ? pw2::kTileCols : 128;
     return (int)(((long long)F * P + w - 1) / w);

@@ -66,13 +66,14 @@ template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn&& fn
     }
 }
 
-constexpr int kWaves = 4;                            // waves per workgroup (independent of each other)
+constexpr int waves_of(bool ALDS) { return ALDS ? 8 : 4; }     // waves per workgroup (independent of each other but for the A table)
 
 // Stores CERTAINLY issued (as wave instructions) in the slots a .. b of the record stream, slot 0 = the current tile's first
 // (negative: the previous tile's; `first`: those do not exist).  A slot's stores follow its DMA.  Row blocks below the
 // last one always hold rows (< M) and every tile in range has a valid column, so each of their rows issues `ns` stores;
 // the last row block is not counted (fewer = a stricter wait).  NE == 0: all of a tile's stores follow slot NRT - 1.
-constexpr int certain_stores(int a, int b, bool first, int NRT, int NST, int RB, int ns, bool ne0) {
+constexpr int certain_stores(int a, int b, bool first, int NRT, int NST, int NE, int RB, int ns) {
+    const bool ne0 = NE == 0;
     int n = 0;
     for (int u = a; u <= b; ++u) {
         int uu = u;
@@ -81,37 +82,62 @@ constexpr int certain_stores(int a, int b, bool first, int NRT, int NST, int RB,
             uu = u + NRT;
         }
         if (ne0) n += uu == NRT - 1 ? 4 * (RB - 1) * ns : 0;
-        else if (uu >= NST && (uu - NST) / 4 < RB - 1) n += ns;
+        else if (uu >= NST && uu < NST + NE && (uu - NST) / 4 < RB - 1) n += ns;
     }
     return n;
 }
-constexpr int nrec_of(int NRT) {                     // ring records per wave: the largest divisor of NRT up to 19 (LDS: 2 x 4 x 19 KB)
-    for (int n = 19; n >= 2; --n)
-        if (NRT % n == 0) return n;
+// Ring geometry: NREC slots with NREC | NRT, so that record s of a tile always sits in slot s % NREC (immediate LDS
+// offsets, no slot counter).  maxrec bounds the ring by the LDS budget; when NRT has no divisor in [8, maxrec] the tile is
+// padded with dummy records (a 1 KB re-read of the head of X, ignored) until it has one.
+constexpr int best_div(int n, int maxrec) {
+    for (int dd = maxrec; dd >= 2; --dd)
+        if (n % dd == 0) return dd;
     return 1;
 }
+constexpr int pad_of(int n, int maxrec) {
+    for (int p = 0; p < 8; ++p)
+        if (best_div(n + p, maxrec) >= 8) return p;
+    return 0;
+}
+constexpr int maxrec_of(bool ALDS) { return ALDS ? 17 : 19; }       // 8 x 17 KB + 23 KB table / 2 x 4 x 19 KB
 
 // RB row blocks of 16, NST k-steps of 4 (A zero-padded to 16 RB x 4 NST in registers).
 // PRO: B operands pass through relu?(ka[k] x + kb[k]).  EPI 0 / 1 (statistics tiles) / 2 (BatchNorm-backward mask + sums,
 // x by records).  RES: + R (by records).
-template <int RB, int NST, bool PRO, int EPI, bool RES>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_pw4_gemm(const float* __restrict__ A, const float* __restrict__ X,
+// ALDS: the small operand in an LDS table shared by the workgroup's 8 waves instead of registers, fragment-major
+// ([rb][st][lane]: one conflict-free ds_read_b32 per row block and k-step, requested one slot ahead) -- for the instances
+// whose operand + accumulators + epilogue do not fit 256 registers (72 channels with a training epilogue: 90 + 80 + ...).
+template <int RB, int NST, bool PRO, int EPI, bool RES, bool ALDS>
+__global__ __launch_bounds__(64 * waves_of(ALDS), ALDS ? 1 : 2) void k_pw4_gemm(const float* __restrict__ A, const float* __restrict__ X,
                                                              const float* __restrict__ R, float* __restrict__ Y, Dims d,
                                                              pw2::GFuse fz, pw2::GTrain tr) {
     static_assert(!(EPI == 2 && (RES || PRO)), "no such instance");
     constexpr int NE = (EPI == 2 || RES) ? 4 * RB : 0;           // epilogue records per tile
-    constexpr int NRT = NST + NE;                                // records per tile
-    constexpr int NREC = nrec_of(NRT);                           // ring slots; NREC | NRT: record s of a tile sits in slot s % NREC
+    constexpr int NPAD = pad_of(NST + NE, maxrec_of(ALDS));      // dummy records per tile
+    constexpr int NRT = NST + NE + NPAD;                         // records per tile
+    constexpr int NREC = best_div(NRT, maxrec_of(ALDS));         // ring slots; NREC | NRT: record s of a tile sits in slot s % NREC
     constexpr int LOOK = NREC - 1;                               // DMAs in flight behind the record being consumed
     constexpr int NS = EPI == 0 ? 1 : 2;                         // stores per output row
     static_assert(LOOK >= 2 && LOOK <= NRT, "ring");
+    constexpr int kWaves = waves_of(ALDS);
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
     float* ring = lds_f + wave * (NREC * 256);
     float2* Ks = reinterpret_cast<float2*>(lds_f + kWaves * NREC * 256);              // [4 NST] (ka, kb)
     float4* Bp = reinterpret_cast<float4*>(lds_f + kWaves * NREC * 256 + 8 * NST);    // [16 RB] (a, b, mean, invstd)
+    float* At = lds_f + kWaves * NREC * 256 + 8 * NST + 64 * RB;                      // ALDS: [RB][NST][64] fragments
     const int K = d.K, M = d.M, P = d.P;
+    if constexpr (ALDS) {
+        for (int e = threadIdx.x; e < RB * NST * 64; e += 64 * kWaves) {
+            const int l = e & 63, fs = e >> 6, st = fs % NST, rb = fs / NST;
+            const int m = 16 * rb + (l & 15), k = 4 * st + (l >> 4);
+            const bool ok = m < M && k < K;
+            const size_t at = d.a_is_mk ? (size_t)m * K + k : (size_t)k * M + m;
+            const float v = A[ok ? at : 0];
+            At[e] = ok ? v : 0.f;
+        }
+    }
     if constexpr (PRO) {
         for (int e = threadIdx.x; e < 4 * NST; e += 64 * kWaves)
             Ks[e] = e < K ? make_float2(fz.ka[e], fz.kb[e]) : make_float2(0.f, 0.f);
@@ -119,7 +145,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_pw4_gemm(const float* __rest
     if constexpr (EPI == 2) {
         for (int e = threadIdx.x; e < 16 * RB; e += 64 * kWaves) Bp[e] = tr.bpack[e < M ? e : M - 1];
     }
-    if constexpr (PRO || EPI == 2) __syncthreads();
+    if constexpr (PRO || EPI == 2 || ALDS) __syncthreads();
 
     // this wave's tiles: gw, gw + nwv, gw + 2 nwv, ... -- at any moment the chip works on one contiguous span of nwv tiles
     // (256 B x nwv of every row: DRAM pages stay open); contiguous per-wave ranges scatter 256-byte pieces over the whole
@@ -166,7 +192,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_pw4_gemm(const float* __rest
         constexpr int ri = decltype(RIc)::value;
         if constexpr (ri == 0) enter_tile();
         const float* src;
-        if constexpr (ri < NST) {
+        if constexpr (ri >= NST + NE) {
+            src = X + lane * 4;                       // padding record (host: X holds >= 256 floats)
+        } else if constexpr (ri < NST) {
             src = ri == NST - 1 ? xp + xfix : xp;
             xp += 4 * (size_t)P;
         } else {
@@ -195,17 +223,26 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_pw4_gemm(const float* __rest
     size_t yo_c = yo_next, yo_next_c = yo_next;       // consumer's tile, and its successor's
 
     // the small operand, once (behind the first records' DMAs): a[rb][st] = A[16 rb + j][4 st + kq] (zero outside)
-    float a[RB][NST];
+    float a[ALDS ? 1 : RB][ALDS ? 1 : NST];
+    if constexpr (!ALDS) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int st = 0; st < NST; ++st) {
-            const int m = 16 * rb + j, k = 4 * st + kq;
-            const bool ok = m < M && k < K;
-            const size_t at = d.a_is_mk ? (size_t)m * K + k : (size_t)k * M + m;
-            const float v = A[ok ? at : 0];
-            a[rb][st] = ok ? v : 0.f;
-        }
+            for (int st = 0; st < NST; ++st) {
+                const int m = 16 * rb + j, k = 4 * st + kq;
+                const bool ok = m < M && k < K;
+                const size_t at = d.a_is_mk ? (size_t)m * K + k : (size_t)k * M + m;
+                const float v = A[ok ? at : 0];
+                a[rb][st] = ok ? v : 0.f;
+            }
+    }
+    float acur[RB];                                   // ALDS: the fragments of the k-step consumed next
+    auto read_a = [&](auto STc, float (&dst)[RB]) {
+        constexpr int st = decltype(STc)::value;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) dst[rb] = At[(rb * NST + st) * 64 + lane];
+    };
+    if constexpr (ALDS) read_a(std::integral_constant<int, 0>{}, acur);
 
     // Record s is READ one slot early (under the MFMAs of record s - 1): two waves of a SIMD run the same instruction stream
     // in phase, so an LDS round trip at the head of every 20-MFMA batch is paid by both at once (measured: the MFMA-only
@@ -275,11 +312,13 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_pw4_gemm(const float* __rest
             // covers the stores exposes the loaded write latency once per tile while the reads drain).
             issue(std::integral_constant<int, (s + LOOK) % NRT>{});
             if constexpr ((s + LOOK) % NRT == 0) yo_next_c = yo_next;         // (the producer entered the consumer's next tile)
-            constexpr int W = (LOOK - 1) + certain_stores(s + 1 - LOOK, s - 1, FIRST, NRT, NST, RB, NS, NE == 0);
+            constexpr int W = (LOOK - 1) + certain_stores(s + 1 - LOOK, s - 1, FIRST, NRT, NST, NE, RB, NS);
             static_assert(W <= 63, "vmcnt is 6 bits");
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");
             const f32x4 vnext = read_rec(std::integral_constant<int, (s + 1) % NRT>{});
             const f32x4 v = vcur;
+            float anext[RB];
+            if constexpr (ALDS && ((s + 1) % NRT) < NST) read_a(std::integral_constant<int, (s + 1) % NRT>{}, anext);
             if constexpr (s < NST) {
                 float b[4] = {v[0], v[1], v[2], v[3]};
                 if constexpr (PRO) {
@@ -294,12 +333,16 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_pw4_gemm(const float* __rest
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        acc[rb][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], b[q], acc[rb][q], 0, 0, 0);
-            } else {
+                        acc[rb][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ALDS ? acur[rb] : a[ALDS ? 0 : rb][ALDS ? 0 : s], b[q], acc[rb][q], 0, 0, 0);
+            } else if constexpr (s < NST + NE) {
                 constexpr int e = s - NST;
                 finish_row(std::integral_constant<int, e / 4>{}, std::integral_constant<int, e % 4>{}, v);
             }
             vcur = vnext;
+            if constexpr (ALDS && ((s + 1) % NRT) < NST) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acur[rb] = anext[rb];
+            }
         });
         if constexpr (NE == 0) {
             static_for<4 * RB>([&](auto Ec) {
@@ -344,21 +387,26 @@ constexpr long long kMinTiles = 4096;                // below: rk_pw2.hip (more,
 template <int RB, int NST, bool PRO, int EPI, bool RES>
 int launch(const float* A, const float* X, const float* R, float* Y, const Dims& d, const pw2::GFuse& fz, const pw2::GTrain& tr,
            hipStream_t stream) {
+    constexpr bool ALDS = RB == 5 && EPI != 0;        // (the 72-channel instance with a training epilogue: see the kernel)
     constexpr int NE = (EPI == 2 || RES) ? 4 * RB : 0;
-    constexpr int NREC = nrec_of(NST + NE);
-    constexpr int wgs_per_cu = 2;
-    const size_t lds = (size_t)kWaves * NREC * 1024 + 8 * NST * sizeof(float) + 16 * RB * sizeof(float4);
+    constexpr int NREC = best_div(NST + NE + pad_of(NST + NE, maxrec_of(ALDS)), maxrec_of(ALDS));
+    constexpr int kWaves = waves_of(ALDS);
+    if ((long long)d.F * d.K * d.P < 256) return RK_ERR_UNSUPPORTED;
+    constexpr int wgs_per_cu = ALDS ? 1 : 2;
+    const size_t lds = (size_t)kWaves * NREC * 1024 + 8 * NST * sizeof(float) + 16 * RB * sizeof(float4) +
+                       (ALDS ? (size_t)RB * NST * 256 : 0);
+    if (lds > 160 * 1024) return RK_ERR_UNSUPPORTED;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw4_gemm<RB, NST, PRO, EPI, RES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw4_gemm<RB, NST, PRO, EPI, RES, ALDS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RK_ERR_LAUNCH;
         raised = true;
     }
     long long wgs = (long long)num_cus() * wgs_per_cu;
     const long long need = (d.ntiles + kWaves - 1) / kWaves;
     wgs = wgs < need ? wgs : need;
-    hipLaunchKernelGGL((k_pw4_gemm<RB, NST, PRO, EPI, RES>), dim3((unsigned)wgs), dim3(64 * kWaves), lds, stream, A, X, R, Y, d, fz,
-                       tr);
+    hipLaunchKernelGGL((k_pw4_gemm<RB, NST, PRO, EPI, RES, ALDS>), dim3((unsigned)wgs), dim3(64 * kWaves), lds, stream, A, X, R, Y, d,
+                       fz, tr);
     return launch_status();
 }
 template <int RB, int NST>
@@ -378,10 +426,11 @@ int launch_flags(int pro, int epi, int res, const float* A, const float* X, cons
 #undef RK_P4
 }
 
-// epi: the epilogue the call will carry.  The 72-channel instance (90 + 80 registers of operand + accumulators) is at the
-// 256-VGPR limit of two waves per SIMD: its training epilogues spill and lose to rk_pw2.hip (178 / 188 / 176 us against
-// 151 / 161 / 169 at [256, 72 -> 72, 56 x 56]); plain and + R win (108-112 / 143 against 124 / 149).
-long long tiles(int F, int K, int M, int P, int epi, bool force) {
+// epi / res: the epilogue the call will carry.  The 72-channel instance keeps its operand in registers (90 + 80 registers of
+// operand + accumulators: the 256-VGPR limit of two waves per SIMD) for plain / + R calls and in an LDS table for the
+// training epilogues; statistics + residual (38 records per tile) measured level with rk_pw2.hip (161 / 601 us against
+// 160 / 591 at [256, 72 -> 72, 56 x 56 / 112 x 112]) and stays there.
+long long tiles(int F, int K, int M, int P, int epi, int res, bool force) {
     if (F <= 0 || K <= 0 || M <= 0 || P <= 0 || P % 4 != 0 || (long long)F * P >= (1ll << 31)) return 0;
     if (mode() == 0) return 0;
     Inst in;
@@ -389,7 +438,7 @@ long long tiles(int F, int K, int M, int P, int epi, bool force) {
     const long long nt = ((long long)F * P + 63) / 64;
     if (!force && mode() != 2) {
         if (nt < kMinTiles) return 0;
-        if (in.rb == 5 && epi != 0) return 0;
+        if (in.rb == 5 && epi == 1 && res) return 0;
     }
     return nt;
 }
@@ -401,7 +450,7 @@ int gemm(const float* A, const float* X, const float* R, float* Y, int F, int K,
     if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15) || (R && ((uintptr_t)R & 15))) return RK_ERR_BAD_DIMS;
     Inst in;
     if (!pick(in, K, M)) return RK_ERR_UNSUPPORTED;
-    if (tiles(F, K, M, P, epi, force) <= 0) return RK_ERR_UNSUPPORTED;
+    if (tiles(F, K, M, P, epi, R != nullptr, force) <= 0) return RK_ERR_UNSUPPORTED;
     pw2::GFuse fz = fuse ? *fuse : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
     pw2::GTrain tr = train ? *train : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};
     if (fz.ma) return RK_ERR_UNSUPPORTED;

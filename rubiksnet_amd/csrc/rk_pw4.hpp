@@ -7,8 +7,8 @@ namespace rk {
 namespace pw4 {
 
 // > 0: the number of 64-column statistics tiles the kernel writes for this shape (= it will take a call with epilogue
-// `epi`); 0: not taken.  force: ignore the size / epilogue policy (tests, probes)
-long long tiles(int F, int K, int M, int P, int epi, bool force);
+// `epi`, with a residual or not); 0: not taken.  force: ignore the size / epilogue policy (tests, probes)
+long long tiles(int F, int K, int M, int P, int epi, int res, bool force);
 // Y[f] = epi(A pro(X[f])) (+ R[f]); RK_ERR_UNSUPPORTED when the shape has no instance (the caller falls back)
 int gemm(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P, int a_is_mk, const pw2::GFuse* fuse,
          const pw2::GTrain* train, int epi, hipStream_t stream, bool force);
