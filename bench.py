@@ -248,15 +248,16 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_* at 64 FLOP/clk/SIMD x 1024 SIMDs x
 
 def pw32_bench(env, iters=30, settle_s=0.2):
     """The fp32 1x1 convolution kernels (rk_pw.hip / rk_pw2.hip behind the public entry points, whichever the dispatch
-    picks) on the layer 70 of RubiksNet-Large's 102 convolutions have, [256, 288 -> 288, 14, 14], and on the 28x28 stage's
-    [256, 144 -> 144, 28, 28]: forward, forward + residual + the next BatchNorm's tile statistics (conv3 of a fused
+    picks) on the layer 70 of RubiksNet-Large's 102 convolutions have, [256, 288 -> 288, 14, 14], on the 28x28 stage's
+    [256, 144 -> 144, 28, 28], and on the shallow 56x56 layers of Tiny / Large ([256, 54 -> 54], [256, 72 -> 72]: the
+    streaming kernel of rk_pw4.hip; as loaded on HBM as on the matrix pipe, so both fractions are reported): forward, forward + residual + the next BatchNorm's tile statistics (conv3 of a fused
     training block), d(input), d(weight).  MFMA-bound at fp32: fraction of the 157.3 TFLOP/s f32 MFMA peak."""
     from rubiksnet_amd import _native
     L = _native.lib()
     dev = env.device
     stream = torch.cuda.current_stream(dev).cuda_stream
     out = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "dtype": "f32 in, f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)"}
-    for Fr, K, M, H in ((256, 288, 288, 14), (256, 144, 144, 28)):
+    for Fr, K, M, H in ((256, 288, 288, 14), (256, 144, 144, 28), (256, 54, 54, 56), (256, 72, 72, 56)):
         P = H * H
         sets = [(torch.randn(Fr, K, P, device=dev), torch.randn(Fr, M, P, device=dev), torch.empty(Fr, M, P, device=dev),
                  torch.empty(Fr, K, P, device=dev)) for _ in range(2)]
@@ -291,9 +292,13 @@ def pw32_bench(env, iters=30, settle_s=0.2):
                           "wgrad")
         flop = 2.0 * Fr * P * K * M
         leg = {"layer": [Fr, K, M, H, H], "GFLOP": flop / 1e9}
+        # the shallow layers (54 / 72 channels on 56 x 56: rk_pw4.hip) load HBM as much as the matrix pipe: both fractions
+        e = 4.0 * Fr * P
+        hbm = {"fwd": e * (K + M), "fwd_residual_stats": e * (K + 2 * M), "dgrad": e * (K + M), "wgrad": e * (K + M)}
         for name, fn in (("fwd", fwd), ("fwd_residual_stats", fwd_res_stats), ("dgrad", dgrad), ("wgrad", wgrad)):
             t = _steady(fn, iters, settle_s)
-            leg[name] = {"us": t * 1e6, "TFLOPs": flop / t / 1e12, "frac_of_mfma_peak": flop / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
+            leg[name] = {"us": t * 1e6, "TFLOPs": flop / t / 1e12, "frac_of_mfma_peak": flop / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "frac_of_hbm_peak": hbm[name] / t / 1e9 / HBM_PEAK_GBS}
         out["%dx%d_%dch" % (H, H, K)] = leg
         del sets, ws
     return out
