@@ -5,7 +5,9 @@ tag=${1:-r02}
 cd "$(dirname "$0")/.."
 python tools/make_profile_summary.py ${tag} gpurun_out/${tag}_op gpurun_out/${tag}_pmc3d > /dev/null
 python tools/make_profile_summary.py ${tag}_tile14 "gpurun_out/${tag}_small_32,8,288,14,14" gpurun_out/${tag}_pmc_tile > /dev/null
-python tools/make_profile_summary.py ${tag}_7x7 "gpurun_out/${tag}_small_32,8,576,7,7" > /dev/null
+if [ -d gpurun_out/${tag}_pmc_7x7 ]; then python tools/make_profile_summary.py ${tag}_7x7 "gpurun_out/${tag}_small_32,8,576,7,7" gpurun_out/${tag}_pmc_7x7 > /dev/null
+else python tools/make_profile_summary.py ${tag}_7x7 "gpurun_out/${tag}_small_32,8,576,7,7" > /dev/null; fi
+[ -d gpurun_out/${tag}_s2b ] && python tools/make_profile_summary.py ${tag}_stride2_28to14 gpurun_out/${tag}_s2b gpurun_out/${tag}_pmc_s2b > /dev/null
 python tools/make_profile_summary.py ${tag}_stride2 gpurun_out/${tag}_s2 gpurun_out/${tag}_pmc_s2 > /dev/null
 python tools/make_profile_summary.py ${tag}_2d_f32 - gpurun_out/${tag}_pmc2d_f32 > /dev/null
 python tools/make_profile_summary.py ${tag}_2d_bf16 - gpurun_out/${tag}_pmc2d_bf16 > /dev/null
