@@ -1378,8 +1378,8 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
         }
         // streaming kernel of the shallow layers (rk_pw4.hip): operand in registers, records through a per-wave LDS ring;
         // its tile records are the 64-column ones of rk_pw2.hip
-        if (pw4::tiles(F, K, M, P, epi, R != nullptr, false) > 0 && !(fuse && fuse->ma) && !(epi == 2 && R)) {
-            const pw2::GFuse f4 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, nullptr, nullptr, fuse->relu_in, 0}
+        if (pw4::tiles(F, K, M, P, epi, R != nullptr, false) > 0 && !(epi && fuse && fuse->ma) && !(epi == 2 && R)) {
+            const pw2::GFuse f4 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, fuse->ma, fuse->mb, fuse->relu_in, fuse->relu_out}
                                        : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
             const pw2::GTrain t4 = train ? pw2::GTrain{train->stats, train->bred, train->bx, train->bpack, train->J}
                                          : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};

@@ -145,7 +145,14 @@ __global__ __launch_bounds__(64 * waves_of(ALDS), ALDS ? 1 : 2) void k_pw4_gemm(
     if constexpr (EPI == 2) {
         for (int e = threadIdx.x; e < 16 * RB; e += 64 * kWaves) Bp[e] = tr.bpack[e < M ? e : M - 1];
     }
-    if constexpr (PRO || EPI == 2 || ALDS) __syncthreads();
+    const bool outaff = EPI == 0 && fz.ma != nullptr;       // inference: Y = relu?(ma[m] (A X) + mb[m]) (+ R) (wave-uniform)
+    if (outaff) {
+        for (int e = threadIdx.x; e < 16 * RB; e += 64 * kWaves) {
+            const int m = e < M ? e : M - 1;
+            Bp[e] = make_float4(fz.ma[m], fz.mb[m], 0.f, 0.f);
+        }
+    }
+    if (PRO || EPI == 2 || ALDS || outaff) __syncthreads();
 
     // this wave's tiles: gw, gw + nwv, gw + 2 nwv, ... -- at any moment the chip works on one contiguous span of nwv tiles
     // (256 B x nwv of every row: DRAM pages stay open); contiguous per-wave ranges scatter 256-byte pieces over the whole
@@ -268,6 +275,13 @@ __global__ __launch_bounds__(64 * waves_of(ALDS), ALDS ? 1 : 2) void k_pw4_gemm(
             const bool live = rb < RB - 1 || m < M;
             const bool on = valid && live;
             float4 o = make_float4(acc[rb][0][r], acc[rb][1][r], acc[rb][2][r], acc[rb][3][r]);
+            if constexpr (EPI == 0) {
+                if (outaff) {
+                    const float4 pk = Bp[16 * rb + 4 * kq + r];
+                    o.x = fmaf(pk.x, o.x, pk.y); o.y = fmaf(pk.x, o.y, pk.y); o.z = fmaf(pk.x, o.z, pk.y); o.w = fmaf(pk.x, o.w, pk.y);
+                    if (fz.relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                }
+            }
             if constexpr (RES) { o.x += ev[0]; o.y += ev[1]; o.z += ev[2]; o.w += ev[3]; }
             if constexpr (EPI == 0) {
                 if (on) *reinterpret_cast<float4*>(yp) = o;
@@ -453,7 +467,7 @@ int gemm(const float* A, const float* X, const float* R, float* Y, int F, int K,
     if (tiles(F, K, M, P, epi, R != nullptr, force) <= 0) return RK_ERR_UNSUPPORTED;
     pw2::GFuse fz = fuse ? *fuse : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
     pw2::GTrain tr = train ? *train : pw2::GTrain{nullptr, nullptr, nullptr, nullptr, 0};
-    if (fz.ma) return RK_ERR_UNSUPPORTED;
+    if (fz.ma && (epi != 0 || !fz.mb)) return RK_ERR_UNSUPPORTED;
     const int pro = fz.ka != nullptr, res = R != nullptr;
     Dims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.ntiles = (d.ntot + 63) / 64; d.a_is_mk = a_is_mk;

@@ -154,3 +154,31 @@ def test_no_instance_is_reported():
     rc = L.rk_pw4_gemm_f32(w.data_ptr(), x.data_ptr(), None, y.data_ptr(), 2, 144, 144, 196, 1, None, None, 0, 0, None, None, None, None,
                            7, torch.cuda.current_stream().cuda_stream)
     assert rc != 0
+
+
+@pytest.mark.parametrize("K,M", [(54, 54), (72, 72)])
+@pytest.mark.parametrize("pro,res,relu_out", [(1, 1, 1), (0, 0, 0), (1, 0, 1)])
+def test_inference_epilogue_through_the_dispatch(K, M, pro, res, relu_out):
+    """rk_pw_gemm_fused_f32 (the folded-BatchNorm inference form: Y = relu?(ma (A relu?(ka x + kb)) + mb) + R) above the
+    dispatch threshold, i.e. on the streaming kernel, against fp64."""
+    native, L = _lib()
+    Fr, P = 96, 3136
+    x, w, r, g = _mk((Fr, P, K, M), 3 * K + pro + res)
+    ka, kb = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    ma, mb = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g) * 0.3
+    xin = x.double()
+    if pro:
+        xin = (xin * ka.double().view(1, K, 1) + kb.double().view(1, K, 1)).clamp_min(0)
+    ref = torch.einsum("mk,fkp->fmp", w.double(), xin) * ma.double().view(1, M, 1) + mb.double().view(1, M, 1)
+    if relu_out:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    A, xd, rd, kad, kbd, mad, mbd = (t.to(DEV).contiguous() for t in (w, x, r, ka, kb, ma, mb))
+    y = torch.full((Fr, M, P), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    native.check(L.rk_pw_gemm_fused_f32(A.data_ptr(), xd.data_ptr(), rd.data_ptr() if res else None, y.data_ptr(), Fr, K, M, P, 1,
+                                        kad.data_ptr() if pro else None, kbd.data_ptr() if pro else None, 1, mad.data_ptr(),
+                                        mbd.data_ptr(), relu_out, st), "rk_pw_gemm_fused_f32")
+    err = float((y.cpu().double() - ref).abs().max())
+    assert err <= 6e-6 * K ** 0.5 * float(ref.abs().max()), err
