@@ -333,7 +333,10 @@ __global__ __launch_bounds__(kBlock) void k2d_raw16_backward(const T* __restrict
 // In BDims "W4" is cells per row = W / 8 here.
 // Frames per workgroup and band count do not matter here ([256,64,56,56] bf16, fwd / bwd us: 1 frame 37.6 / 57.3,
 // 2: 37.1 / 56.3, 4: 37.4 / 57.5, 8: 37.6 / 58.1, 16: 36.9 / 57.1; two 28-row bands: the same within 1 us).
-constexpr int kFramesRaw16 = 4;
+// frames per workgroup.  Measured on [256, 64, 56, 56] bf16 (round 4): forward 40.1 / 35.7 / 36.9 / 38.4 / 40.0 us with
+// 1 / 2 / 3 / 4 / 8 frames, backward 65.9 / 59.8 / 57.7 / 59.0 / 60.0 / 58.5 us with 2 / 3 / 4 / 5 / 6 / 8
+constexpr int kFramesRaw16 = 4;                   // backward
+constexpr int kFramesRaw16Fwd = 2;                // forward / d(x) alone
 inline bool make_fdims8(FDims& f, const Dims2& d, int frames_per_group) {
     const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
     if (!s1p0 || d.W % 8 != 0 || !streaming_kernels_on()) return false;
@@ -354,7 +357,7 @@ template <typename T, bool NEGATE, typename S>
 inline bool launch_interp2(const T* src, const S* shift, T* dst, const Dims2& d, hipStream_t stream) {
     constexpr int D = 2;
     FDims f;
-    if (!make_fdims8(f, d, kFramesRaw16) || !aligned16(src) || !aligned16(dst)) return false;
+    if (!make_fdims8(f, d, kFramesRaw16Fwd) || !aligned16(src) || !aligned16(dst)) return false;
     const size_t lds = interp_ring_bytes(f.b, D);
     if (lds > 64 * 1024) return false;
     const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
