@@ -541,7 +541,28 @@ int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* ru
 // constants.  Here a workgroup owns 8 192 CONTIGUOUS elements (32 KB of every tensor; consecutive lanes, consecutive
 // 16-byte cells), and the constants of the <= 8 192 / P + 2 planes it touches sit in LDS, indexed by plane.
 // Same expression per element: bit-identical to k_bn_bwd_dx_pre.
-constexpr int kFlatElems = 8192;
+// Chunk size and cache policy, measured (round 4; [256,288,14,14] / [256,72,56,56] fp32, us, plain | + skip): 8192 elements,
+// default policy 35.5 | 48.1 / 123.6 | 166.2; non-temporal store 33.9 | 46.1 / 119.1 | 160.1; + non-temporal dz / skip loads
+// 30.0 | 40.7 / 114.1 | 155.6; + non-temporal x loads 32.0 | 44.2 / 113.0 | 154.2; 4096 elements with all three 28.7 | 39.0 /
+// 112.1 | 156.2; 16384 elements 41.6 / 129.5.  Every operand is touched once by one workgroup and the result is far larger
+// than L2; in the train steps all-non-temporal measured best (Large 54.0 -> 53.5 ms, Tiny 19.75 -> 19.6, Small 34.4 -> 34.0).
+#ifndef RK_BNF_NT
+#define RK_BNF_NT 7
+#endif
+constexpr int kFlatElems = 4096;
+typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T, bool NT> __device__ __forceinline__ void flat_load(const T* p, float (&v)[4]) {
+    if constexpr (NT && std::is_same<T, float>::value) {
+        const bn_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p));
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    } else Pack<T, 4>::load(p, v);
+}
+template <typename T, bool NT> __device__ __forceinline__ void flat_store(T* p, const float (&v)[4]) {
+    if constexpr (NT && std::is_same<T, float>::value) {
+        bn_f32x4 q = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<bn_f32x4*>(p));
+    } else Pack<T, 4>::store(p, v);
+}
 constexpr int kFlatPlanes = 2048;          // planes of P >= 4 elements a chunk can touch, + 1
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre_flat(const T* __restrict__ dz, const T* __restrict__ x,
@@ -573,8 +594,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre_flat(const T* __restri
         const float4 cf = coef[li];
         const float k2 = coef2[li];
         float xv[4], gv[4];
-        Pack<T, 4>::load(x + e, xv);
-        Pack<T, 4>::load(dz + e, gv);
+        flat_load<T, (RK_BNF_NT & 2) != 0>(x + e, xv);
+        flat_load<T, (RK_BNF_NT & 1) != 0>(dz + e, gv);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float xh = (xv[q] - cf.x) * cf.y;
@@ -582,11 +603,11 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre_flat(const T* __restri
         }
         if (skip) {
             float sv[4];
-            Pack<T, 4>::load(skip + e, sv);
+            flat_load<T, (RK_BNF_NT & 1) != 0>(skip + e, sv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) gv[q] += sv[q];
         }
-        Pack<T, 4>::store(dx + e, gv);
+        flat_store<T, (RK_BNF_NT & 4) != 0>(dx + e, gv);
     }
 }
 

@@ -55,6 +55,18 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
     return v;
 }
 
+// (non-temporal Y stores: level in the train steps -- Large 53.4 / 53.1, Tiny 19.4 / 19.6 ms -- left off)
+#ifndef RK_PW2_NT
+#define RK_PW2_NT 0
+#endif
+__device__ __forceinline__ void st_y4(float* p, const float4& o) {
+#if RK_PW2_NT
+    f32x4 t = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = o;
+#endif
+}
 // AMODE 0: A [M][K], K % 4 == 0, 16-byte aligned: fragments by float4 loads along K
 // AMODE 1: A [K][M]: fragments by dword loads (64 contiguous bytes per k)
 // AMODE 2: any layout / any K: an LDS image As[k][mpad] made once per workgroup
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256, RB == 3 ? 5 : (RB == 4 ? 4 : 3)) void k_pw2_ge
                     }
                 }
                 if (R) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
-                *reinterpret_cast<float4*>(Y + yoff + (size_t)m * P) = o;
+                st_y4(Y + yoff + (size_t)m * P, o);
             }
         }
     } else {
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(256, RB == 3 ? 5 : (RB == 4 ? 4 : 3)) void k_pw2_ge
                     o.z = fmaf(pa, xv[r].z, pb) <= 0.f ? 0.f : o.z;  s1 += o.z;  s2 = fmaf(o.z, (xv[r].z - mu) * iv, s2);
                     o.w = fmaf(pa, xv[r].w, pb) <= 0.f ? 0.f : o.w;  s1 += o.w;  s2 = fmaf(o.w, (xv[r].w - mu) * iv, s2);
                 }
-                if (on) *reinterpret_cast<float4*>(Y + yoff + (size_t)m * P) = o;
+                if (on) st_y4(Y + yoff + (size_t)m * P, o);
                 s1 = row16_sum_to_lane15(s1);
                 s2 = row16_sum_to_lane15(s2);
                 if (j == 15 && m < M) {

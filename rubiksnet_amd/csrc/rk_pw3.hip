@@ -52,6 +52,27 @@ __device__ __forceinline__ void dma16v(const void* p, unsigned lds_dst_uniform) 
         : "v"(p), "s"(lds_dst_uniform)
         : "memory");
 }
+// Non-temporal Y stores measured WORSE here (RubiksNet-Large train step 53.4 -> 57.8 ms): the 58 MB results of the 14 x 14
+// layers are re-read by the next kernel out of L2 / Infinity Cache.  (The streaming kernel of the 56 x 56 layers, rk_pw4.hip,
+// and the BatchNorm d(x) sweep gain from them.)
+#ifndef RK_PW3_NT
+#define RK_PW3_NT 0
+#endif
+__device__ __forceinline__ void st_y1(float* p, float v) {
+#if RK_PW3_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_y4(float* p, float a, float b, float c, float d) {
+#if RK_PW3_NT
+    f32x4 t = {a, b, c, d};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#endif
+}
 __device__ __forceinline__ float row16_sum_to_lane15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
@@ -284,9 +305,9 @@ __global__ __launch_bounds__(64 * NRG * 2) void k_pw3_gemm(const float* __restri
                         s2 = fmaf(o[cb], (xv[r][cb] - pk[r].z) * pk[r].w, s2);
                     }
                 }
-                if (on && cb >= 4) Y[yo[cb] + mo] = o[cb];
+                if (on && cb >= 4) st_y1(Y + yo[cb] + mo, o[cb]);
             }
-            if (con[0] && mok) *reinterpret_cast<float4*>(Y + yo[0] + mo) = make_float4(o[0], o[1], o[2], o[3]);
+            if (con[0] && mok) st_y4(Y + yo[0] + mo, o[0], o[1], o[2], o[3]);
             if constexpr (EPI != 0) {
                 s1 = row16_sum_to_lane15(s1);
                 s2 = row16_sum_to_lane15(s2);

@@ -40,13 +40,21 @@ struct Dims {
     int a_is_mk;
 };
 
+#ifndef RK_PW4_NT
+#define RK_PW4_NT 2      // 1: non-temporal DMA loads, 2: non-temporal Y stores (measured: stores help, loads within noise)
+#endif
+#if RK_PW4_NT & 1
+#define RK_PW4_LDNT " nt"
+#else
+#define RK_PW4_LDNT ""
+#endif
 __device__ __forceinline__ void dma16v(const void* p, unsigned lds_dst_uniform) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off" RK_PW4_LDNT "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(p), "s"(lds_dst_uniform)
@@ -58,6 +66,14 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
     return v;
+}
+__device__ __forceinline__ void store_y(float* p, const float4& o) {
+#if RK_PW4_NT & 2
+    f32x4 t = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = o;
+#endif
 }
 template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn&& fn) {
     if constexpr (N > 0) {
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(64 * waves_of(ALDS), ALDS ? 1 : 2) void k_pw4_gemm(
             }
             if constexpr (RES) { o.x += ev[0]; o.y += ev[1]; o.z += ev[2]; o.w += ev[3]; }
             if constexpr (EPI == 0) {
-                if (on) *reinterpret_cast<float4*>(yp) = o;
+                if (on) store_y(yp, o);
             } else {
                 float s1 = 0.f, s2 = 0.f, piv = 0.f;
                 if constexpr (EPI == 1) {
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(64 * waves_of(ALDS), ALDS ? 1 : 2) void k_pw4_gemm(
                         o.w = fmaf(pa, ev[3], pb) <= 0.f ? 0.f : o.w;  s1 += o.w;  s2 = fmaf(o.w, (ev[3] - mu) * iv, s2);
                     }
                 }
-                if (on) *reinterpret_cast<float4*>(yp) = o;
+                if (on) store_y(yp, o);
                 s1 = row16_sum_to_lane15(s1);
                 s2 = row16_sum_to_lane15(s2);
                 if (j == 15 && live) {
