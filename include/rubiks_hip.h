@@ -460,6 +460,12 @@ int rk_clip_u8_to_chw_bf16(const unsigned char* hwc, const float* mean3, const f
 RK_DECL_SE(f32)
 RK_DECL_SE(bf16)
 #undef RK_DECL_SE
+/* The SE backward of the fused training block in 4 tensor passes instead of 5: dgate[f, c] = sum_p dy * x alone, and -- once
+ * the two Linear layers' backward produced d(mean) [F, C] -- dx = dy * gate[f, c] + add[f, c] * add_scale (add_scale = 1 / P
+ * is the squeeze's share, SELayer backward of rubiksnet/backbone.py:56-71).  fp32. */
+int rk_se_dgate_f32(const float* dy, const float* x, float* dgate, int F, int C, int P, rk_stream_t stream);
+int rk_se_scale_add_f32(const float* x, const float* gate, const float* add, float add_scale, float* y, int F, int C, int P,
+                        rk_stream_t stream);
 
 #ifdef __cplusplus
 }

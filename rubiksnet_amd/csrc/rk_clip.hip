@@ -15,6 +15,7 @@
 // view, 2 x Linear, ReLU, sigmoid, expand_as and a broadcast multiply as separate kernels and autograd saves x and
 // the expanded gate; here squeeze and scale are one pass each, and the backward of the scale produces d(x) and
 // d(gate) (a per-plane dot product) in one pass over (dy, x).
+#include <type_traits>
 #include "rk_common.hpp"
 
 using namespace rk;
@@ -53,6 +54,10 @@ __global__ __launch_bounds__(kBlock) void k_clip_u8_to_chw(const unsigned char* 
 }
 
 // ------------------------------------------------------------------------------------------ SE squeeze / scale
+// a plane of P fp32 elements can be walked in 16-byte cells (wave-uniform: planes are P apart from an aligned base)
+__device__ __forceinline__ bool se_vec4(const void* plane_ptr, int P) {
+    return (P & 3) == 0 && (reinterpret_cast<uintptr_t>(plane_ptr) & 15) == 0;
+}
 // one wave per (frame, channel) plane
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_se_squeeze(const T* __restrict__ x, float* __restrict__ mean, long long planes,
@@ -62,6 +67,19 @@ __global__ __launch_bounds__(kBlock) void k_se_squeeze(const T* __restrict__ x, 
     const int lane = threadIdx.x & (kWave - 1);
     const T* p = x + plane * P;
     float s = 0.f;
+    if constexpr (std::is_same<T, float>::value) {
+        if (se_vec4(p, P)) {                              // 16-byte accesses, 4 in flight per lane (the scalar walk below is one
+            const int n4 = P >> 2;                        //  4-byte load per lane and round trip: latency-bound at 56 x 56)
+#pragma unroll 4
+            for (int i = lane; i < n4; i += kWave) {
+                const float4 v = reinterpret_cast<const float4*>(p)[i];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            s = wave_sum(s);
+            if (lane == 0) mean[plane] = s / (float)P;
+            return;
+        }
+    }
     for (int i = lane; i < P; i += kWave) s += ld(p + i);
     s = wave_sum(s);
     if (lane == 0) mean[plane] = s / (float)P;
@@ -77,6 +95,18 @@ __global__ __launch_bounds__(kBlock) void k_se_scale(const T* __restrict__ x, co
     const float g = gate[plane];
     const T* p = x + plane * P;
     T* o = y + plane * P;
+    if constexpr (std::is_same<T, float>::value) {
+        if (se_vec4(p, P) && se_vec4(o, P)) {
+            const int n4 = P >> 2;
+#pragma unroll 4
+            for (int i = lane; i < n4; i += kWave) {
+                float4 v = reinterpret_cast<const float4*>(p)[i];
+                v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+                reinterpret_cast<float4*>(o)[i] = v;
+            }
+            return;
+        }
+    }
     for (int i = lane; i < P; i += kWave) st(o + i, ld(p + i) * g);
 }
 
@@ -93,6 +123,21 @@ __global__ __launch_bounds__(kBlock) void k_se_scale_backward(const T* __restric
     const T* px = x + plane * P;
     T* o = dx + plane * P;
     float s = 0.f;
+    if constexpr (std::is_same<T, float>::value) {
+        if (se_vec4(pd, P) && se_vec4(px, P) && se_vec4(o, P)) {
+            const int n4 = P >> 2;
+#pragma unroll 4
+            for (int i = lane; i < n4; i += kWave) {
+                const float4 d = reinterpret_cast<const float4*>(pd)[i];
+                const float4 v = reinterpret_cast<const float4*>(px)[i];
+                s = fmaf(d.x, v.x, s); s = fmaf(d.y, v.y, s); s = fmaf(d.z, v.z, s); s = fmaf(d.w, v.w, s);
+                reinterpret_cast<float4*>(o)[i] = make_float4(d.x * g, d.y * g, d.z * g, d.w * g);
+            }
+            s = wave_sum(s);
+            if (lane == 0) dgate[plane] = s;
+            return;
+        }
+    }
     for (int i = lane; i < P; i += kWave) {
         const float d = ld(pd + i);
         s = fmaf(d, ld(px + i), s);
@@ -100,6 +145,52 @@ __global__ __launch_bounds__(kBlock) void k_se_scale_backward(const T* __restric
     }
     s = wave_sum(s);
     if (lane == 0) dgate[plane] = s;
+}
+
+// The fused training block's SE backward in 4 tensor passes instead of 5 (scale_backward = 3, then dx += dmean / P = 2):
+// dgate[plane] = sum(dy * x) alone (2 reads), then -- after the two Linear layers gave d(mean) -- dx = dy * gate[plane] +
+// add[plane] (1 read, 1 write).
+__global__ __launch_bounds__(kBlock) void k_se_dgate(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     float* __restrict__ dgate, long long planes, int P) {
+    const long long plane = (long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const float* pd = dy + plane * P;
+    const float* px = x + plane * P;
+    float s = 0.f;
+    if (se_vec4(pd, P) && se_vec4(px, P)) {
+        const int n4 = P >> 2;
+#pragma unroll 4
+        for (int i = lane; i < n4; i += kWave) {
+            const float4 d = reinterpret_cast<const float4*>(pd)[i];
+            const float4 v = reinterpret_cast<const float4*>(px)[i];
+            s = fmaf(d.x, v.x, s); s = fmaf(d.y, v.y, s); s = fmaf(d.z, v.z, s); s = fmaf(d.w, v.w, s);
+        }
+    } else {
+        for (int i = lane; i < P; i += kWave) s = fmaf(pd[i], px[i], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) dgate[plane] = s;
+}
+__global__ __launch_bounds__(kBlock) void k_se_scale_add(const float* __restrict__ x, const float* __restrict__ gate,
+                                                         const float* __restrict__ add, float add_scale, float* __restrict__ y,
+                                                         long long planes, int P) {
+    const long long plane = (long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const float g = gate[plane], a = add[plane] * add_scale;
+    const float* p = x + plane * P;
+    float* o = y + plane * P;
+    if (se_vec4(p, P) && se_vec4(o, P)) {
+        const int n4 = P >> 2;
+#pragma unroll 4
+        for (int i = lane; i < n4; i += kWave) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            reinterpret_cast<float4*>(o)[i] = make_float4(fmaf(v.x, g, a), fmaf(v.y, g, a), fmaf(v.z, g, a), fmaf(v.w, g, a));
+        }
+    } else {
+        for (int i = lane; i < P; i += kWave) o[i] = fmaf(p[i], g, a);
+    }
 }
 
 unsigned plane_grid(long long planes) { return (unsigned)((planes + kBlock / kWave - 1) / (kBlock / kWave)); }
@@ -156,6 +247,22 @@ int rk_clip_u8_to_chw_bf16(const unsigned char* hwc, const float* mean3, const f
                            (hipStream_t)stream, (const T*)dy, (const T*)x, gate, (T*)dx, dgate, planes, P);         \
         return launch_status();                                                                                     \
     }
+int rk_se_dgate_f32(const float* dy, const float* x, float* dgate, int F, int C, int P, rk_stream_t stream) {
+    if (!dy || !x || !dgate) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;
+    const long long planes = (long long)F * C;
+    hipLaunchKernelGGL(k_se_dgate, dim3(plane_grid(planes)), dim3(kBlock), 0, (hipStream_t)stream, dy, x, dgate, planes, P);
+    return launch_status();
+}
+int rk_se_scale_add_f32(const float* x, const float* gate, const float* add, float add_scale, float* y, int F, int C, int P,
+                        rk_stream_t stream) {
+    if (!x || !gate || !add || !y) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;
+    const long long planes = (long long)F * C;
+    hipLaunchKernelGGL(k_se_scale_add, dim3(plane_grid(planes)), dim3(kBlock), 0, (hipStream_t)stream, x, gate, add, add_scale,
+                       y, planes, P);
+    return launch_status();
+}
 RK_SE_IMPL(f32, float)
 RK_SE_IMPL(bf16, __hip_bfloat16)
 #undef RK_SE_IMPL

@@ -305,16 +305,20 @@ class _FusedTrainBlock(torch.autograd.Function):
                 if ctx.has_se:
                     # SE backward: ds (so far d(s * gate)) -> d(s) = ds gate + d(squeeze) / HW, d(gate) = sum_hw(ds s) in one
                     # pass over (ds, s); the two Linear layers and their activations by hand (a few [F, C]-sized kernels)
-                    dsg = torch.empty_like(s)
+                    # (4 tensor passes: the reduction alone, then d(s) with the squeeze's share added in the same pass --
+                    # scale_backward + a broadcast add were 5)
                     dgate = torch.empty_like(se_g)
-                    _native.check(L.rk_se_scale_backward_f32(ds.data_ptr(), s.data_ptr(), se_g.data_ptr(), dsg.data_ptr(),
-                                                             dgate.data_ptr(), Fr, Cmid, Po, st), "rk_se_scale_backward_f32")
+                    _native.check(L.rk_se_dgate_f32(ds.data_ptr(), s.data_ptr(), dgate.data_ptr(), Fr, Cmid, Po, st),
+                                  "rk_se_dgate_f32")
                     dpre2 = dgate * se_g * (1.0 - se_g)
                     dwse2 = dpre2.t() @ se_h
                     dpre1 = (dpre2 @ wse2) * (se_h > 0).to(dpre2.dtype)
                     dwse1 = dpre1.t() @ se_q
-                    dq = dpre1 @ wse1
-                    ds = dsg.view(Fr, Cmid, Po).add_((dq / float(Po)).unsqueeze(-1)).view_as(s)
+                    dq = (dpre1 @ wse1).contiguous()
+                    dsg = torch.empty_like(s)
+                    _native.check(L.rk_se_scale_add_f32(ds.data_ptr(), se_g.data_ptr(), dq.data_ptr(), 1.0 / float(Po),
+                                                        dsg.data_ptr(), Fr, Cmid, Po, st), "rk_se_scale_add_f32")
+                    ds = dsg
                 # the shift and bn2: d(shift), and d(z) = bn2 + ReLU backward of d(a2).  Fused: the shift backward reads z,
                 # masks its d(x) with the ReLU and reduces bn2's sums in the same launch (dg2, db2, k12); one d(x) pass finishes.
                 N = Fr // plan.T
