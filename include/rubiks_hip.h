@@ -463,6 +463,14 @@ RK_DECL_SE(bf16)
 /* The SE backward of the fused training block in 4 tensor passes instead of 5: dgate[f, c] = sum_p dy * x alone, and -- once
  * the two Linear layers' backward produced d(mean) [F, C] -- dx = dy * gate[f, c] + add[f, c] * add_scale (add_scale = 1 / P
  * is the squeeze's share, SELayer backward of rubiksnet/backbone.py:56-71).  fp32. */
+/* The gate's two bias-free Linear layers on the squeezed vector, fused (one workgroup per frame): q [F, C], W1 [Cr, C], W2 [C, Cr]
+ * (nn.Linear layout) -> h = relu(q W1^T) [F, Cr], g = sigmoid(h W2^T) [F, C]; backward: dgate [F, C] -> dq [F, C], dW1, dW2
+ * (dpre2 [F, C], dpre1 [F, Cr]: caller-owned scratch).  RK_ERR_UNSUPPORTED for C > 2048 or Cr > 128. */
+int rk_se_mlp_forward_f32(const float* q, const float* W1, const float* W2, float* h, float* g, int F, int C, int Cr,
+                          rk_stream_t stream);
+int rk_se_mlp_backward_f32(const float* dgate, const float* g, const float* h, const float* q, const float* W1, const float* W2,
+                           float* dpre2, float* dpre1, float* dq, float* dW1, float* dW2, int F, int C, int Cr,
+                           rk_stream_t stream);
 int rk_se_dgate_f32(const float* dy, const float* x, float* dgate, int F, int C, int P, rk_stream_t stream);
 int rk_se_scale_add_f32(const float* x, const float* gate, const float* add, float add_scale, float* y, int F, int C, int P,
                         rk_stream_t stream);

@@ -193,6 +193,83 @@ __global__ __launch_bounds__(kBlock) void k_se_scale_add(const float* __restrict
     }
 }
 
+// ---- the two bias-free Linear layers of the gate (backbone.py:60-64: Linear(C, C / r) -> ReLU -> Linear(C / r, C) -> Sigmoid)
+// on the squeezed [F, C] vector, one workgroup per frame: as PyTorch ops this is 4 launches forward and 9 backward per block
+// of ~5-15 us each (2 ms of the RubiksNet-Small train step for 40 MFLOP).  W1 [Cr][C], W2 [C][Cr] (nn.Linear layout).
+constexpr int kSeMaxC = 2048, kSeMaxCr = 128;
+__global__ __launch_bounds__(kBlock) void k_se_mlp_forward(const float* __restrict__ q, const float* __restrict__ W1,
+                                                           const float* __restrict__ W2, float* __restrict__ h,
+                                                           float* __restrict__ g, int C, int Cr) {
+    __shared__ float qs[kSeMaxC], hs[kSeMaxCr];
+    const int f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    for (int c = threadIdx.x; c < C; c += kBlock) qs[c] = q[(size_t)f * C + c];
+    __syncthreads();
+    for (int j = wave; j < Cr; j += kBlock / kWave) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += kWave) s = fmaf(W1[(size_t)j * C + c], qs[c], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            s = s > 0.f ? s : 0.f;
+            hs[j] = s;
+            h[(size_t)f * Cr + j] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+        float s = 0.f;
+        for (int j = 0; j < Cr; ++j) s = fmaf(W2[(size_t)c * Cr + j], hs[j], s);
+        g[(size_t)f * C + c] = 1.f / (1.f + expf(-s));
+    }
+}
+// dpre2 = dgate g (1 - g); dpre1 = (dpre2 W2) [h > 0]; dq = dpre1 W1
+__global__ __launch_bounds__(kBlock) void k_se_mlp_backward(const float* __restrict__ dgate, const float* __restrict__ g,
+                                                            const float* __restrict__ h, const float* __restrict__ W1,
+                                                            const float* __restrict__ W2, float* __restrict__ dpre2,
+                                                            float* __restrict__ dpre1, float* __restrict__ dq, int C, int Cr) {
+    __shared__ float d2[kSeMaxC], p1[kSeMaxCr];
+    const int f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+        const float gv = g[(size_t)f * C + c];
+        const float v = dgate[(size_t)f * C + c] * gv * (1.f - gv);
+        d2[c] = v;
+        dpre2[(size_t)f * C + c] = v;
+    }
+    __syncthreads();
+    for (int j = wave; j < Cr; j += kBlock / kWave) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += kWave) s = fmaf(d2[c], W2[(size_t)c * Cr + j], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            s = h[(size_t)f * Cr + j] > 0.f ? s : 0.f;
+            p1[j] = s;
+            dpre1[(size_t)f * Cr + j] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+        float s = 0.f;
+        for (int j = 0; j < Cr; ++j) s = fmaf(p1[j], W1[(size_t)j * C + c], s);
+        dq[(size_t)f * C + c] = s;
+    }
+}
+// dW2[c][j] = sum_f dpre2[f][c] h[f][j]; dW1[j][c] = sum_f dpre1[f][j] q[f][c]  (frames in order: deterministic)
+__global__ __launch_bounds__(kBlock) void k_se_mlp_wgrad(const float* __restrict__ dpre2, const float* __restrict__ h,
+                                                         const float* __restrict__ dpre1, const float* __restrict__ q,
+                                                         float* __restrict__ dW1, float* __restrict__ dW2, int F, int C, int Cr) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x, n = C * Cr;
+    if (idx < n) {
+        const int c = idx / Cr, j = idx - c * Cr;
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s = fmaf(dpre2[(size_t)f * C + c], h[(size_t)f * Cr + j], s);
+        dW2[idx] = s;
+    } else if (idx < 2 * n) {
+        const int i2 = idx - n, j = i2 / C, c = i2 - j * C;
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s = fmaf(dpre1[(size_t)f * Cr + j], q[(size_t)f * C + c], s);
+        dW1[i2] = s;
+    }
+}
+
 unsigned plane_grid(long long planes) { return (unsigned)((planes + kBlock / kWave - 1) / (kBlock / kWave)); }
 
 template <typename T>
@@ -247,6 +324,26 @@ int rk_clip_u8_to_chw_bf16(const unsigned char* hwc, const float* mean3, const f
                            (hipStream_t)stream, (const T*)dy, (const T*)x, gate, (T*)dx, dgate, planes, P);         \
         return launch_status();                                                                                     \
     }
+int rk_se_mlp_forward_f32(const float* q, const float* W1, const float* W2, float* h, float* g, int F, int C, int Cr,
+                          rk_stream_t stream) {
+    if (!q || !W1 || !W2 || !h || !g) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || C <= 0 || Cr <= 0) return RK_ERR_BAD_DIMS;
+    if (C > kSeMaxC || Cr > kSeMaxCr) return RK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_se_mlp_forward, dim3((unsigned)F), dim3(kBlock), 0, (hipStream_t)stream, q, W1, W2, h, g, C, Cr);
+    return launch_status();
+}
+int rk_se_mlp_backward_f32(const float* dgate, const float* g, const float* h, const float* q, const float* W1, const float* W2,
+                           float* dpre2, float* dpre1, float* dq, float* dW1, float* dW2, int F, int C, int Cr,
+                           rk_stream_t stream) {
+    if (!dgate || !g || !h || !q || !W1 || !W2 || !dpre2 || !dpre1 || !dq || !dW1 || !dW2) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || C <= 0 || Cr <= 0) return RK_ERR_BAD_DIMS;
+    if (C > kSeMaxC || Cr > kSeMaxCr) return RK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_se_mlp_backward, dim3((unsigned)F), dim3(kBlock), 0, (hipStream_t)stream, dgate, g, h, W1, W2, dpre2,
+                       dpre1, dq, C, Cr);
+    hipLaunchKernelGGL(k_se_mlp_wgrad, dim3((unsigned)((2 * C * Cr + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       dpre2, h, dpre1, q, dW1, dW2, F, C, Cr);
+    return launch_status();
+}
 int rk_se_dgate_f32(const float* dy, const float* x, float* dgate, int F, int C, int P, rk_stream_t stream) {
     if (!dy || !x || !dgate) return RK_ERR_NULL_POINTER;
     if (F <= 0 || C <= 0 || P <= 0) return RK_ERR_BAD_DIMS;

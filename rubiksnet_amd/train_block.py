@@ -228,8 +228,16 @@ class _FusedTrainBlock(torch.autograd.Function):
                 if wse1 is not None:
                     se_q = torch.empty(Fr, Cmid, dtype=torch.float32, device=dev)
                     _native.check(L.rk_se_squeeze_f32(s.data_ptr(), se_q.data_ptr(), Fr, Cmid, Po, st), "rk_se_squeeze_f32")
-                    se_h = torch.relu(se_q @ wse1.t())
-                    se_g = torch.sigmoid(se_h @ wse2.t()).contiguous()
+                    Cr = wse1.shape[0]
+                    se_h = torch.empty(Fr, Cr, dtype=torch.float32, device=dev)
+                    se_g = torch.empty(Fr, Cmid, dtype=torch.float32, device=dev)
+                    rc = L.rk_se_mlp_forward_f32(se_q.data_ptr(), wse1.data_ptr(), wse2.data_ptr(), se_h.data_ptr(), se_g.data_ptr(),
+                                                 Fr, Cmid, Cr, st)
+                    if rc == rubiksnet_cuda.UNSUPPORTED:          # (wider than the kernel's tables: the two Linear layers in PyTorch)
+                        se_h = torch.relu(se_q @ wse1.t())
+                        se_g = torch.sigmoid(se_h @ wse2.t()).contiguous()
+                    else:
+                        _native.check(rc, "rk_se_mlp_forward_f32")
                     s_in = torch.empty_like(s)
                     _native.check(L.rk_se_scale_f32(s.data_ptr(), se_g.data_ptr(), s_in.data_ptr(), Fr, Cmid, Po, st),
                                   "rk_se_scale_f32")
@@ -310,11 +318,22 @@ class _FusedTrainBlock(torch.autograd.Function):
                     dgate = torch.empty_like(se_g)
                     _native.check(L.rk_se_dgate_f32(ds.data_ptr(), s.data_ptr(), dgate.data_ptr(), Fr, Cmid, Po, st),
                                   "rk_se_dgate_f32")
-                    dpre2 = dgate * se_g * (1.0 - se_g)
-                    dwse2 = dpre2.t() @ se_h
-                    dpre1 = (dpre2 @ wse2) * (se_h > 0).to(dpre2.dtype)
-                    dwse1 = dpre1.t() @ se_q
-                    dq = (dpre1 @ wse1).contiguous()
+                    Cr = wse1.shape[0]
+                    dpre2 = torch.empty_like(se_g)
+                    dpre1 = torch.empty_like(se_h)
+                    dq = torch.empty_like(se_g)
+                    dwse1, dwse2 = torch.empty_like(wse1), torch.empty_like(wse2)
+                    rc = L.rk_se_mlp_backward_f32(dgate.data_ptr(), se_g.data_ptr(), se_h.data_ptr(), se_q.data_ptr(), wse1.data_ptr(),
+                                                  wse2.data_ptr(), dpre2.data_ptr(), dpre1.data_ptr(), dq.data_ptr(), dwse1.data_ptr(),
+                                                  dwse2.data_ptr(), Fr, Cmid, Cr, st)
+                    if rc == rubiksnet_cuda.UNSUPPORTED:
+                        dpre2 = dgate * se_g * (1.0 - se_g)
+                        dwse2 = dpre2.t() @ se_h
+                        dpre1 = (dpre2 @ wse2) * (se_h > 0).to(dpre2.dtype)
+                        dwse1 = dpre1.t() @ se_q
+                        dq = (dpre1 @ wse1).contiguous()
+                    else:
+                        _native.check(rc, "rk_se_mlp_backward_f32")
                     dsg = torch.empty_like(s)
                     _native.check(L.rk_se_scale_add_f32(ds.data_ptr(), se_g.data_ptr(), dq.data_ptr(), 1.0 / float(Po),
                                                         dsg.data_ptr(), Fr, Cmid, Po, st), "rk_se_scale_add_f32")
