@@ -8,6 +8,7 @@
 #include "rk3d_translate.hpp"
 #include "rk3d_stride2.hpp"
 #include "rk3d_column.hpp"
+#include "rk3d_slab.hpp"
 
 #include <type_traits>
 
@@ -52,7 +53,10 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
     if constexpr (std::is_same<T, float>::value) {
         if (!quantize && plane3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
         if (!quantize && dma3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
+        const bool p14 = d.H == 14 && d.W == 14;
+        if (!quantize && p14 && slab3d::slab14_on(false) && slab3d::launch_interp(false, x, shift, y, d, stream)) return launch_status();
         if (!quantize && tile3d::launch_interp<false>(x, shift, y, d, stream)) return launch_status();
+        if (!quantize && !p14 && slab3d::launch_interp(false, x, shift, y, d, stream)) return launch_status();   // small planes
         if (quantize && xlate3d::launch<false>(x, shift, y, d, stream)) return launch_status();   // plane translation
         if (!quantize && s2::launch_forward(x, shift, y, d, stream)) return launch_status();       // stride (1,2,2)
     }
@@ -114,10 +118,17 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
                 if (P_out) *P_out = P;
                 return launch_status();
             }
-            if (const int P = tile3d::launch_bwd(x, shift, gy, gx, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
-                                                 t_factor, stream)) {
-                if (P_out) *P_out = P;
-                return launch_status();
+            {   // 14x14: the tile kernels (or, RK_SLAB14=1, the slab kernels first); other small planes: the slab kernels
+                const bool p14 = d.H == 14 && d.W == 14;
+                float* gs = P_out ? nullptr : gshift;
+                int P = 0;
+                if (p14 && slab3d::slab14_on(true)) P = slab3d::launch_bwd(x, shift, gy, gx, gs, (float*)ws, d, normalize_grad, t_factor, stream);
+                if (!P) P = tile3d::launch_bwd(x, shift, gy, gx, gs, (float*)ws, d, normalize_grad, t_factor, stream);
+                if (!P && !p14) P = slab3d::launch_bwd(x, shift, gy, gx, gs, (float*)ws, d, normalize_grad, t_factor, stream);
+                if (P) {
+                    if (P_out) *P_out = P;
+                    return launch_status();
+                }
             }
             if (const int P = s2::launch_backward(x, shift, gy, gx, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
                                                   t_factor, stream)) {      // stride (1,2,2)
@@ -127,7 +138,10 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
         } else if (!quantize && gx) {
             if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
+            const bool p14 = d.H == 14 && d.W == 14;
+            if (p14 && slab3d::slab14_on(false) && slab3d::launch_interp(true, gy, shift, gx, d, stream)) return launch_status();
             if (tile3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
+            if (!p14 && slab3d::launch_interp(true, gy, shift, gx, d, stream)) return launch_status();
         }
     }
     if (gshift && col3d::supported(d, quantize)) {

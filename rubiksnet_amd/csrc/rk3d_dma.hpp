@@ -404,9 +404,9 @@ struct BnFuse {
     float inv_count;              // 1 / (N T H W)
 };
 template <int D>
-__device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, int P, const BnFuse& bn = BnFuse{}) {
+__device__ __forceinline__ void finalizer_wave(const Fin3& fin, int c, int C, int P, const BnFuse& bn = BnFuse{}, int count = -1) {
     double s[D];
-    const bool ok = fin_collect<D>(fin.f, c, P, s);
+    const bool ok = fin_collect<D>(fin.f, c, P, s, count);
     if (threadIdx.x == 0) {
         if constexpr (D == 5) {
             const float nanv = __uint_as_float(0x7fc00000u);

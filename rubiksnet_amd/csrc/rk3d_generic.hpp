@@ -145,7 +145,7 @@ __device__ __forceinline__ int unmap(int p, int s, int lim) {
 template <typename T, bool QUANT>
 __device__ __forceinline__ void backward_input_plane(const T* __restrict__ shift, const T* __restrict__ gy,
                                                      T* __restrict__ gx, const Dims3& d, int n, int t, int c,
-                                                     int e, int E) {
+                                                     int e, int E, int lo = 0, int hi = 0x7fffffff) {
     const T nT = -shift[c], nH = -shift[d.C + c], nW = -shift[2 * d.C + c];
     const Frac<T> fT = split_shift(nT), fH = split_shift(nH), fW = split_shift(nW);
     const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
@@ -154,6 +154,9 @@ __device__ __forceinline__ void backward_input_plane(const T* __restrict__ shift
     T* gp = gx + (((size_t)n * d.T + t) * d.C + c) * HW;
     const int oT = t + d.pT;
 
+    // elements lo + e, lo + e + E, ... below min(hi, HW): the whole plane by default, a sub-range for rk3d_slab.hpp
+    e += lo;
+    const int HWe = hi < HW ? hi : HW;
     int h = e / d.W, w = e - h * d.W;
     const int dh = E / d.W, dw = E - dh * d.W;
 
@@ -166,7 +169,7 @@ __device__ __forceinline__ void backward_input_plane(const T* __restrict__ shift
         const int aW = QUANT ? ((fW.r < 0.5f) ? fW.fl : fW.fl + 1) : 0;
         const int tt = unmap(oT + aT, d.sT, d.To);
         const T* p = gc + (tt >= 0 ? (size_t)tt * tstride : 0);
-        for (int i = e; i < HW; i += E) {
+        for (int i = e; i < HWe; i += E) {
             const int hh = unmap(h + d.pH + aH, d.sH, d.Ho), ww = unmap(w + d.pW + aW, d.sW, d.Wo);
             T v = 0;
             if (tt >= 0 && hh >= 0 && ww >= 0) v = p[hh * d.Wo + ww];
@@ -180,7 +183,7 @@ __device__ __forceinline__ void backward_input_plane(const T* __restrict__ shift
     const int t0 = unmap(oT + fT.fl, d.sT, d.To), t1 = unmap(oT + fT.fl + 1, d.sT, d.To);
     const T* p0 = gc + (t0 >= 0 ? (size_t)t0 * tstride : 0);
     const T* p1 = gc + (t1 >= 0 ? (size_t)t1 * tstride : 0);
-    for (int i = e; i < HW; i += E) {
+    for (int i = e; i < HWe; i += E) {
         const int h0 = unmap(h + d.pH + fH.fl, d.sH, d.Ho), h1 = unmap(h + d.pH + fH.fl + 1, d.sH, d.Ho);
         const int w0 = unmap(w + d.pW + fW.fl, d.sW, d.Wo), w1 = unmap(w + d.pW + fW.fl + 1, d.sW, d.Wo);
         T q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
@@ -230,7 +233,8 @@ struct BnAct {
 template <typename T, typename Act = NoAct>
 __device__ __forceinline__ void shift_grad_plane(const T* __restrict__ x, const T* __restrict__ shift,
                                                  const T* __restrict__ gy, const Dims3& d, int n, int to, int c,
-                                                 int e, int E, T& aT, T& aH, T& aW, const Act act = Act()) {
+                                                 int e, int E, T& aT, T& aH, T& aW, const Act act = Act(),
+                                                 int lo = 0, int hi = 0x7fffffff) {
     const Frac<T> fT = split_shift(shift[c]);
     const Frac<T> fH = split_shift(shift[d.C + c]);
     const Frac<T> fW = split_shift(shift[2 * d.C + c]);
@@ -245,9 +249,11 @@ __device__ __forceinline__ void shift_grad_plane(const T* __restrict__ x, const 
     const T* p0 = xc + (v0 ? (size_t)t0 * tstride : 0);
     const T* p1 = xc + (v1 ? (size_t)t1 * tstride : 0);
 
+    e += lo;                                              // output elements lo + e, lo + e + E, ... below min(hi, HWo)
+    const int HWe = hi < HWo ? hi : HWo;
     int ho = e / d.Wo, wo = e - ho * d.Wo;
     const int dh = E / d.Wo, dw = E - dh * d.Wo;
-    for (int i = e; i < HWo; i += E) {
+    for (int i = e; i < HWe; i += E) {
         const int hb = ho * d.sH - d.pH + fH.fl, wb = wo * d.sW - d.pW + fW.fl;
         const int h0 = hb - zH, h1 = hb + 1, w0 = wb - zW, w1 = wb + 1;
         const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h1 >= 0 && h1 < d.H;

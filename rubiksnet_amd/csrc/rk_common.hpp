@@ -35,10 +35,46 @@ template <> __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p
 }
 
 // ---- wave / block reductions (deterministic: fixed tree, no float atomics) -------
+// Sum over the 64 lanes, returned in EVERY lane.  float / double: DPP row shifts + row broadcasts (the gfx9 reduction
+// idiom: 4 steps inside each row of 16 lanes, row_bcast:15, row_bcast:31, then lane 63 read back) -- a handful of VALU
+// instructions; the __shfl_down tree it replaces is one ds_bpermute round trip per step (two for a double): ~1.8 us for
+// the three fp64 sums of a d(shift) finalizer wave, on the tail of every fused backward launch.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_or_zero(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);       // 0 where there is no source lane / row masked
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_or_zero(float v) {
+    return __builtin_bit_cast(float, dpp_or_zero<CTRL, ROW_MASK>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_or_zero(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_or_zero<CTRL, ROW_MASK>((int)(unsigned)b);
+    const unsigned hi = (unsigned)dpp_or_zero<CTRL, ROW_MASK>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename A> __device__ __forceinline__ A wave_sum_dpp(A v) {
+    v += dpp_or_zero<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += dpp_or_zero<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
 template <typename A> __device__ __forceinline__ A wave_sum(A v) {
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     return v;
+}
+template <> __device__ __forceinline__ float wave_sum<float>(float v) {
+    v = wave_sum_dpp(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <> __device__ __forceinline__ double wave_sum<double>(double v) {
+    v = wave_sum_dpp(v);
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 // Sum `v` over groups of `group` consecutive threads (group in {64,128,256}, a divisor of

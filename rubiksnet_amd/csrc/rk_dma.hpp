@@ -257,12 +257,23 @@ inline unsigned next_launch_tag() {
 // satisfies all three conditions by accident is out of reach (< 2^-90 per granule even for adversarial float data,
 // tests/test_parity_3d.py::test_backward_ignores_adversarial_workspace_contents fills the workspace with near misses).
 __device__ __forceinline__ unsigned fin_tag2(unsigned tag) { return tag * 2654435761u ^ 0x9e3779b9u; }
+// A pair that is 16-byte aligned (any workspace that came from an allocator) moves as ONE 16-byte agent-scope access
+// instead of two 8-byte ones: half the memory transactions of the hand-off (233 k scattered 8-byte stores + as many
+// polls + as many retiring stores at [32,8,576,7,7]).  A 16-byte access is not single-copy atomic -- it does not have to
+// be: a torn pair fails fin_ready (tags + complement) and is polled again, exactly like a half-written pair of 8-byte stores.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool fin_wide(const Fin& fin) { return ((size_t)fin.gran & 15) == 0; }     // wave-uniform
+__device__ __forceinline__ void fin_store16(unsigned long long* p, unsigned long long v, unsigned long long w) {
+    const u32x4 q = {(unsigned)v, (unsigned)(v >> 32), (unsigned)w, (unsigned)(w >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
 __device__ __forceinline__ void fin_publish(const Fin& fin, size_t at, float v) {
     const unsigned bits = __float_as_uint(v);
-    __hip_atomic_store(fin.gran + 2 * at, ((unsigned long long)fin.tag << 32) | bits, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fin.gran + 2 * at + 1, ((unsigned long long)fin_tag2(fin.tag) << 32) | (unsigned)~bits,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long a = ((unsigned long long)fin.tag << 32) | bits;
+    const unsigned long long b = ((unsigned long long)fin_tag2(fin.tag) << 32) | (unsigned)~bits;
+    if (fin_wide(fin)) { fin_store16(fin.gran + 2 * at, a, b); return; }
+    __hip_atomic_store(fin.gran + 2 * at, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fin.gran + 2 * at + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // both granules of a pair carry this launch's tags and agree on the payload
 __device__ __forceinline__ bool fin_ready(const Fin& fin, unsigned long long v, unsigned long long w) {
@@ -271,25 +282,56 @@ __device__ __forceinline__ bool fin_ready(const Fin& fin, unsigned long long v, 
 // one wave (lanes 0..63 of the block): s[k] = sum_i granule[c][k][i] over this launch's P partials; false = timed out.
 // The D loads of a lane go out together (one round trip, not D dependent ones: the finalizers' sweep is the tail of
 // the launch), then each lane re-polls only what is still missing.
+// D pairs of one lane (row stride P pairs, lane index i), all requested before the first is used
 template <int D>
-__device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double (&s)[D]) {
+__device__ __forceinline__ void fin_load(const Fin& fin, unsigned long long* g, int P, int i, unsigned long long (&v)[D],
+                                         unsigned long long (&w)[D], const bool (&want)[D]) {
+    if (fin_wide(fin)) {
+        u32x4 q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            q[k] = u32x4{(unsigned)v[k], (unsigned)(v[k] >> 32), (unsigned)w[k], (unsigned)(w[k] >> 32)};
+            if (want[k]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(q[k]) : "v"(g + 2 * ((size_t)k * P + i)) : "memory");
+        }
+        if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) : : "memory");
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[k]) : : "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            v[k] = ((unsigned long long)q[k].y << 32) | q[k].x;
+            w[k] = ((unsigned long long)q[k].w << 32) | q[k].z;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        if (want[k]) {
+            const size_t at = 2 * ((size_t)k * P + i);
+            v[k] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w[k] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+// `count` <= P: the partials that exist for this channel (rows keep the stride P)
+template <int D>
+__device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double (&s)[D], int count = -1) {
     const int lane = threadIdx.x;
+    if (count < 0) count = P;
     unsigned long long* g = fin.gran + 2 * (size_t)c * D * P;
     const unsigned long long done = (unsigned long long)fin.tag << 32;          // a ready pair holding 0.0f
     const unsigned long long done2 = ((unsigned long long)fin_tag2(fin.tag) << 32) | 0xffffffffull;
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0;
-    for (int i0 = 0; i0 < P; i0 += kWave) {
+    for (int i0 = 0; i0 < count; i0 += kWave) {
         const int i = i0 + lane;
-        const bool act = i < P;
+        const bool act = i < count;
         unsigned long long v[D], w[D];
+        bool want[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const size_t at = 2 * ((size_t)k * P + i);
-            v[k] = act ? __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done;
-            w[k] = act ? __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done2;
-        }
+        for (int k = 0; k < D; ++k) { v[k] = done; w[k] = done2; want[k] = act; }
+        fin_load<D>(fin, g, P, i, v, w, want);
         for (int spin = 0; spin < 8000000; ++spin) {                 // ~0.25 us per poll: gives up after ~2 s
             bool ready = true;
 #pragma unroll
@@ -297,12 +339,8 @@ __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double
             if (ready) break;
             __builtin_amdgcn_s_sleep(8);
 #pragma unroll
-            for (int k = 0; k < D; ++k)
-                if (!fin_ready(fin, v[k], w[k])) {
-                    const size_t at = 2 * ((size_t)k * P + i);
-                    v[k] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w[k] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            for (int k = 0; k < D; ++k) want[k] = !fin_ready(fin, v[k], w[k]);
+            fin_load<D>(fin, g, P, i, v, w, want);
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -312,8 +350,11 @@ __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double
             // tag -- a captured hipGraph -- cannot take the previous replay's partials for its own
             if (act) {
                 const size_t at = 2 * ((size_t)k * P + i);
-                __hip_atomic_store(g + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + at + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fin_wide(fin)) fin_store16(g + at, 0ull, 0ull);
+                else {
+                    __hip_atomic_store(g + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(g + at + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }

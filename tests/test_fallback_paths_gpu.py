@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"RK_SHIFT_KERNELS": "column"},                # no LDS-DMA streaming kernels
     {"RK_SHIFT_KERNELS": "generic"},               # per-plane generic kernels only
     {"RK_FORCE_GENERIC": "1"},                     # older spelling of the same
-], ids=["column", "generic", "force-generic"])
+    {"RK_SLAB14": "1"},                            # 14x14 planes on the slab kernels instead of the tile kernels
+], ids=["column", "generic", "force-generic", "slab14"])
 def test_parity_suite_on_fallback_kernels(env):
     e = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "bit_exact or shift_grad",

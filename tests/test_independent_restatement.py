@@ -32,6 +32,10 @@ SHAPES3 = [
     (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)),
     (2, 4, 24, 7, 7, (1, 1, 1), (0, 0, 0)),
     (3, 5, 6, 14, 14, (1, 1, 1), (0, 0, 0)),
+    (2, 8, 44, 7, 7, (1, 1, 1), (0, 0, 0)),
+    (1, 8, 576, 7, 7, (1, 1, 1), (0, 0, 0)),
+    (2, 5, 8, 7, 8, (1, 1, 1), (0, 0, 0)),
+    (2, 3, 8, 13, 15, (1, 1, 1), (0, 0, 0)),
 ]
 KINDS3 = ["generic", "wide", "integer", "half", "oob"]
 SHAPES2 = [

@@ -30,6 +30,10 @@ SHAPES = [
     (2, 3, 5, 60, 56, (1, 1, 1), (0, 0, 0)),       # one band, ragged last round
     (2, 4, 24, 7, 7, (1, 1, 1), (0, 0, 0)),        # tile kernels: 7x7, channel groups of 16 + 8
     (3, 5, 6, 14, 14, (1, 1, 1), (0, 0, 0)),       # tile kernels: 14x14, channel groups of 4 + 2, odd T
+    (2, 8, 44, 7, 7, (1, 1, 1), (0, 0, 0)),        # slab kernels (rk3d_slab.hpp): 7x7, 3 chunks, planes straddling chunk edges
+    (1, 8, 576, 7, 7, (1, 1, 1), (0, 0, 0)),       # layer4 of RubiksNet-Large: 28 chunks, the last one ragged
+    (2, 5, 8, 7, 8, (1, 1, 1), (0, 0, 0)),         # slab: one ragged chunk, odd T, H != W
+    (2, 3, 8, 13, 15, (1, 1, 1), (0, 0, 0)),       # slab: the widest plane it takes (halo of 4 cells)
 ]
 KINDS = ["generic", "wide", "integer", "half", "oob"]
 
