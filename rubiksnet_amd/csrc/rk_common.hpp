@@ -130,6 +130,18 @@ __device__ __forceinline__ float4 lds_b128(const float4* p) {
     return v;
 }
 
+// compute units of the current device, cached per device (256 on a full MI355X; fewer in partitioned modes)
+inline int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    static int cached[16] = {0};
+    if (!cached[dev]) {
+        int v = 0;
+        cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cached[dev];
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RK_OK : RK_ERR_LAUNCH; }
 
 // threads of a finalize workgroup for P partials per channel

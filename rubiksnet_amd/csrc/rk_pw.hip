@@ -1396,6 +1396,23 @@ int pw_gemm(const float* A, const void* X_, const void* R_, void* Y_, int F, int
             if (rc != RK_ERR_UNSUPPORTED) return rc;
             if (epi) return rc;                              // (the tile count was promised for this generation)
         }
+        // A training epilogue whose caller allocated 64-column tile records (what rk_pw_gemm_tiles() promises whenever
+        // rk_pw4.hip takes the shape) but which no second-generation kernel WANTED -- rk_pw4.hip declines some (epilogue,
+        // residual) pairs and rk_pw2.hip was counted on for them; with RK_PW2=0, or a shape rk_pw2.hip serves only in its
+        // slow operand mode, nobody was left and the first-generation kernel below (128-column records) answered
+        // RK_ERR_BAD_DIMS in the middle of a train step (round-4 advisor finding).  The promise is kept: such a call goes to
+        // whichever 64-column kernel CAN take it, wanted or not.
+        const long long fp = (long long)F * P;
+        if (epi && train && fp > 64 && (long long)train->J == (fp + 63) / 64) {
+            const pw2::GFuse f2 = fuse ? pw2::GFuse{fuse->ka, fuse->kb, fuse->ma, fuse->mb, fuse->relu_in, fuse->relu_out}
+                                       : pw2::GFuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
+            const pw2::GTrain t2{train->stats, train->bred, train->bx, train->bpack, train->J};
+            if (!(fuse && fuse->ma) && !(epi == 2 && R)) {
+                const int rc = pw4::gemm(A, X, R, Y, F, K, M, P, a_is_mk, &f2, &t2, epi, (hipStream_t)stream_, true);
+                if (rc != RK_ERR_UNSUPPORTED) return rc;
+            }
+            return pw2::gemm(A, X, R, Y, F, K, M, P, a_is_mk, &f2, &t2, epi, (hipStream_t)stream_, nullptr);
+        }
     }
     PwDims d;
     d.F = F; d.K = K; d.M = M; d.P = P; d.ntot = (long long)F * P; d.a_is_mk = a_is_mk;

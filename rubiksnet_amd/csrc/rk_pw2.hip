@@ -737,7 +737,7 @@ inline int make_wdims(WDims& d, const WInst& in, int ns, int F, int K, int M, in
         long long wpc = (160 * 1024) / lds;
         if (wpc > 20 / waves) wpc = 20 / waves;
         if (wpc < 1) wpc = 1;
-        S = (256 * wpc) / T;
+        S = ((long long)device_cus() * wpc) / T;             // (workspace size and launch read the same cached count)
         const long long cap = ((long long)(M + K) * d.ntot) / (4LL * M * K);
         if (S > cap) S = cap;
     }

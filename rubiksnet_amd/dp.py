@@ -16,7 +16,7 @@ import torch.nn as nn
 
 __all__ = [
     "DistEnv", "init_distributed", "shard_range", "wrap_ddp", "make_optimizer", "train_step",
-    "timed_region", "barrier",
+    "timed_region", "barrier", "ensure_process_group",
 ]
 
 
@@ -56,6 +56,27 @@ def init_distributed(prefer_gpu=True):
     return DistEnv(rank, local_rank, world, device, backend)
 
 
+def ensure_process_group(env):
+    """A process group for a job of ONE rank (RCCL on a GPU, gloo on CPU): what `bench.py --gpus 1` uses so that its
+    all-reduce probe and a DDP-wrapped replica run through the same RCCL code path as an N-rank job -- the bucket hooks,
+    `gradient_as_bucket_view` and the side-stream d(weight) kernels then meet on a device without an 8-GPU node.
+    Returns True when this call created the group (the caller destroys it)."""
+    if dist.is_initialized():
+        return False
+    import socket
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+    if env.device.type == "cuda":
+        dist.init_process_group(env.backend, rank=env.rank, world_size=env.world_size, device_id=env.device)
+    else:
+        dist.init_process_group(env.backend, rank=env.rank, world_size=env.world_size)
+    return True
+
+
 def shard_range(global_batch, rank, world_size):
     """[lo, hi) of the clips rank `rank` owns; remainder clips go to the lowest ranks."""
     base, rem = divmod(global_batch, world_size)
@@ -63,11 +84,12 @@ def shard_range(global_batch, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def wrap_ddp(model, env, bucket_cap_mb=25):
+def wrap_ddp(model, env, bucket_cap_mb=25, force=False):
     """DDP replica.  Gradient volume is tiny (Tiny 7.6 MB, Large 34 MB fp32), so a single default
     bucket size keeps the all-reduce count low; xGMI rings are per-link bound (~153 GB/s), i.e.
-    ~0.4 ms for Large -- hidden behind backward by bucket overlap."""
-    if not env.distributed:
+    ~0.4 ms for Large -- hidden behind backward by bucket overlap.  `force`: wrap at world size 1 too
+    (needs a process group: ensure_process_group)."""
+    if not env.distributed and not (force and dist.is_initialized()):
         return model
     kwargs = dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
     if env.device.type == "cuda":

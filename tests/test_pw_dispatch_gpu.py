@@ -82,3 +82,21 @@ def test_tile_promise_and_epilogues(K, M, H, Fr):
     f = 0
     ref = _ref_slice(w, x, f)
     assert float((y[f].double().cpu() - ref).abs().max()) <= 4e-6 * K ** 0.5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("env", [{"RK_PW2": "0"}, {"RK_PW4": "0"}, {"RK_PW4": "2"}, {"RK_PW2": "0", "RK_PW4": "2"}],
+                         ids=["pw2-off", "pw4-off", "pw4-everywhere", "pw2-off-pw4-everywhere"])
+def test_tile_promise_under_the_generation_switches(env):
+    """The switches are read once per process, so the sweep above runs again in a subprocess on each non-default setting
+    (round-4 advisor finding: with RK_PW2=0 the promise of rk_pw_gemm_tiles() and the dispatch disagreed for the 72 -> 72
+    conv3 with a residual: RK_ERR_BAD_DIMS in the middle of a train step)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "test_tile_promise_and_epilogues and not 512",
+           os.path.join(root, "tests", "test_pw_dispatch_gpu.py")]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

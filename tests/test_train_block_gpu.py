@@ -135,7 +135,7 @@ def test_fused_train_block_matches_fp64_reference(oracle, cin, cout, stride, dim
 
     K = max(cin, block.conv2.out_channels)
     close(out, out_ref, 4e-6 * K ** 0.5, "out")
-    big = N * T * H * W > 20000                # 14.4 M activations: a handful of them sit on a ReLU kink to fp32 round-off
+    big = N * T * H * W > 40000                # 288 x 288 on 256 frames, 14.4 M activations: a handful sit on a ReLU kink to fp32 round-off
     dxg = xg.grad
     if big and ref._near_kink is not None:
         keep = ~ref._near_kink
