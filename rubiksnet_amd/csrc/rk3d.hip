@@ -135,6 +135,11 @@ int backward_impl(const T* x, const T* shift, const T* gy, T* gx, T* gshift, int
                 if (P_out) *P_out = P;
                 return launch_status();
             }
+            if (const int P = slab3d::launch_bwd_s2(x, shift, gy, gx, P_out ? nullptr : gshift, (float*)ws, d, normalize_grad,
+                                                    t_factor, stream)) {    // stride (1,2,2), 28 -> 14 and 14 -> 7
+                if (P_out) *P_out = P;
+                return launch_status();
+            }
         } else if (!quantize && gx) {
             if (plane3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();
             if (dma3d::launch_interp<true>(gy, shift, gx, d, stream)) return launch_status();

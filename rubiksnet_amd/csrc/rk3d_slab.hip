@@ -557,6 +557,270 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stride (1,2,2), pad 0, even H and W <= 56 with Wo % 4 != 0 -- 28 -> 14 and 14 -> 7, the third and fourth down-sampling
+// layers of every network -- backward: d(x) + d(shift) in one pass.  (rk3d_stride2.hpp needs a 4-output cell; these
+// two layers ran on the column kernels: 1 619 VALU instructions per wave, 143 us at [32,8,288,28,28], 3.6 TB/s.)
+// Same scheme as above on the INPUT side: a wave owns 256 consecutive elements of the x slab (one float4 cell per lane:
+// x in through inline-asm loads, d(x) out as float4 stores); with both spatial strides 2 an input element has at most
+// ONE gy tap (rk3d_column.hpp, SINGLE: the tree collapses exactly to wj (v wk)), and the taps of 256 consecutive input
+// elements lie in a short run of the gy slab -- (h/2 - 1) .. (h/2 + 1) rows around them, <= 58 cells of 16 bytes -- that ONE
+// DMA instruction per plane brings into the wave's slot.  All T planes up front, counted waits, no barrier in the walk.
+struct S2Dims {
+    int N, T, C, H, W, HW, Wo, HWo;
+    int slab_in, slab_out;        // C * HW, C * HWo
+    int nchunks;                  // ceil(slab_in / 1024)
+};
+struct ElemS2 {
+    unsigned rel;                 // LDS byte address (slot 0) of the element's one gy tap, or of the zero cell
+    float wj, wk, sj, sk, rT;
+    bool f0, fast, slow;
+};
+constexpr int kS2Chunk = 1024, kS2Cells = 64, kS2Z = kS2Cells * 16, kS2Stride = (kS2Cells + 1) * 16;
+
+__device__ __forceinline__ void load_x4(f32x4& v, const float* sbase_uniform, int voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(v) : "v"(voff), "s"(sbase_uniform) : "memory");
+}
+// first output row's flat index in the gy slab for input element e: c HWo + (h / 2) Wo
+__device__ __forceinline__ int s2_row0(const S2Dims& d, int e) {
+    const int c = e / d.HW, p = e - c * d.HW;
+    return c * d.HWo + ((p / d.W) >> 1) * d.Wo;
+}
+template <bool INT_IS_SLOW>
+__device__ __forceinline__ bool s2_channel_is_slow(const S2Dims& d, const float* __restrict__ shift, int c) {
+    const Frac<float> fT = split_shift(-shift[c]), fH = split_shift(-shift[d.C + c]), fW = split_shift(-shift[2 * d.C + c]);
+    bool near = (unsigned)(fT.fl + 1) < 2u && (unsigned)(fH.fl + 1) < 2u && (unsigned)(fW.fl + 1) < 2u;
+    if (INT_IS_SLOW) near = near && fT.r != 0 && fH.r != 0 && fW.r != 0;
+    return !near;
+}
+
+template <bool WRITE_GX, bool FUSED>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k3d_slab_s2_backward(
+    const float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ gy, float* gx,
+    float* __restrict__ part, S2Dims d, Dims3 gd, dma3d::Fin3 fin) {
+    constexpr int M = 4;
+    const int P = 2 * d.N;
+    if (FUSED && (int)blockIdx.x >= fin.f.producers) {
+        if (threadIdx.x < kWave) {
+            const int c = (int)blockIdx.x - fin.f.producers;
+            const bool two = (c * d.HW) / kS2Chunk != ((c + 1) * d.HW - 1) / kS2Chunk;
+            dma3d::finalizer_wave<3>(fin, c, d.C, P, dma3d::BnFuse{}, two ? P : d.N);
+        }
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    __shared__ float red[3][kBlock / kWave];
+    const int tid = (int)threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = (int)(blockIdx.x % (unsigned)d.nchunks), n = (int)(blockIdx.x / (unsigned)d.nchunks);
+    const int ew0 = chunk * kS2Chunk + wave * (kWave * M);            // the wave's first input element
+    const int e0 = ew0 + M * lane;                                   // mine
+    const bool cell_live = e0 < d.slab_in;
+    const size_t nb_in = (size_t)n * d.T * d.slab_in, nb_out = (size_t)n * d.T * d.slab_out;
+
+    // shifts of my 4 elements, then my cell of every x plane (asm loads: ours to wait for), then the gy pieces
+    LaneShift<M> ls;
+    {
+        const float* sb = uniform_ptr(shift);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int c = min(e0 + m, d.slab_in - 1) / d.HW;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ls.s[m][k] = 0.f; load_f1(ls.s[m][k], sb, (k * d.C + c) * 4); }
+        }
+    }
+    f32x4 xq[kMaxT];
+    {
+        const float* xw = x + nb_in + (size_t)ew0;
+#pragma unroll
+        for (int t = 0; t < kMaxT; ++t) {
+            xq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < d.T && cell_live) load_x4(xq[t], uniform_ptr(xw + (size_t)t * d.slab_in), lane * 16);
+        }
+    }
+    // the wave's piece of a gy plane: 16-byte cells pc0 .. pc0 + 63 of the gy slab (those inside it)
+    const int ew1 = min(ew0 + kWave * M, d.slab_in);
+    const int g_lo = ew0 < d.slab_in ? s2_row0(d, ew0) - d.Wo : 0;
+    const int pc0 = __builtin_amdgcn_readfirstlane(g_lo >= 0 ? g_lo >> 2 : -((3 - g_lo) >> 2));       // floor(g_lo / 4)
+    const bool actA = ew0 < d.slab_in && pc0 + lane >= 0 && pc0 + lane < (d.slab_out >> 2);
+    const int nF = __ballot(actA) != 0ull ? 1 : 0;
+    const unsigned g0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(lds_raw)) + (unsigned)(wave * (kMaxT * kS2Stride));
+    {
+        const float* gp = gy + nb_out + (ptrdiff_t)pc0 * 4;           // never dereferenced outside the slab
+#pragma unroll
+        for (int p = 0; p < kMaxT; ++p)
+            if (p < d.T && actA) dma16s<true>(uniform_ptr(gp + (size_t)p * d.slab_out), lane * 16, g0 + (unsigned)(p * kS2Stride));
+    }
+    if (lane < kMaxT) *reinterpret_cast<float4*>(lds_raw + wave * (kMaxT * kS2Stride) + lane * kS2Stride + kS2Z) = make_float4(0.f, 0.f, 0.f, 0.f);
+    (void)ew1;
+
+    wait_vmcnt(nF * min(kMaxT, d.T));                                // the shift and x loads are older than the fetches
+    tie<M>(ls);
+    ElemS2 el[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int e = e0 + m;
+        const bool live = e < d.slab_in;
+        const int ec = live ? e : 0;
+        const int c = ec / d.HW, p = ec - c * d.HW;
+        const int h = p / d.W, w = p - h * d.W;
+        const Frac<float> fT = split_shift(-ls.s[m][0]), fH = split_shift(-ls.s[m][1]), fW = split_shift(-ls.s[m][2]);
+        const bool near = (unsigned)(fT.fl + 1) < 2u && (unsigned)(fH.fl + 1) < 2u && (unsigned)(fW.fl + 1) < 2u &&
+                          fT.r != 0 && fH.r != 0 && fW.r != 0;
+        el[m].fast = live && near;
+        el[m].slow = live && !near;
+        el[m].f0 = fT.fl == 0;
+        el[m].rT = fT.r;
+        // rubiks3d_kernels.cu:586-589 through rk3d_column.hpp (SINGLE): the one j in {0, 1} with (h + fl'H + j) even, k alike
+        const int r0 = unmap(h + fH.fl, 2, d.H >> 1), r1 = unmap(h + fH.fl + 1, 2, d.H >> 1);
+        const int c0 = unmap(w + fW.fl, 2, d.Wo), c1 = unmap(w + fW.fl + 1, 2, d.Wo);
+        const int r = r0 >= 0 ? r0 : r1, q = c0 >= 0 ? c0 : c1;
+        el[m].wj = r0 >= 0 ? 1 - fH.r : fH.r;  el[m].sj = r0 >= 0 ? 1.f : -1.f;
+        el[m].wk = c0 >= 0 ? 1 - fW.r : fW.r;  el[m].sk = c0 >= 0 ? 1.f : -1.f;
+        const int g = c * d.HWo + r * d.Wo + q - 4 * pc0;            // float index inside the piece
+        const bool ok = el[m].fast && r >= 0 && q >= 0 && g >= 0 && g < 4 * kS2Cells;
+        el[m].rel = g0 + (ok ? (unsigned)(g * 4) : (unsigned)kS2Z);
+    }
+    bool all_fast = true, thread_slow = false;
+#pragma unroll
+    for (int m = 0; m < M; ++m) { all_fast = all_fast && el[m].fast; thread_slow = thread_slow || el[m].slow; }
+    const bool regular = d.T == kMaxT && nF == 1 && __ballot(all_fast) == ~0ull;      // wave-uniform
+
+    float* optr = WRITE_GX ? gx + nb_in + (size_t)e0 : nullptr;
+    float aT[M], aH[M], aW[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { aT[m] = 0.f; aH[m] = 0.f; aW[m] = 0.f; }
+    auto walk = [&](auto REGC) {
+        constexpr bool REG = decltype(REGC)::value;
+        float Qprev[M], vprev[M], xa[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) { Qprev[m] = 0.f; vprev[m] = 0.f; xa[m] = 0.f; }
+        for_each_step(std::make_integer_sequence<int, kMaxT + 1>{}, [&](auto KC) {
+            constexpr int k = decltype(KC)::value;
+            if (!REG && k > d.T) return;
+            if (k == 0) {
+                if (REG) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(xq[4]),
+                                      "+v"(xq[5]), "+v"(xq[6]), "+v"(xq[7]) : "n"(allowed(0, 1, kMaxT, WRITE_GX)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(xq[4]),
+                                  "+v"(xq[5]), "+v"(xq[6]), "+v"(xq[7]) : : "memory");
+#pragma unroll
+                for (int m = 0; m < M; ++m) xa[m] = (el[m].fast && !el[m].f0) ? xq[0][m] : 0.f;
+            } else if (k < kMaxT && (REG || k < d.T)) {
+                if (REG) wait_lit<allowed(k < kMaxT ? k : 0, 1, kMaxT, WRITE_GX)>(); else wait_vmcnt(0);
+            }
+            float v[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) v[m] = 0.f;
+            if (k < kMaxT && (REG || k < d.T)) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) v[m] = lds_at(el[m].rel, k * kS2Stride);
+            }
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 xk = k < kMaxT ? xq[k < kMaxT ? k : 0] : zero4;
+            const f32x4 xk1 = k + 1 < kMaxT ? xq[k + 1 < kMaxT ? k + 1 : 0] : zero4;
+            float o[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float vk = v[m] * el[m].wk;
+                const float Q = el[m].wj * vk;                        // = the reference's tree with three zero taps
+                const float QH = el[m].sj * vk, QW = el[m].sk * (el[m].wj * v[m]);
+                const float uT = 1 - el[m].rT;
+                float xb = el[m].f0 ? xk[m] : xk1[m];
+                if (!REG) xb = el[m].fast ? xb : 0.f;
+                const float dx = xb - xa[m], mx = fmaf(uT, xb, el[m].rT * xa[m]);
+                aT[m] = fmaf(Q, dx, aT[m]);
+                aH[m] = fmaf(QH, mx, aH[m]);
+                aW[m] = fmaf(QW, mx, aW[m]);
+                xa[m] = xb;
+                const float vv = uT * Qprev[m] + el[m].rT * Q;
+                o[m] = el[m].f0 ? vv : vprev[m];
+                vprev[m] = vv; Qprev[m] = Q;
+            }
+            if (WRITE_GX && k >= 1) {
+                float* out = optr + (size_t)(k - 1) * d.slab_in;
+                const f32x4 t = {o[0], o[1], o[2], o[3]};
+                if (REG) {
+                    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(out));
+                } else if (cell_live) {
+                    if (all_fast) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(out));
+                    else {
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+                            if (el[m].fast) out[m] = o[m];
+                    }
+                }
+            }
+        });
+    };
+    if (regular) walk(std::true_type{}); else walk(std::false_type{});
+
+    // per-channel sums of the chunk (see k3d_slab_backward): [4][1024] floats behind the slots
+    f32x4* acc = reinterpret_cast<f32x4*>(lds_raw + (kBlock / kWave) * kMaxT * kS2Stride);
+    acc[tid] = f32x4{aT[0], aT[1], aT[2], aT[3]};
+    acc[kBlock + tid] = f32x4{aH[0], aH[1], aH[2], aH[3]};
+    acc[2 * kBlock + tid] = f32x4{aW[0], aW[1], aW[2], aW[3]};
+    acc[3 * kBlock + tid] = f32x4{el[0].slow ? 1.f : 0.f, el[1].slow ? 1.f : 0.f, el[2].slow ? 1.f : 0.f, el[3].slow ? 1.f : 0.f};
+    const int any_slow = __syncthreads_or((int)thread_slow);
+    const float* accf = reinterpret_cast<const float*>(acc);
+    const int ce0 = chunk * kS2Chunk, ce1 = min(d.slab_in, ce0 + kS2Chunk);
+    const int cA = ce0 / d.HW, cB = (ce1 - 1) / d.HW, nch = cB - cA + 1;
+    auto share = [&](int c, int& lo, int& hi) {                      // the chunk's share of channel c's INPUT plane
+        lo = max(c * d.HW, ce0) - c * d.HW;
+        hi = min((c + 1) * d.HW, ce1) - c * d.HW;
+    };
+    auto publish = [&](int c, int k, float v) {
+        const int a = (c * d.HW) / kS2Chunk, b = ((c + 1) * d.HW - 1) / kS2Chunk;
+        const size_t at = ((size_t)c * 3 + k) * P + n;               // index j N + n
+        const int j = chunk == a ? 0 : 1;
+        if (FUSED) {
+            fin_publish(fin.f, at + (size_t)j * d.N, v);
+        } else {
+            part[at + (size_t)j * d.N] = v;
+            if (a == b) part[at + d.N] = 0.f;
+        }
+    };
+    for (int base = 0; base < 3 * nch; base += kBlock / 16) {        // 16 lanes (one DPP row) per (channel, component)
+        const int item = base + (tid >> 4), sub = tid & 15;
+        const bool valid = item < 3 * nch;
+        const int it = valid ? item : 0;
+        const int k = it / nch, c = cA + it - k * nch;
+        int lo, hi;
+        share(c, lo, hi);
+        const float* a0 = accf + k * kS2Chunk + (c * d.HW - ce0);    // the plane's element 0
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                // four chains, fixed order
+        if (valid) {
+            int i = lo + sub;
+            for (; i + 48 < hi; i += 64) { s0 += a0[i]; s1 += a0[i + 16]; s2 += a0[i + 32]; s3 += a0[i + 48]; }
+            for (; i < hi; i += 16) s0 += a0[i];
+        }
+        float sum = (s0 + s1) + (s2 + s3);
+        sum += dpp_or_zero<0x111, 0xf>(sum);
+        sum += dpp_or_zero<0x112, 0xf>(sum);
+        sum += dpp_or_zero<0x114, 0xf>(sum);
+        sum += dpp_or_zero<0x118, 0xf>(sum);                         // lane 15 of the row: the item's sum
+        const bool slow_ch = a0[(3 - k) * kS2Chunk + lo] != 0.f;     // the helpers below publish a slow channel
+        if (valid && sub == 15 && !slow_ch) publish(c, k, sum);
+    }
+    if (any_slow) {
+        for (int c = cA; c <= cB; ++c) {
+            if (!s2_channel_is_slow<true>(d, shift, c)) continue;
+            int lo, hi;
+            share(c, lo, hi);
+            // the output-side helpers sum over OUTPUT elements: the chunk's share of the output plane, cut at the same fractions
+            const int lo_o = (int)(((long long)lo * d.HWo + d.HW - 1) / d.HW), hi_o = (int)(((long long)hi * d.HWo + d.HW - 1) / d.HW);
+            float sT = 0.f, sH = 0.f, sW = 0.f;
+            for (int t = 0; t < d.T; ++t) {
+                if (WRITE_GX) backward_input_plane<float, false>(shift, gy, gx, gd, n, t, c, tid, kBlock, lo, hi);
+                shift_grad_plane<float>(x, shift, gy, gd, n, t, c, tid, kBlock, sT, sH, sW, NoAct(), lo_o, hi_o);
+            }
+            sT = group_sum(sT, kBlock, red[0]);
+            sH = group_sum(sH, kBlock, red[1]);
+            sW = group_sum(sW, kBlock, red[2]);
+            if (tid == 0) { publish(c, 0, sT); publish(c, 1, sH); publish(c, 2, sW); }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side.
 // 14x14 planes: the forward / d(x)-only kernels here are level with the tile kernels at C = 216 and 10 % faster at C = 288
 // (22.0 vs 24.7 us), the fused backward is level (29.2 vs 29.1 us) and rk3d_tile.hpp has the BatchNorm-fused variants, so by
@@ -621,6 +885,37 @@ int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, f
 #undef RK_SLAB_BWD_H
 #undef RK_SLAB_BWD_R
 #undef RK_SLAB_BWD
+    return 2 * d.N;
+}
+
+
+// stride (1,2,2) backward of the small strided layers (28 -> 14, 14 -> 7); returns P (0 = not handled here)
+int launch_bwd_s2(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws, const Dims3& d,
+                  int normalize, float t_factor, hipStream_t stream) {
+    const bool s122 = d.sT == 1 && d.sH == 2 && d.sW == 2 && d.pT == 0 && d.pH == 0 && d.pW == 0;
+    if (!s122 || !streaming_kernels_on()) return 0;
+    if (d.T > kMaxT || (d.H & 1) || (d.W & 1) || d.W > 56 || d.W < 4 || d.H < 2) return 0;
+    const long long slab_in = (long long)d.C * d.H * d.W, slab_out = (long long)d.C * d.Ho * d.Wo;
+    if (slab_in % 4 != 0 || slab_out % 4 != 0 || slab_in > 0x1fffffff) return 0;
+    if (!aligned16(x) || !aligned16(gy) || (gx && !aligned16(gx))) return 0;
+    S2Dims s;
+    s.N = d.N; s.T = d.T; s.C = d.C; s.H = d.H; s.W = d.W; s.HW = d.H * d.W; s.Wo = d.Wo; s.HWo = d.Ho * d.Wo;
+    s.slab_in = (int)slab_in; s.slab_out = (int)slab_out;
+    s.nchunks = (int)((slab_in + kS2Chunk - 1) / kS2Chunk);
+    const unsigned producers = (unsigned)((long long)s.N * s.nchunks);
+    dma3d::Fin3 fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = (int)producers;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    fin.t_factor = t_factor;
+    const size_t lds = (size_t)(kBlock / kWave) * kMaxT * kS2Stride + 4 * kS2Chunk * 4;
+#define RK_SLAB_S2(GX, FU) hipLaunchKernelGGL((k3d_slab_s2_backward<GX, FU>), dim3(producers + (FU ? d.C : 0)), dim3(kBlock), lds, \
+                                              stream, x, shift, gy, gx, ws, s, d, fin)
+    if (gshift) { if (gx) RK_SLAB_S2(true, true); else RK_SLAB_S2(false, true); }
+    else { if (gx) RK_SLAB_S2(true, false); else RK_SLAB_S2(false, false); }
+#undef RK_SLAB_S2
     return 2 * d.N;
 }
 

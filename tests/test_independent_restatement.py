@@ -36,6 +36,9 @@ SHAPES3 = [
     (1, 8, 576, 7, 7, (1, 1, 1), (0, 0, 0)),
     (2, 5, 8, 7, 8, (1, 1, 1), (0, 0, 0)),
     (2, 3, 8, 13, 15, (1, 1, 1), (0, 0, 0)),
+    (2, 8, 12, 28, 28, (1, 2, 2), (0, 0, 0)),
+    (2, 8, 24, 14, 14, (1, 2, 2), (0, 0, 0)),
+    (1, 5, 4, 10, 12, (1, 2, 2), (0, 0, 0)),
 ]
 KINDS3 = ["generic", "wide", "integer", "half", "oob"]
 SHAPES2 = [

@@ -34,6 +34,9 @@ SHAPES = [
     (1, 8, 576, 7, 7, (1, 1, 1), (0, 0, 0)),       # layer4 of RubiksNet-Large: 28 chunks, the last one ragged
     (2, 5, 8, 7, 8, (1, 1, 1), (0, 0, 0)),         # slab: one ragged chunk, odd T, H != W
     (2, 3, 8, 13, 15, (1, 1, 1), (0, 0, 0)),       # slab: the widest plane it takes (halo of 4 cells)
+    (2, 8, 12, 28, 28, (1, 2, 2), (0, 0, 0)),      # slab, stride (1,2,2) backward: 28 -> 14, planes straddling chunks
+    (2, 8, 24, 14, 14, (1, 2, 2), (0, 0, 0)),      # slab, stride (1,2,2) backward: 14 -> 7
+    (1, 5, 4, 10, 12, (1, 2, 2), (0, 0, 0)),       # slab, stride (1,2,2) backward: ragged chunk, odd T, H != W
 ]
 KINDS = ["generic", "wide", "integer", "half", "oob"]
 
