@@ -59,6 +59,7 @@ int forward_impl(const T* x, const T* shift, T* y, int N, int Tn, int C, int H, 
         if (!quantize && !p14 && slab3d::launch_interp(false, x, shift, y, d, stream)) return launch_status();   // small planes
         if (quantize && xlate3d::launch<false>(x, shift, y, d, stream)) return launch_status();   // plane translation
         if (!quantize && s2::launch_forward(x, shift, y, d, stream)) return launch_status();       // stride (1,2,2)
+        if (!quantize && slab3d::launch_fwd_s2(x, shift, y, d, stream)) return launch_status();    // stride (1,2,2), 28 -> 14 and 14 -> 7
     }
     if (col3d::supported(d, quantize)) return col3d::launch_forward<T>(x, shift, y, d, stream);
     set_group(d, d.Ho * d.Wo);

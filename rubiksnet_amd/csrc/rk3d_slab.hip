@@ -821,6 +821,190 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// The forward of the same layers (stride (1,2,2), 28 -> 14 and 14 -> 7), on the OUTPUT side: a wave owns 128 consecutive
+// elements of the y slab (two per lane); the 2 x 2 tap windows of consecutive outputs tile consecutive input rows, so
+// their taps lie in ONE run of the x slab -- 4 x 128 floats + a row and a half each side, <= 160 cells -- that three DMA
+// instructions per plane bring into a ring of 3 private slots.  The rest is k3d_slab_interp's walk.
+constexpr int kF2Cells = 160, kF2Z = kF2Cells * 16, kF2Stride = (kF2Cells + 1) * 16, kF2RG = 3, kF2NF = 3, kF2Chunk = 512;
+
+__global__ __launch_bounds__(kBlock) void k3d_slab_s2_forward(const float* __restrict__ x, const float* __restrict__ shift,
+                                                              float* y, S2Dims d, Dims3 gd) {
+    constexpr int M = 2;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int tid = (int)threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = (d.slab_out + kF2Chunk - 1) / kF2Chunk;
+    const int chunk = (int)(blockIdx.x % (unsigned)nchunks), n = (int)(blockIdx.x / (unsigned)nchunks);
+    const int ow0 = chunk * kF2Chunk + wave * (kWave * M);            // the wave's first OUTPUT element
+    const int o0 = ow0 + M * lane;
+    const bool cell_live = o0 < d.slab_out;
+    const size_t nb_in = (size_t)n * d.T * d.slab_in, nb_out = (size_t)n * d.T * d.slab_out;
+
+    LaneShift<M> ls;
+    {
+        const float* sb = uniform_ptr(shift);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int c = min(o0 + m, d.slab_out - 1) / d.HWo;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ls.s[m][k] = 0.f; load_f1(ls.s[m][k], sb, (k * d.C + c) * 4); }
+        }
+    }
+    // flat index in the x slab of the input element (2 ho, 2 wo) of output element o
+    auto x0_of = [&](int o) {
+        const int c = o / d.HWo, p = o - c * d.HWo;
+        const int ho = p / d.Wo, wo = p - ho * d.Wo;
+        return c * d.HW + 2 * ho * d.W + 2 * wo;
+    };
+    const int xl = ow0 < d.slab_out ? x0_of(ow0) - d.W - 1 : 0;
+    const int pc0 = __builtin_amdgcn_readfirstlane(xl >= 0 ? xl >> 2 : -((3 - xl) >> 2));           // floor(xl / 4)
+    const int slab_cells = d.slab_in >> 2;
+    bool act[kF2NF];
+    int nF = 0;
+#pragma unroll
+    for (int i = 0; i < kF2NF; ++i) {
+        const int pc = kWave * i + lane;
+        act[i] = ow0 < d.slab_out && pc < kF2Cells && pc0 + pc >= 0 && pc0 + pc < slab_cells;
+        nF += __ballot(act[i]) != 0ull ? 1 : 0;
+    }
+    nF = __builtin_amdgcn_readfirstlane(nF);
+    const unsigned g0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(lds_raw)) + (unsigned)(wave * (kF2RG * kF2Stride));
+    const float* xp = x + nb_in + (ptrdiff_t)pc0 * 4;                 // never dereferenced outside the slab
+    auto fetch = [&](int p, int slot) {
+        const float* src = uniform_ptr(xp + (size_t)p * d.slab_in);
+#pragma unroll
+        for (int i = 0; i < kF2NF; ++i)
+            if (act[i]) dma16s<true>(src, (kWave * i + lane) * 16, g0 + (unsigned)(slot * kF2Stride + kWave * i * 16));
+    };
+#pragma unroll
+    for (int p = 0; p < kF2RG; ++p)
+        if (p < d.T) fetch(p, p);
+    if (lane < kF2RG) *reinterpret_cast<float4*>(lds_raw + wave * (kF2RG * kF2Stride) + lane * kF2Stride + kF2Z) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    wait_vmcnt(nF * min(kF2RG, d.T));                                // the shift loads are older than the fetches
+    tie<M>(ls);
+    Elem el[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int o = o0 + m;
+        const bool live = o < d.slab_out;
+        const int oc = live ? o : 0;
+        const int c = oc / d.HWo, p = oc - c * d.HWo;
+        const int ho = p / d.Wo, wo = p - ho * d.Wo;
+        const Frac<float> fT = split_shift(ls.s[m][0]), fH = split_shift(ls.s[m][1]), fW = split_shift(ls.s[m][2]);
+        const bool near = (unsigned)(fT.fl + 1) < 2u && (unsigned)(fH.fl + 1) < 2u && (unsigned)(fW.fl + 1) < 2u;
+        el[m].fast = live && near;
+        el[m].slow = live && !near;
+        el[m].f0 = fT.fl == 0;
+        el[m].rT = fT.r; el[m].rH = fH.r; el[m].rW = fW.r;
+        const int h0 = 2 * ho + fH.fl, w0 = 2 * wo + fW.fl;
+        const bool mh0 = (unsigned)h0 < (unsigned)d.H, mh1 = (unsigned)(h0 + 1) < (unsigned)d.H;
+        const bool mw0 = (unsigned)w0 < (unsigned)d.W, mw1 = (unsigned)(w0 + 1) < (unsigned)d.W;
+        const int g = c * d.HW + h0 * d.W + w0 - 4 * pc0;             // float index of tap (0,0) inside the piece
+        const bool in = g >= 0 && g + d.W + 1 < 4 * kF2Cells;
+        const unsigned a = g0 + (unsigned)(g * 4), Z = g0 + kF2Z;
+        el[m].rel[0] = el[m].fast && in && mh0 && mw0 ? a : Z;
+        el[m].rel[1] = el[m].fast && in && mh0 && mw1 ? a + 4u : Z;
+        el[m].rel[2] = el[m].fast && in && mh1 && mw0 ? a + 4u * d.W : Z;
+        el[m].rel[3] = el[m].fast && in && mh1 && mw1 ? a + 4u * d.W + 4u : Z;
+    }
+    bool all_fast = true, thread_slow = false;
+#pragma unroll
+    for (int m = 0; m < M; ++m) { all_fast = all_fast && el[m].fast; thread_slow = thread_slow || el[m].slow; }
+    const bool regular = d.T == kMaxT && nF == kF2NF && __ballot(all_fast) == ~0ull;      // wave-uniform
+
+    float* optr = y + nb_out + (size_t)o0;
+    auto walk = [&](auto REGC) {
+        constexpr bool REG = decltype(REGC)::value;
+        float Bprev[M], vprev[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) { Bprev[m] = 0.f; vprev[m] = 0.f; }
+        for_each_step(std::make_integer_sequence<int, kMaxT + 1>{}, [&](auto KC) {
+            constexpr int k = decltype(KC)::value;
+            if (!REG && k > d.T) return;
+            float B[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) B[m] = 0.f;
+            if (k < kMaxT && (REG || k < d.T)) {
+                if (REG) wait_lit<allowed(k < kMaxT ? k : 0, kF2NF, kF2RG, true)>(); else wait_vmcnt(0);
+                float q[M][4];
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[m][j] = lds_at(el[m].rel[j], (k % kF2RG) * kF2Stride);
+                if (k + kF2RG < kMaxT && (REG || k + kF2RG < d.T)) fetch(k + kF2RG, k % kF2RG);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float uW = 1 - el[m].rW, uH = 1 - el[m].rH;
+                    B[m] = uH * (q[m][0] * uW + q[m][1] * el[m].rW) + el[m].rH * (q[m][2] * uW + q[m][3] * el[m].rW);
+                }
+            }
+            float o[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float v = (1 - el[m].rT) * Bprev[m] + el[m].rT * B[m];
+                o[m] = el[m].f0 ? v : vprev[m];
+                vprev[m] = v; Bprev[m] = B[m];
+            }
+            if (k >= 1) {
+                float* out = optr + (size_t)(k - 1) * d.slab_out;
+                const f32x2 t = {o[0], o[1]};
+                if (REG) {
+                    __builtin_nontemporal_store(t, reinterpret_cast<f32x2*>(out));
+                } else if (cell_live) {
+                    if (all_fast) __builtin_nontemporal_store(t, reinterpret_cast<f32x2*>(out));
+                    else {
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+                            if (el[m].fast) out[m] = o[m];
+                    }
+                }
+            }
+        });
+    };
+    if (regular) walk(std::true_type{}); else walk(std::false_type{});
+
+    if (__syncthreads_or((int)thread_slow)) {                        // workgroup-uniform from here on: the generic loop per slow channel
+        const int ce0 = chunk * kF2Chunk, ce1 = min(d.slab_out, ce0 + kF2Chunk);
+        for (int c = ce0 / d.HWo; c <= (ce1 - 1) / d.HWo; ++c) {
+            const Frac<float> fT = split_shift(shift[c]), fH = split_shift(shift[d.C + c]), fW = split_shift(shift[2 * d.C + c]);
+            if ((unsigned)(fT.fl + 1) < 2u && (unsigned)(fH.fl + 1) < 2u && (unsigned)(fW.fl + 1) < 2u) continue;
+            const int lo = max(c * d.HWo, ce0) - c * d.HWo, hi = min((c + 1) * d.HWo, ce1) - c * d.HWo;
+            const float* xc = x + nb_in + (size_t)c * d.HW;
+            for (int to = 0; to < d.T; ++to) {
+                float* yp = y + nb_out + (size_t)to * d.slab_out + (size_t)c * d.HWo;
+                const int t0 = to + fT.fl;
+                const bool v0 = t0 >= 0 && t0 < d.T, v1 = t0 + 1 >= 0 && t0 + 1 < d.T;
+                const float* p0 = xc + (v0 ? (size_t)t0 * d.slab_in : 0);
+                const float* p1 = xc + (v1 ? (size_t)(t0 + 1) * d.slab_in : 0);
+                for (int i = lo + tid; i < hi; i += kBlock) {
+                    const int ho = i / d.Wo, wo = i - ho * d.Wo;
+                    const int h0 = 2 * ho + fH.fl, w0 = 2 * wo + fW.fl;
+                    const bool mh0 = h0 >= 0 && h0 < d.H, mh1 = h0 + 1 >= 0 && h0 + 1 < d.H;
+                    const bool mw0 = w0 >= 0 && w0 < d.W, mw1 = w0 + 1 >= 0 && w0 + 1 < d.W;
+                    const int o00 = h0 * d.W + w0;
+                    float q000 = 0, q001 = 0, q010 = 0, q011 = 0, q100 = 0, q101 = 0, q110 = 0, q111 = 0;
+                    if (v0) {
+                        if (mh0 && mw0) q000 = p0[o00];
+                        if (mh0 && mw1) q001 = p0[o00 + 1];
+                        if (mh1 && mw0) q010 = p0[o00 + d.W];
+                        if (mh1 && mw1) q011 = p0[o00 + d.W + 1];
+                    }
+                    if (v1) {
+                        if (mh0 && mw0) q100 = p1[o00];
+                        if (mh0 && mw1) q101 = p1[o00 + 1];
+                        if (mh1 && mw0) q110 = p1[o00 + d.W];
+                        if (mh1 && mw1) q111 = p1[o00 + d.W + 1];
+                    }
+                    yp[i] = trilerp(q000, q001, q010, q011, q100, q101, q110, q111, fT.r, fH.r, fW.r);
+                }
+            }
+        }
+    }
+    (void)gd;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side.
 // 14x14 planes: the forward / d(x)-only kernels here are level with the tile kernels at C = 216 and 10 % faster at C = 288
 // (22.0 vs 24.7 us), the fused backward is level (29.2 vs 29.1 us) and rk3d_tile.hpp has the BatchNorm-fused variants, so by
@@ -888,6 +1072,25 @@ int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, f
     return 2 * d.N;
 }
 
+
+// forward of the same layers; false = not handled here
+bool launch_fwd_s2(const float* x, const float* shift, float* y, const Dims3& d, hipStream_t stream) {
+    const bool s122 = d.sT == 1 && d.sH == 2 && d.sW == 2 && d.pT == 0 && d.pH == 0 && d.pW == 0;
+    if (!s122 || !streaming_kernels_on()) return false;
+    if (d.T > kMaxT || (d.H & 1) || (d.W & 1) || d.W > 56 || d.W < 4 || d.H < 2) return false;
+    const long long slab_in = (long long)d.C * d.H * d.W, slab_out = (long long)d.C * d.Ho * d.Wo;
+    if (slab_in % 4 != 0 || slab_out % 2 != 0 || slab_in > 0x1fffffff) return false;
+    if (!aligned16(x) || !aligned16(y)) return false;
+    // the piece of a wave: 4 x 128 floats of windows + a row and a column each side, in 16-byte cells
+    if ((4 * kWave * 2 + 2 * d.W + 2 + 3) / 4 + 2 > kF2Cells) return false;
+    S2Dims s;
+    s.N = d.N; s.T = d.T; s.C = d.C; s.H = d.H; s.W = d.W; s.HW = d.H * d.W; s.Wo = d.Wo; s.HWo = d.Ho * d.Wo;
+    s.slab_in = (int)slab_in; s.slab_out = (int)slab_out;
+    s.nchunks = 0;
+    const unsigned grid = (unsigned)((long long)s.N * ((slab_out + kF2Chunk - 1) / kF2Chunk));
+    hipLaunchKernelGGL(k3d_slab_s2_forward, dim3(grid), dim3(kBlock), (size_t)(kBlock / kWave) * kF2RG * kF2Stride, stream, x, shift, y, s, d);
+    return true;
+}
 
 // stride (1,2,2) backward of the small strided layers (28 -> 14, 14 -> 7); returns P (0 = not handled here)
 int launch_bwd_s2(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws, const Dims3& d,

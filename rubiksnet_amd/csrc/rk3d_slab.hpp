@@ -15,6 +15,7 @@ int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, f
                int normalize, float t_factor, hipStream_t stream);
 
 // the same for stride (1,2,2) / pad 0 on even planes up to 56 wide (the layers rk3d_stride2.hpp does not take: 28 -> 14, 14 -> 7)
+bool launch_fwd_s2(const float* x, const float* shift, float* y, const Dims3& d, hipStream_t stream);
 int launch_bwd_s2(const float* x, const float* shift, const float* gy, float* gx, float* gshift, float* ws, const Dims3& d,
                   int normalize, float t_factor, hipStream_t stream);
 
