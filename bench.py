@@ -758,6 +758,8 @@ def main():
     ap.add_argument("--model-batch", type=int, default=32, help="clips per GPU for the train-step legs")
     ap.add_argument("--model-steps", type=int, default=6)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary kernel legs (2-D, strided / small planes, "
+                    "temporal, GEMM, BatchNorm): what tools/rocprof_stats.sh traces is then the headline operator alone")
     ap.add_argument("--settle", type=float, default=0.4,
                     help="seconds of untimed continuous load before the warm-up steps (clock / power settle)")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: launcher / rendezvous / timing only (gloo)")
@@ -804,7 +806,10 @@ def main():
     # communicator down -- untested on RCCL, flagged by the round-2 review.)  The other ranks idle at the barrier.
     traffic, traffic_src = pmc_traffic("backward")
     rk2d = secondary = tshift = pw16 = pw32 = bnleg = cpu = None
-    if env.is_main:
+    if env.is_main and args.no_legs:
+        if not args.no_cpu:
+            cpu = cpu_baseline()
+    elif env.is_main:
         rk2d = op2d_bench(env)
         secondary = secondary_points(env)
         try:

@@ -279,6 +279,12 @@ size_t rk_pw_packed_bytes(int rows, int depth);
 int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_stream_t stream);
 int rk_pw_gemm_packed_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P,
                            rk_stream_t stream);
+/* training (round 5): the same GEMM + the tile statistics of Y for the BatchNorm that consumes it (backbone.py:50-53 after
+ * :44-45 under autocast): stats float4 [M][tiles] = (pivot, sum(y - pivot), sum((y - pivot)^2), columns) per 64 columns of
+ * the values as stored, tiles = rk_pw16_stat_tiles(F, P); finished by rk_bn_finish_tiles_f32. */
+int rk_pw16_stat_tiles(int F, int P);
+int rk_pw_gemm_packed_stats_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P,
+                                 void* stats, int tiles, rk_stream_t stream);
 /*   rk_pw_wgrad16_bf16: d(weight)[M][K] (fp32) = sum_f dY[f] X[f]^T for bf16 dY [F,M,P], X [F,K,P] (P % 4 == 0, P >= 8):
  *                   both operands DMA'd fragment-wise, output tiles of up to 160 x 160 per workgroup; ws of
  *                   rk_pw_wgrad16_workspace_bytes() bytes (per-split partial matrices, summed in a fixed order). */
@@ -417,6 +423,8 @@ int rk_bn_finish_tiles_f32(const void* stats, int tiles, long long count, const 
                            float* b, float* abmi /* [C][4] packed copy, may be NULL */, int C, float eps, float momentum,
                            long long* num_batches_tracked, rk_stream_t stream);
 int rk_bn_tile_stats_f32(const float* x, void* stats, int F, int C, int P, rk_stream_t stream);
+int rk_bn_apply_affine_bf16(const void* x, const float* a, const float* b, void* y, int F, int C, int P, int relu,
+                            rk_stream_t stream);
 int rk_bn_apply_affine_f32(const float* x, const float* a, const float* b, float* y, int F, int C, int P, int relu,
                            rk_stream_t stream);
 int rk_bn_bwd_finish_tiles_f32(const void* bred, int tiles, long long count, float* k12, float* dgamma, float* dbeta,

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rk_pw_packed_bytes": (_sz, [_i, _i]),
     "rk_pw_pack_bf16": (_i, [_p, _i, _i, _p, _p, _p]),
     "rk_pw_gemm_packed_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_pw16_stat_tiles": (_i, [_i, _i]),
+    "rk_pw_gemm_packed_stats_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rk_pw_wgrad16_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_pw_wgrad16_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_stem_conv3x3s2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -88,6 +90,7 @@ SIGNATURES = {
                                     ctypes.c_float, _p, _p]),
     "rk_bn_tile_stats_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "rk_bn_apply_affine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_bn_apply_affine_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rk_bn_bwd_finish_tiles_f32": (_i, [_p, _i, ctypes.c_longlong, _p, _p, _p, _i, _p]),
     "rk_bn_bwd_dx_pre_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rk_bn_bwd_dx_pre_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -638,6 +638,20 @@ int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save
 using namespace rk;
 using namespace rk::bn;
 
+template <typename T>
+static int bn_apply_affine(const T* x, const float* a, const float* b, T* y, int F, int C, int P, int relu, rk_stream_t stream) {
+    if (!x || !a || !b || !y) return RK_ERR_NULL_POINTER;
+    BnDims d;
+    if (int rc = make_bn(d, F, C, P)) return rc;
+    const dim3 grid(grid_bn(d)), block(kBlock);
+    const bool v4 = vec4_ok<T>(d, x, y);
+#define RK_AA(VEC, RELU) hipLaunchKernelGGL((k_bn_apply_affine<T, VEC, RELU>), grid, block, 0, (hipStream_t)stream, x, a, b, y, d)
+    if (v4) { if (relu) RK_AA(4, true); else RK_AA(4, false); }
+    else { if (relu) RK_AA(1, true); else RK_AA(1, false); }
+#undef RK_AA
+    return launch_status();
+}
+
 extern "C" {
 
 size_t rk_bn_workspace_bytes(int F, int C, int P) {
@@ -677,16 +691,11 @@ int rk_bn_tile_stats_f32(const float* x, void* stats, int F, int C, int P, rk_st
 // y = relu?(a[c] x + b[c])
 int rk_bn_apply_affine_f32(const float* x, const float* a, const float* b, float* y, int F, int C, int P, int relu,
                            rk_stream_t stream) {
-    if (!x || !a || !b || !y) return RK_ERR_NULL_POINTER;
-    BnDims d;
-    if (int rc = make_bn(d, F, C, P)) return rc;
-    const dim3 grid(grid_bn(d)), block(kBlock);
-    const bool v4 = vec4_ok<float>(d, x, y);
-#define RK_AA(VEC, RELU) hipLaunchKernelGGL((k_bn_apply_affine<float, VEC, RELU>), grid, block, 0, (hipStream_t)stream, x, a, b, y, d)
-    if (v4) { if (relu) RK_AA(4, true); else RK_AA(4, false); }
-    else { if (relu) RK_AA(1, true); else RK_AA(1, false); }
-#undef RK_AA
-    return launch_status();
+    return bn_apply_affine<float>(x, a, b, y, F, C, P, relu, stream);
+}
+int rk_bn_apply_affine_bf16(const void* x, const float* a, const float* b, void* y, int F, int C, int P, int relu,
+                            rk_stream_t stream) {
+    return bn_apply_affine<__hip_bfloat16>((const __hip_bfloat16*)x, a, b, (__hip_bfloat16*)y, F, C, P, relu, stream);
 }
 // bred: float2 [C][tiles] from rk_pw_gemm_bnbwd_f32 (or the shift backward) -> k12 [2][C] = (sum dz / count,
 // sum dz xhat / count), d(gamma), d(beta)

@@ -86,9 +86,14 @@ __device__ __forceinline__ const char* uniform_bytes(const char* p) {
 // a workgroup covers 32 RB rows (blockIdx.y selects the row range when M is larger).  DX: stages of the X ring.
 // Waves 0-1 issue the X DMAs (counted vmcnt), waves 2-3 move the A chunks (ordinary loads, compiler-counted): vmcnt is
 // per wave and in order, so a wave doing both could not wait for its A chunk without draining the X prefetch.
-template <int RB, bool RES, int DX>
+// STATS (training, round 5): the tile statistics of Y for the BatchNorm that consumes it -- stats[row][2 blockIdx.x + column
+// group] = (pivot, sum(y - pivot), sum((y - pivot)^2), columns) over the wave's 64 columns, of the values AS STORED (rounded
+// to bf16), the record rk_bn_finish_tiles_f32 finishes (rk_bn.hip) -- so that the consumer's statistics pass over Y
+// (k_bn_stats: 98 launches, 1.5 ms of a Large-AQ train step) never runs.
+template <int RB, bool RES, int DX, bool STATS = false>
 __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict__ Apk, const __hip_bfloat16* __restrict__ X,
-                                                         const __hip_bfloat16* R, __hip_bfloat16* Y, Dims d) {
+                                                         const __hip_bfloat16* R, __hip_bfloat16* Y, Dims d,
+                                                         float4* __restrict__ stats = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int kAStage = 2 * RB * 1024;
     char* Xs = lds;                                  // [DX][kXStage]
@@ -173,11 +178,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     const long long ug = (long long)blockIdx.x * 16 + 8 * cgp + (n >> 1);
     const bool out_ok = ug < d.nunits;
     size_t at0 = 0;                                  // element offset of this lane's UNIT in row 0 of its frame's output
+    bool repeated = false;                           // this lane's 4 pixels are the repeated half of a frame's last unit
     {
         const long long q = out_ok ? ug : 0;
         const int f = (int)(q / d.U), j = (int)(q - (long long)f * d.U);
         const int p = (odd_tail && j == d.U - 1) ? d.P - 8 : 8 * j;  // (a frame's last unit: its repeated half is stored again,
         at0 = ((size_t)f * d.M) * d.P + p;                           //  with the identical values)
+        repeated = odd_tail && j == d.U - 1 && (n & 1) == 0;
     }
     const int half = n & 1;                          // this lane's 4 pixels within the unit
     const int rowb = 16 * (rb0 + rh * RB) + 4 * g;
@@ -281,6 +288,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     // swap two rows each (DPP) so that every lane stores 2 rows x 16 bytes instead of 4 rows x 8: the epilogue is
     // store-ISSUE bound (MI355X_MICROARCH.md, "attention epilogue store tail").
     const unsigned hm = 0u - (unsigned)half;          // all ones in the odd lane of a pair
+    const bool counted = out_ok && !repeated;        // STATS: this lane's 4 columns exist (once) in Y
+    float ncols = 0.f;
+    if (STATS) {
+        ncols = counted ? 4.f : 0.f;
+        ncols += dpp_or_zero<0x111, 0xf>(ncols); ncols += dpp_or_zero<0x112, 0xf>(ncols);
+        ncols += dpp_or_zero<0x114, 0xf>(ncols); ncols += dpp_or_zero<0x118, 0xf>(ncols);     // lane n = 15: the wave's columns
+    }
+    const int J = 2 * (int)gridDim.x;
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         unsigned w[4][2];
@@ -288,6 +303,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         for (int i = 0; i < 4; ++i) {
             w[i][0] = bf16_bits(acc[r][0][i]) | (bf16_bits(acc[r][1][i]) << 16);
             w[i][1] = bf16_bits(acc[r][2][i]) | (bf16_bits(acc[r][3][i]) << 16);
+        }
+        if (STATS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y0 = __uint_as_float(w[i][0] << 16), y1 = __uint_as_float(w[i][0] & 0xffff0000u);
+                const float y2 = __uint_as_float(w[i][1] << 16), y3 = __uint_as_float(w[i][1] & 0xffff0000u);
+                // pivot: the row's first column of this wave (lane n = 0 of the 16-lane row; 0 when that column does not exist)
+                const float piv = __shfl(counted ? y0 : 0.f, lane & 48);
+                const float e0 = y0 - piv, e1 = y1 - piv, e2 = y2 - piv, e3 = y3 - piv;
+                float s1 = counted ? (e0 + e1) + (e2 + e3) : 0.f;
+                float s2 = counted ? fmaf(e0, e0, e1 * e1) + fmaf(e2, e2, e3 * e3) : 0.f;
+                s1 += dpp_or_zero<0x111, 0xf>(s1); s2 += dpp_or_zero<0x111, 0xf>(s2);
+                s1 += dpp_or_zero<0x112, 0xf>(s1); s2 += dpp_or_zero<0x112, 0xf>(s2);
+                s1 += dpp_or_zero<0x114, 0xf>(s1); s2 += dpp_or_zero<0x114, 0xf>(s2);
+                s1 += dpp_or_zero<0x118, 0xf>(s1); s2 += dpp_or_zero<0x118, 0xf>(s2);
+                const int row = rowb + 16 * r + i;
+                if (n == 15 && row < d.M) stats[(size_t)row * J + 2 * blockIdx.x + cgp] = make_float4(piv, s1, s2, ncols);
+            }
         }
         // even lane keeps rows 0, 1 and receives the partner's halves of them; odd lane keeps rows 2, 3
         unsigned send[2][2], recv[2][2];
@@ -314,18 +347,18 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
 
 inline int rows_per_wave(int nrb) { return nrb > 10 ? 9 : (nrb > 6 ? 5 : 3); }
 
-template <int RB, bool RES, int DX>
+template <int RB, bool RES, int DX, bool STATS = false>
 int launch_gemm(const char* Apk, const __hip_bfloat16* X, const __hip_bfloat16* R, __hip_bfloat16* Y, const Dims& d,
-                hipStream_t stream) {
+                hipStream_t stream, float4* stats = nullptr) {
     constexpr size_t lds = (size_t)DX * kXStage + (size_t)2 * 2 * RB * 1024;
     static bool raised = false;                      // > 64 KB of dynamic LDS needs the attribute, once per instance
     if (lds > 65536 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_gemm<RB, RES, DX>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_gemm<RB, RES, DX, STATS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RK_ERR_LAUNCH;
         raised = true;
     }
     const dim3 grid((unsigned)((d.nunits + 15) / 16), (unsigned)((d.nrb + 2 * RB - 1) / (2 * RB)));
-    hipLaunchKernelGGL((k_pw16_gemm<RB, RES, DX>), grid, dim3(kBlock), lds, stream, Apk, X, R, Y, d);
+    hipLaunchKernelGGL((k_pw16_gemm<RB, RES, DX, STATS>), grid, dim3(kBlock), lds, stream, Apk, X, R, Y, d, stats);
     return launch_status();
 }
 
@@ -590,6 +623,39 @@ int rk_pw_gemm_packed_bf16(const void* Apk, const void* X_, const void* R_, void
     const char* A = (const char*)Apk;
     const int rb = rows_per_wave(d.nrb);
 #define RK_GO(RBV, DXV) (R ? launch_gemm<RBV, true, DXV>(A, X, R, Y, d, stream) : launch_gemm<RBV, false, DXV>(A, X, R, Y, d, stream))
+    if (rb == 9) return RK_GO(9, 3);
+    if (rb == 5) return RK_GO(5, 3);
+    return RK_GO(3, 3);
+#undef RK_GO
+}
+
+// The same GEMM in training: also the tile statistics of Y (float4 [M][tiles], tiles = rk_pw16_stat_tiles(F, P): one record
+// per 64 columns) for the BatchNorm that consumes Y -- finished by rk_bn_finish_tiles_f32.
+int rk_pw16_stat_tiles(int F, int P) {
+    if (F <= 0 || P < 8) return 0;
+    const long long nunits = (long long)F * ((P + 7) / 8);
+    return (int)(2 * ((nunits + 15) / 16));
+}
+int rk_pw_gemm_packed_stats_bf16(const void* Apk, const void* X_, const void* R_, void* Y_, int F, int K, int M, int P,
+                                 void* stats, int tiles, rk_stream_t stream_) {
+    const __hip_bfloat16* X = (const __hip_bfloat16*)X_;
+    const __hip_bfloat16* R = (const __hip_bfloat16*)R_;
+    __hip_bfloat16* Y = (__hip_bfloat16*)Y_;
+    if (!Apk || !X || !Y || !stats) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || K <= 0 || M <= 0 || P < 8 || P % 4 != 0) return RK_ERR_BAD_DIMS;
+    if (((uintptr_t)Apk & 15) || ((uintptr_t)X & 7) || ((uintptr_t)Y & 7) || (R && ((uintptr_t)R & 7)) || ((uintptr_t)stats & 15))
+        return RK_ERR_BAD_DIMS;
+    if ((long long)F * K * P * 2 >= (1ll << 31)) return RK_ERR_BAD_DIMS;
+    if (tiles != rk_pw16_stat_tiles(F, P)) return RK_ERR_BAD_DIMS;
+    Dims d;
+    d.F = F; d.K = K; d.M = M; d.P = P;
+    d.nrb = (M + 15) / 16; d.nch = (K + kCh - 1) / kCh;
+    d.U = (P + 7) / 8; d.nunits = (long long)F * d.U;
+    hipStream_t stream = (hipStream_t)stream_;
+    const char* A = (const char*)Apk;
+    const int rb = rows_per_wave(d.nrb);
+    float4* st = (float4*)stats;
+#define RK_GO(RBV, DXV) (R ? launch_gemm<RBV, true, DXV, true>(A, X, R, Y, d, stream, st) : launch_gemm<RBV, false, DXV, true>(A, X, R, Y, d, stream, st))
     if (rb == 9) return RK_GO(9, 3);
     if (rb == 5) return RK_GO(5, 3);
     return RK_GO(3, 3);

@@ -32,16 +32,64 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+# ---- tile statistics handed over by the GEMM that produced a tensor (rk_pw_gemm_packed_stats_bf16, round 5) ----
+def attach_stats(t, stats):
+    """`stats` (float4 [C][tiles], one record per 64 columns) describe `t` as it is now."""
+    t._rk_stats = stats
+    t._rk_stats_count = t.numel() // t.shape[1]
+    t._rk_stats_version = t._version          # an in-place edit of the tensor invalidates them
+    return t
+
+
+def take_stats(x):
+    st = getattr(x, "_rk_stats", None)
+    if st is None:
+        return None
+    if (st.dim() != 3 or st.shape[0] != x.shape[1] or st.shape[1] < 1 or st.shape[2] != 4 or st.device != x.device
+            or st.dtype != torch.float32 or getattr(x, "_rk_stats_count", None) != x.numel() // x.shape[1]
+            or getattr(x, "_rk_stats_version", None) != x._version):
+        return None
+    return st
+
+
+def _finish_tiles(L, stats, count, weight, bias, running_mean, running_var, momentum, eps, counter_ptr, dev, stream):
+    """Tile records -> rows (mean, invstd, a, b) [+ 4 packed rows]; running statistics / num_batches_tracked as
+    nn.BatchNorm2d's training forward (the same finisher the fp32 fused block uses, train_block._finish)."""
+    C = weight.shape[0]
+    out = torch.empty(8, C, dtype=torch.float32, device=dev)
+    _native.check(L.rk_bn_finish_tiles_f32(stats.data_ptr(), stats.shape[1], count, weight.data_ptr(), bias.data_ptr(),
+                                           _ptr(running_mean), _ptr(running_var), out[0].data_ptr(), out[1].data_ptr(),
+                                           out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(), C, float(eps),
+                                           float(momentum), counter_ptr, stream), "rk_bn_finish_tiles_f32")
+    return out
+
+
 class _BNReLUTrain(torch.autograd.Function):
     """y = relu?(batch_norm(x)) with batch statistics; updates running_mean / running_var in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, with_skip=False, counter_ptr=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, with_skip=False, counter_ptr=None,
+                stats=None):
         L = _native.lib()
         Fr, C, H, W = x.shape
         P = H * W
         dev = x.device
         y = torch.empty_like(x)
+        if stats is not None:
+            # the producing GEMM already reduced x tile by tile: finish + ONE normalising pass (no statistics pass over x)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                fin = _finish_tiles(L, stats, Fr * P, weight, bias, running_mean, running_var, momentum, eps, counter_ptr, dev,
+                                    stream)
+                _native.check(getattr(L, "rk_bn_apply_affine_" + _SFX[x.dtype])(
+                    x.data_ptr(), fin[2].data_ptr(), fin[3].data_ptr(), y.data_ptr(), Fr, C, P, int(relu), stream),
+                    "rk_bn_apply_affine")
+            ctx.save_for_backward(x, weight, bias, fin[0], fin[1])
+            ctx.relu = relu
+            ctx.with_skip = with_skip
+            if with_skip:
+                return y, x.view_as(x)
+            return y
         save_mean = torch.empty(C, dtype=torch.float32, device=dev)
         save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -86,7 +134,7 @@ class _BNReLUTrain(torch.autograd.Function):
                 save_invstd.data_ptr(), _ptr(dskip), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, P,
                 int(ctx.relu), ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "rk_bn_relu_backward")
-        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(bias.dtype), None, None, None, None, None, None, None, None
 
 
 class _BNReLUTShiftTrain(torch.autograd.Function):
@@ -97,24 +145,29 @@ class _BNReLUTShiftTrain(torch.autograd.Function):
     for the block's identity shortcut, whose gradient joins inside the d(x) kernel (cf. _BNReLUTrain with_skip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, taps, running_mean, running_var, momentum, eps, n_segment, counter_ptr):
+    def forward(ctx, x, weight, bias, taps, running_mean, running_var, momentum, eps, n_segment, counter_ptr, stats=None):
         L = _native.lib()
         Fr, C, H, W = x.shape
         P = H * W
         dev = x.device
         sfx = _SFX[x.dtype]
-        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
-        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
-        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
         taps32 = taps.detach().float().contiguous()
         y = torch.empty_like(x)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            ws, nbytes = _ws(L, Fr, C, P, dev)
-            _native.check(getattr(L, "rk_bn_stats_finish_" + sfx)(
-                x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var), save_mean.data_ptr(),
-                save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(), nbytes,
-                stream), "rk_bn_stats_finish")
+            if stats is not None:          # x came out of a GEMM that reduced it tile by tile: no statistics pass
+                fin = _finish_tiles(L, stats, Fr * P, weight, bias, running_mean, running_var, momentum, eps, counter_ptr, dev,
+                                    stream)
+                save_mean, save_invstd, ab = fin[0], fin[1], fin[2:4]
+            else:
+                save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+                save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+                ws, nbytes = _ws(L, Fr, C, P, dev)
+                _native.check(getattr(L, "rk_bn_stats_finish_" + sfx)(
+                    x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var), save_mean.data_ptr(),
+                    save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(),
+                    nbytes, stream), "rk_bn_stats_finish")
             _native.check(getattr(L, "rk_tshift3_bn_forward_" + sfx)(
                 x.data_ptr(), taps32.data_ptr(), ab.data_ptr(), y.data_ptr(), Fr, n_segment, C, P, stream),
                 "rk_tshift3_bn_forward")
@@ -158,7 +211,8 @@ class _BNReLUTShiftTrain(torch.autograd.Function):
             _native.check(getattr(L, "rk_bn_bwd_dx_pre_" + sfx)(
                 dz.data_ptr(), x.data_ptr(), weight.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), k12.data_ptr(),
                 _ptr(dskip), dz.data_ptr(), Fr, C, P, stream), "rk_bn_bwd_dx_pre")            # in place: dz -> d(x)
-        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gtaps.to(ctx.taps_dtype), None, None, None, None, None, None)
+        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gtaps.to(ctx.taps_dtype), None, None, None, None, None, None,
+                None)
 
 
 def bn_relu_tshift_skip(bn, shift, x):
@@ -176,7 +230,8 @@ def bn_relu_tshift_skip(bn, shift, x):
     momentum, counter = _count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BNReLUTShiftTrain.apply(x, bn.weight, bn.bias, shift.soft_taps(), rm, rv, momentum, bn.eps, S, _ptr(counter))
+    return _BNReLUTShiftTrain.apply(x, bn.weight, bn.bias, shift.soft_taps(), rm, rv, momentum, bn.eps, S, _ptr(counter),
+                                    take_stats(x))
 
 
 def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):
@@ -231,7 +286,8 @@ def bn_relu_skip(bn, x):
         momentum, counter = _count_batch(bn)
         rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
         rv = bn.running_var if (bn.training and bn.track_running_stats) else None
-        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, True, True, _ptr(counter))
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, True, True, _ptr(counter),
+                                  take_stats(x) if bn.training else None)
     return bn_relu(bn, x), x
 
 
@@ -246,7 +302,8 @@ def bn_relu(bn, x, relu=True):
         momentum, counter = _count_batch(bn)
         rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
         rv = bn.running_var if (bn.training and bn.track_running_stats) else None
-        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, False, _ptr(counter))
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, False, _ptr(counter),
+                                  take_stats(x) if bn.training else None)
     if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
         y = bn(x)                                  # frozen-statistics fine-tuning: stock kernels
         return F.relu(y, inplace=True) if relu else y

@@ -116,16 +116,28 @@ class _Conv1x1Func(torch.autograd.Function):
     d(weight) is the HIP kernel either way (it wins on every shape: MIOpen's needs two layout transposes)."""
 
     @staticmethod
-    def forward(ctx, x, weight, hip_gemm, residual, hip_dx=None):
+    def forward(ctx, x, weight, hip_gemm, residual, hip_dx=None, want_stats=False):
         Fr, Cin, H, W = x.shape
         Cout = weight.shape[0]
         ctx.packed_bwd = None
+        stats = None
         if hip_gemm:
             y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
             fwd = None
             if _packed_ok(weight, x, Cin, Cout, H * W, True):
                 fwd, ctx.packed_bwd = _pack(weight)
-            _gemm(weight, x, y, Fr, Cin, Cout, H * W, True, residual, fwd)      # `+ residual` in the GEMM's epilogue
+            if want_stats and fwd is not None:
+                # training: the GEMM also leaves the tile statistics of y for the BatchNorm that consumes it (fused_bn.py)
+                L = _native.lib()
+                J = int(L.rk_pw16_stat_tiles(Fr, H * W))
+                stats = torch.empty(Cout, J, 4, dtype=torch.float32, device=x.device)
+                with torch.cuda.device(x.device):
+                    _native.check(L.rk_pw_gemm_packed_stats_bf16(
+                        fwd.data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), Fr, Cin,
+                        Cout, H * W, stats.data_ptr(), J, torch.cuda.current_stream(x.device).cuda_stream),
+                        "rk_pw_gemm_packed_stats_bf16")
+            else:
+                _gemm(weight, x, y, Fr, Cin, Cout, H * W, True, residual, fwd)  # `+ residual` in the GEMM's epilogue
         else:
             y = torch.ops.aten.convolution(x, _as(weight, x.dtype), None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
             if residual is not None:
@@ -133,10 +145,15 @@ class _Conv1x1Func(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.hip_dx = hip_gemm if hip_dx is None else hip_dx
         ctx.has_residual = residual is not None
+        if want_stats:
+            if stats is None:
+                stats = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
@@ -152,7 +169,7 @@ class _Conv1x1Func(torch.autograd.Function):
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dy, x, weight)
-        return dx, dw, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None), None
+        return dx, dw, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None), None, None
 
 
 def _eligible(conv, x, has_residual=False):
@@ -405,6 +422,11 @@ def conv1x1(conv, x, residual=None):
             y += residual
         return y
     hip_dx = hip_gemm
+    if (hip_gemm and x.dtype == torch.bfloat16 and conv.training and torch.is_grad_enabled() and config.switches().fused_train
+            and config.switches().fused_bn):
+        from .fused_bn import attach_stats
+        y, stats = _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual, hip_dx, True)
+        return attach_stats(y, stats) if stats.dim() == 3 else y
     return _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual, hip_dx)
 
 
