@@ -292,27 +292,32 @@ __global__ __launch_bounds__(kFin) void k_bn_finish_tiles(const float4* __restri
                                                             float* __restrict__ a_out, float* __restrict__ b_out,
                                                             float4* __restrict__ pack, float eps,
                                                             float momentum, long long* __restrict__ num_batches_tracked) {
-    __shared__ double red[2][kFin / kWave];
+    __shared__ double red[3][kFin / kWave];
     const int c = blockIdx.x;
     const float4* p = stats + (size_t)c * J;
     const double K = (double)p[0].x;
-    double s1 = 0, s2 = 0;
+    double s1 = 0, s2 = 0, sn = 0;
     for (int j = threadIdx.x; j < J; j += (int)blockDim.x) {
         const float4 t = p[j];
         const double n = (double)t.w;                            // columns of tile j: every producer writes it
         const double dp = (double)t.x - K;
         s1 += (double)t.y + n * dp;
         s2 += (double)t.z + 2.0 * dp * (double)t.y + n * dp * dp;
+        sn += n;
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
+    sn = wave_sum(sn);
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = sn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double S1 = 0, S2 = 0;
-        for (int w = 0; w < (int)blockDim.x / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
+        double S1 = 0, S2 = 0, SN = 0;
+        for (int w = 0; w < (int)blockDim.x / kWave; ++w) { S1 += red[0][w]; S2 += red[1][w]; SN += red[2][w]; }
         const double M = (double)count;
+        // the tiles must add up to `count` columns: a record a producer left unwritten (torch.empty garbage in .w) or a
+        // producer / consumer disagreement about the tile count yields NaN statistics -- loud -- instead of silently wrong ones
+        if (SN != M) S1 = __longlong_as_double(0x7ff8000000000000ll);
         const double ms = S1 / M;
         double var = S2 / M - ms * ms;
         var = var < 0 ? 0 : var;

@@ -87,7 +87,7 @@ __device__ __forceinline__ const char* uniform_bytes(const char* p) {
 // Waves 0-1 issue the X DMAs (counted vmcnt), waves 2-3 move the A chunks (ordinary loads, compiler-counted): vmcnt is
 // per wave and in order, so a wave doing both could not wait for its A chunk without draining the X prefetch.
 // STATS (training, round 5): the tile statistics of Y for the BatchNorm that consumes it -- stats[row][2 blockIdx.x + column
-// group] = (pivot, sum(y - pivot), sum((y - pivot)^2), columns) over the wave's 64 columns, of the values AS STORED (rounded
+// group] = (pivot = 0, sum y, sum y^2, columns) over the wave's 64 columns, of the values AS STORED (rounded
 // to bf16), the record rk_bn_finish_tiles_f32 finishes (rk_bn.hip) -- so that the consumer's statistics pass over Y
 // (k_bn_stats: 98 launches, 1.5 ms of a Large-AQ train step) never runs.
 template <int RB, bool RES, int DX, bool STATS = false>
@@ -305,21 +305,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
             w[i][1] = bf16_bits(acc[r][2][i]) | (bf16_bits(acc[r][3][i]) << 16);
         }
         if (STATS) {
+            // (pivot 0: bf16 data carries 8 bits, the fp32 sums of 64 columns 24, and the finisher combines the records in fp64)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float y0 = __uint_as_float(w[i][0] << 16), y1 = __uint_as_float(w[i][0] & 0xffff0000u);
                 const float y2 = __uint_as_float(w[i][1] << 16), y3 = __uint_as_float(w[i][1] & 0xffff0000u);
-                // pivot: the row's first column of this wave (lane n = 0 of the 16-lane row; 0 when that column does not exist)
-                const float piv = __shfl(counted ? y0 : 0.f, lane & 48);
-                const float e0 = y0 - piv, e1 = y1 - piv, e2 = y2 - piv, e3 = y3 - piv;
-                float s1 = counted ? (e0 + e1) + (e2 + e3) : 0.f;
-                float s2 = counted ? fmaf(e0, e0, e1 * e1) + fmaf(e2, e2, e3 * e3) : 0.f;
+                float s1 = counted ? (y0 + y1) + (y2 + y3) : 0.f;
+                float s2 = counted ? fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3) : 0.f;
                 s1 += dpp_or_zero<0x111, 0xf>(s1); s2 += dpp_or_zero<0x111, 0xf>(s2);
                 s1 += dpp_or_zero<0x112, 0xf>(s1); s2 += dpp_or_zero<0x112, 0xf>(s2);
                 s1 += dpp_or_zero<0x114, 0xf>(s1); s2 += dpp_or_zero<0x114, 0xf>(s2);
                 s1 += dpp_or_zero<0x118, 0xf>(s1); s2 += dpp_or_zero<0x118, 0xf>(s2);
                 const int row = rowb + 16 * r + i;
-                if (n == 15 && row < d.M) stats[(size_t)row * J + 2 * blockIdx.x + cgp] = make_float4(piv, s1, s2, ncols);
+                if (n == 15 && row < d.M) stats[(size_t)row * J + 2 * blockIdx.x + cgp] = make_float4(0.f, s1, s2, ncols);
             }
         }
         // even lane keeps rows 0, 1 and receives the partner's halves of them; odd lane keeps rows 2, 3

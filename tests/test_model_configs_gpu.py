@@ -160,8 +160,8 @@ class _Taps:
         btf, btb = BT.forward, BT.backward
         self.fa_bn, self.ba_bn = {}, {}
 
-        def btfwd(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter):
-            out = btf(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter)
+        def btfwd(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter, stats=None):
+            out = btf(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter, stats)
             taps.calls["fa"] += 1
             key = (tuple(x.shape), x.dtype)
             if key not in taps.fa_bn:
@@ -259,6 +259,30 @@ def test_large_train_step_shift_layers_match_oracle(oracle, monkeypatch):
         assert torch.isfinite(after[n]).all() and not torch.equal(after[n], before[n]), n
     shifts = [p for n, p in net.named_parameters() if n.endswith("shift")]
     assert len(shifts) == 51 and all(p.grad is not None and torch.isfinite(p.grad).all() for p in shifts)
+
+
+def test_tiny_train_step_at_the_bench_batch_matches_oracle(oracle, monkeypatch):
+    """The per-GPU batch of the bench (32 clips, what one rank of configs[3] / the metric's Tiny leg runs): RubiksNet-Tiny
+    forward + backward + Adam with every distinct RubiksShift3D call -- 9 shapes over 17 layers, at N = 32 the launches take
+    the paths the bench times (full workgroup rounds, the slab kernels' finalizers with 64 partials per channel) -- compared
+    with the oracle, forward AND backward (d(shift) sums over all 32 clips)."""
+    from rubiksnet_amd import RubiksNet, dp
+
+    torch.manual_seed(7)
+    B = 32
+    net = RubiksNet("tiny", 174, verbose=False).to(DEV)
+    opt = dp.make_optimizer(net, lr=1e-3, lr_shift_mult=0.1, kind="adam")
+    taps = _Taps(monkeypatch)
+    clips = torch.randn(B, 8, 3, 224, 224, device=DEV)
+    labels = torch.randint(0, 174, (B,), device=DEV)
+    loss = dp.train_step(net, opt, clips, labels)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert taps.calls["f3"] == 17 and taps.calls["b3"] == 17
+    want = {((B, 8, c, h, h), (1, s, s)) for c, h, s in _expected_shapes(54)}
+    assert set(taps.f3) == want and set(taps.b3) == want
+    _check_3d_forward(oracle, taps.f3, "tiny b32")
+    _check_3d_backward(oracle, taps.b3, "tiny b32")
 
 
 def test_tiny_forward_batch64_shift_layers_match_oracle(oracle, monkeypatch):
