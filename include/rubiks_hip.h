@@ -406,6 +406,11 @@ int rk_pw4_gemm_f32(const float* A, const float* X, const float* R, float* Y, in
 size_t rk_pw2_wgrad_workspace_bytes(int F, int K, int M, int P);
 int rk_pw2_wgrad_cfg_f32(const float* dY, const float* X, float* dW, int F, int K, int M, int P, void* ws, size_t ws_bytes,
                          const float* ka, const float* kb, int relu_in, int inst, int stages, int splits, rk_stream_t stream);
+/* Operand layout of the two training entry points: rk_pw_gemm_stats_f32 is the FORWARD of conv2 / conv3 and is instantiated
+ * for a_is_mk = 1 (A = the weight [M][K]); rk_pw_gemm_bnbwd_f32 is conv2's D(INPUT) and is instantiated for a_is_mk = 0 (A =
+ * the weight read as [K][M]).  Those are the layouts rubiksnet_amd/train_block.py uses; the other two combinations have
+ * instances only in the first-generation kernel and return RK_ERR_UNSUPPORTED for shapes the later generations take
+ * (M <= 224 rows, or the 257..288-row layers): not a layout the training block can produce. */
 int rk_pw_gemm_stats_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, void* stats, int tiles,
                          rk_stream_t stream);

@@ -8,6 +8,9 @@
                                   temporal filter (fused_bn.bn_relu_tshift_skip) / layer by layer
     RK_WGRAD_OVERLAP 1 | 0        the d(weight) kernels of a fused training block on a second HIP stream, next to the
                                   streaming kernels of the same backward / on the current stream
+    RK_PW16_STATS  0 | 1          bf16 training: separate statistics pass / conv2's GEMM epilogue leaves the tile statistics
+                                  of its output for bn2 (rk_pw_gemm_packed_stats_bf16).  Off by default: measured on the
+                                  Large-AQ step the epilogue costs what the pass it replaces cost (33.1 vs 32.8 ms), DESIGN 3.5b
 
 Everything else that used to be tunable from the environment (tile shapes, channel limits, prefetch depths)
 is a constant next to the code it tunes.  The native library has one switch of its own, RK_SHIFT_KERNELS
@@ -27,6 +30,7 @@ class Switches:
     fused_eval: bool = True
     fused_train: bool = True
     wgrad_overlap: bool = True
+    pw16_stats: bool = False
 
     @staticmethod
     def from_env(env=None):
@@ -37,7 +41,8 @@ class Switches:
         return Switches(fused_bn=env.get("RK_FUSED_BN", "1") != "0", pointwise=pw,
                         fused_eval=env.get("RK_FUSED_EVAL", "1") != "0",
                         fused_train=env.get("RK_FUSED_TRAIN", "1") != "0",
-                        wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0")
+                        wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0",
+                        pw16_stats=env.get("RK_PW16_STATS", "0") == "1")
 
 
 _current = Switches.from_env()

@@ -178,13 +178,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     const long long ug = (long long)blockIdx.x * 16 + 8 * cgp + (n >> 1);
     const bool out_ok = ug < d.nunits;
     size_t at0 = 0;                                  // element offset of this lane's UNIT in row 0 of its frame's output
-    bool repeated = false;                           // this lane's 4 pixels are the repeated half of a frame's last unit
     {
         const long long q = out_ok ? ug : 0;
         const int f = (int)(q / d.U), j = (int)(q - (long long)f * d.U);
         const int p = (odd_tail && j == d.U - 1) ? d.P - 8 : 8 * j;  // (a frame's last unit: its repeated half is stored again,
         at0 = ((size_t)f * d.M) * d.P + p;                           //  with the identical values)
-        repeated = odd_tail && j == d.U - 1 && (n & 1) == 0;
     }
     const int half = n & 1;                          // this lane's 4 pixels within the unit
     const int rowb = 16 * (rb0 + rh * RB) + 4 * g;
@@ -288,9 +286,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     // swap two rows each (DPP) so that every lane stores 2 rows x 16 bytes instead of 4 rows x 8: the epilogue is
     // store-ISSUE bound (MI355X_MICROARCH.md, "attention epilogue store tail").
     const unsigned hm = 0u - (unsigned)half;          // all ones in the odd lane of a pair
-    const bool counted = out_ok && !repeated;        // STATS: this lane's 4 columns exist (once) in Y
+    // STATS: this lane's 4 columns exist (once) in Y -- not past the tensor, not the repeated half of a frame's last unit.
+    // (recomputed here rather than kept from the prologue: carried across the K loop the flags cost 50 spilled SGPRs, the VGPRs
+    // that held them 24 spilled VGPRs, on a kernel that sits at its 256-register cap)
+    bool counted = false;
     float ncols = 0.f;
     if (STATS) {
+        const long long q = out_ok ? ug : 0;
+        const int j = (int)(q % d.U);
+        counted = out_ok && !(odd_tail && j == d.U - 1 && (n & 1) == 0);
         ncols = counted ? 4.f : 0.f;
         ncols += dpp_or_zero<0x111, 0xf>(ncols); ncols += dpp_or_zero<0x112, 0xf>(ncols);
         ncols += dpp_or_zero<0x114, 0xf>(ncols); ncols += dpp_or_zero<0x118, 0xf>(ncols);     // lane n = 15: the wave's columns
@@ -316,7 +320,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
                 s1 += dpp_or_zero<0x112, 0xf>(s1); s2 += dpp_or_zero<0x112, 0xf>(s2);
                 s1 += dpp_or_zero<0x114, 0xf>(s1); s2 += dpp_or_zero<0x114, 0xf>(s2);
                 s1 += dpp_or_zero<0x118, 0xf>(s1); s2 += dpp_or_zero<0x118, 0xf>(s2);
-                const int row = rowb + 16 * r + i;
+                int row = rowb + 16 * r + i;
+                asm volatile("" : "+v"(row));          // (or hipcc precomputes the 36 row masks ahead of the K loop: 50 spilled SGPRs)
                 if (n == 15 && row < d.M) stats[(size_t)row * J + 2 * blockIdx.x + cgp] = make_float4(0.f, s1, s2, ncols);
             }
         }

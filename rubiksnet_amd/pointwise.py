@@ -126,7 +126,10 @@ class _Conv1x1Func(torch.autograd.Function):
             fwd = None
             if _packed_ok(weight, x, Cin, Cout, H * W, True):
                 fwd, ctx.packed_bwd = _pack(weight)
-            if want_stats and fwd is not None:
+            if want_stats and fwd is not None and residual is None:
+                # (conv2 -> bn2 only: with the residual's 72 registers on top of 144 accumulators the statistics variant of
+                # the 288-row kernel spills, and the 144-row one drops from 3 to 2 waves per SIMD: measured slower than the
+                # statistics pass it saves)
                 # training: the GEMM also leaves the tile statistics of y for the BatchNorm that consumes it (fused_bn.py)
                 L = _native.lib()
                 J = int(L.rk_pw16_stat_tiles(Fr, H * W))
@@ -423,7 +426,7 @@ def conv1x1(conv, x, residual=None):
         return y
     hip_dx = hip_gemm
     if (hip_gemm and x.dtype == torch.bfloat16 and conv.training and torch.is_grad_enabled() and config.switches().fused_train
-            and config.switches().fused_bn):
+            and config.switches().fused_bn and config.switches().pw16_stats):
         from .fused_bn import attach_stats
         y, stats = _Conv1x1Func.apply(x.contiguous(), conv.weight, hip_gemm, residual, hip_dx, True)
         return attach_stats(y, stats) if stats.dim() == 3 else y
