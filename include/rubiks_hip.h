@@ -174,6 +174,30 @@ size_t rk2d_backward_workspace_bytes(int N, int C, int H, int W,
                                      int stride_H, int stride_W, int pad_H, int pad_W,
                                      int elem_size);
 
+/* Training fusion for the 2-D operator (round 5; the -aq blocks of rubiksnet/backbone.py:129-131 with models.py:71-79's
+ * RubiksShift2D): the shift applied to relu(bn2(z)) = max(a z + b, 0) without the activation being stored.
+ *   forward : y = shift2d(round(max(a z + b, 0))); ab [2][C] = the affine map of bn2's training forward
+ *             (rk_bn_stats_finish_* / rk_bn_finish_tiles_f32).
+ *   backward: dz = d(bn2's output) = d(x) of the shift masked by the ReLU; gshift [2][C] (K9 applied when normalize_grad);
+ *             bn2's backward constants k12 [2][C] = (sum dz, sum dz zhat) / count, d(gamma), d(beta): what
+ *             rk_bn_bwd_dx_pre_* needs to finish bn2's d(x) in one pass.  abmi [C][4] = (a, b, mean, invstd).
+ * Shift table and d(shift) in fp32 (as rk2d_*_sf32).  RK_ERR_UNSUPPORTED (nothing launched) when no fused kernel takes the
+ * configuration -- today 14 x 14 planes, stride 1, pad 0, quantize off; the caller then normalises with
+ * rk_bn_apply_affine_* and calls the plain entry points. */
+size_t rk2d_backward_bn_workspace_bytes(int N, int C, int H, int W, int stride_H, int stride_W, int pad_H, int pad_W);
+int rk2d_forward_bn_f32(const float* z, const float* ab, const float* shift, float* y, int N, int C, int H, int W,
+                        int stride_H, int stride_W, int pad_H, int pad_W, int quantize, rk_stream_t stream);
+int rk2d_forward_bn_bf16_sf32(const void* z, const float* ab, const float* shift, void* y, int N, int C, int H, int W,
+                              int stride_H, int stride_W, int pad_H, int pad_W, int quantize, rk_stream_t stream);
+int rk2d_backward_bn_f32(const float* gy, const float* z, const float* abmi, const float* shift, float* dz, float* gshift,
+                         float* k12, float* dgamma, float* dbeta, int N, int C, int H, int W, int stride_H, int stride_W,
+                         int pad_H, int pad_W, int normalize_grad, int quantize, void* workspace, size_t workspace_bytes,
+                         rk_stream_t stream);
+int rk2d_backward_bn_bf16_sf32(const void* gy, const void* z, const float* abmi, const float* shift, void* dz, float* gshift,
+                               float* k12, float* dgamma, float* dbeta, int N, int C, int H, int W, int stride_H,
+                               int stride_W, int pad_H, int pad_W, int normalize_grad, int quantize, void* workspace,
+                               size_t workspace_bytes, rk_stream_t stream);
+
 /* ------------------------------------------------------------ temporal 3-tap
  * The device half of AttentionShift (rubiksnet/attention_shift.py:32-39): the
  * per-channel 3-tap temporal filter the reference runs as transpose -> grouped

@@ -35,6 +35,11 @@ SIGNATURES = {
     "rk3d_backward_partials_f32": (_i, [_p] * 4 + _DIMS3 + [_i, _p, _sz, ctypes.POINTER(ctypes.c_int), _p]),
     "rk3d_backward_finalize_f32": (_i, [_p, _i, _i, _p, _i, ctypes.c_float, _p]),
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
+    "rk2d_backward_bn_workspace_bytes": (_sz, _DIMS2),
+    "rk2d_forward_bn_f32": (_i, [_p] * 4 + _DIMS2 + [_i, _p]),
+    "rk2d_forward_bn_bf16_sf32": (_i, [_p] * 4 + _DIMS2 + [_i, _p]),
+    "rk2d_backward_bn_f32": (_i, [_p] * 9 + _DIMS2 + [_i, _i, _p, _sz, _p]),
+    "rk2d_backward_bn_bf16_sf32": (_i, [_p] * 9 + _DIMS2 + [_i, _i, _p, _sz, _p]),
     "rk_tshift3_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_tshift3_bn_forward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rk_tshift3_bn_forward_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),

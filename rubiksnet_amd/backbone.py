@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _native, config
-from .fused_bn import bn_relu, bn_relu_skip, bn_relu_tshift_skip
+from .fused_bn import bn_relu, bn_relu_shift2d, bn_relu_skip, bn_relu_tshift_skip
 from .pointwise import all_frozen, conv1x1, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 from .train_block import bn_relu_from_stats, fused_train_block
@@ -162,8 +162,10 @@ class RubiksShiftBlock(nn.Module):
                 r = bn_relu_tshift_skip(self.bn1, self.conv2[0], x)
                 if r is not None:
                     out, shortcut = r
-                    out = bn_relu(self.bn2, conv1x1(self.conv2[1], out))
-                    out = self.as3(out)
+                    z2 = conv1x1(self.conv2[1], out)
+                    out = bn_relu_shift2d(self.bn2, self.as3, z2)     # bn2 + ReLU inside the 2-D shift kernels (14 x 14 planes)
+                    if out is None:
+                        out = self.as3(bn_relu(self.bn2, z2))
                     if self.se:
                         out = self.se(out)
                     return conv1x1(self.conv3, out, residual=shortcut)
@@ -172,8 +174,10 @@ class RubiksShiftBlock(nn.Module):
         else:
             out = bn_relu(self.bn1, x)
             shortcut = conv1x1(self.shortcut, out)
-        out = bn_relu(self.bn2, conv1x1(self.conv2, out))
-        out = self.as3(out)
+        z2 = conv1x1(self.conv2, out)
+        out = bn_relu_shift2d(self.bn2, self.as3, z2) if self.training else None
+        if out is None:
+            out = self.as3(bn_relu(self.bn2, z2))
         if self.se:
             out = self.se(out)
         return conv1x1(self.conv3, out, residual=shortcut)      # conv3(out) + shortcut, the add in the GEMM's epilogue

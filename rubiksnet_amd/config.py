@@ -8,6 +8,8 @@
                                   temporal filter (fused_bn.bn_relu_tshift_skip) / layer by layer
     RK_WGRAD_OVERLAP 1 | 0        the d(weight) kernels of a fused training block on a second HIP stream, next to the
                                   streaming kernels of the same backward / on the current stream
+    RK_BN_SHIFT2D  1 | 0          -aq training blocks: bn2 + ReLU inside the 2-D shift kernels (fused_bn.bn_relu_shift2d; 14 x 14
+                                  planes) / bn2 + ReLU as their own passes
     RK_PW16_STATS  0 | 1          bf16 training: separate statistics pass / conv2's GEMM epilogue leaves the tile statistics
                                   of its output for bn2 (rk_pw_gemm_packed_stats_bf16).  Off by default: measured on the
                                   Large-AQ step the epilogue costs what the pass it replaces cost (33.1 vs 32.8 ms), DESIGN 3.5b
@@ -31,6 +33,7 @@ class Switches:
     fused_train: bool = True
     wgrad_overlap: bool = True
     pw16_stats: bool = False
+    bn_shift2d: bool = True
 
     @staticmethod
     def from_env(env=None):
@@ -42,7 +45,8 @@ class Switches:
                         fused_eval=env.get("RK_FUSED_EVAL", "1") != "0",
                         fused_train=env.get("RK_FUSED_TRAIN", "1") != "0",
                         wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0",
-                        pw16_stats=env.get("RK_PW16_STATS", "0") == "1")
+                        pw16_stats=env.get("RK_PW16_STATS", "0") == "1",
+                        bn_shift2d=env.get("RK_BN_SHIFT2D", "1") != "0")
 
 
 _current = Switches.from_env()

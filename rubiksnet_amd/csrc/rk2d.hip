@@ -156,6 +156,39 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
     return launch_status();
 }
 
+// ---- training fusion (round 5): the shift applied to relu(bn2(z)) without the activation ever being stored
+// (fused_bn.bn_relu_shift2d; backbone.py:129-131 under models.py:71-79's 2-D variant).  RK_ERR_UNSUPPORTED (nothing launched) when
+// no fused kernel covers the configuration (today: 14 x 14 planes, stride 1, pad 0, no quantize); the caller then normalises
+// with rk_bn_apply_affine_* and calls the plain entry points.
+template <typename T>
+static int forward2_bn(const void* z, const float* ab, const float* shift, void* y, int N, int C, int H, int W, int sH, int sW,
+                       int pH, int pW, int quantize, rk_stream_t stream) {
+    if (!z || !ab || !shift || !y) return RK_ERR_NULL_POINTER;
+    Dims2 d;
+    if (int rc = make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return rc;
+    if (quantize) return RK_ERR_UNSUPPORTED;
+    if (tile2d::launch_forward2_bn<T, float>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream)) return launch_status();
+    return RK_ERR_UNSUPPORTED;
+}
+template <typename T>
+static int backward2_bn(const void* gy, const void* z, const float* abmi, const float* shift, void* dz, float* gshift, float* k12,
+                        float* dgamma, float* dbeta, int N, int C, int H, int W, int sH, int sW, int pH, int pW,
+                        int normalize_grad, int quantize, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!gy || !z || !abmi || !shift || !dz || !gshift || !k12 || !dgamma || !dbeta) return RK_ERR_NULL_POINTER;
+    Dims2 d;
+    if (int rc = make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return rc;
+    if (quantize) return RK_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < 2 * workspace2(d, 4)) return RK_ERR_WORKSPACE;
+    tile2d::BnFuse2 bn;
+    bn.abmi = reinterpret_cast<const float4*>(abmi);
+    bn.k12 = k12; bn.dgamma = dgamma; bn.dbeta = dbeta;
+    bn.inv_count = (float)(1.0 / ((double)N * H * W));
+    if (tile2d::launch_backward2_bn<T, float>((const T*)gy, (const T*)z, shift, (T*)dz, gshift, ws, normalize_grad, bn, d,
+                                              (hipStream_t)stream))
+        return launch_status();
+    return RK_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" {
@@ -201,5 +234,31 @@ RK_DEF_2D(bf16, __hip_bfloat16, void)
 RK_DEF_2D_MIXED(f16, __half)
 RK_DEF_2D_MIXED(bf16, __hip_bfloat16)
 #undef RK_DEF_2D_MIXED
+
+size_t rk2d_backward_bn_workspace_bytes(int N, int C, int H, int W, int sH, int sW, int pH, int pW) {
+    Dims2 d;
+    if (make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return 0;
+    return 2 * workspace2(d, 4);                                   // four partials per (channel, group) instead of two
+}
+int rk2d_forward_bn_f32(const float* z, const float* ab, const float* shift, float* y, int N, int C, int H, int W, int sH,
+                        int sW, int pH, int pW, int quantize, rk_stream_t stream) {
+    return forward2_bn<float>(z, ab, shift, y, N, C, H, W, sH, sW, pH, pW, quantize, stream);
+}
+int rk2d_forward_bn_bf16_sf32(const void* z, const float* ab, const float* shift, void* y, int N, int C, int H, int W, int sH,
+                              int sW, int pH, int pW, int quantize, rk_stream_t stream) {
+    return forward2_bn<__hip_bfloat16>(z, ab, shift, y, N, C, H, W, sH, sW, pH, pW, quantize, stream);
+}
+int rk2d_backward_bn_f32(const float* gy, const float* z, const float* abmi, const float* shift, float* dz, float* gshift,
+                         float* k12, float* dgamma, float* dbeta, int N, int C, int H, int W, int sH, int sW, int pH, int pW,
+                         int normalize_grad, int quantize, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return backward2_bn<float>(gy, z, abmi, shift, dz, gshift, k12, dgamma, dbeta, N, C, H, W, sH, sW, pH, pW, normalize_grad,
+                               quantize, ws, ws_bytes, stream);
+}
+int rk2d_backward_bn_bf16_sf32(const void* gy, const void* z, const float* abmi, const float* shift, void* dz, float* gshift,
+                               float* k12, float* dgamma, float* dbeta, int N, int C, int H, int W, int sH, int sW, int pH,
+                               int pW, int normalize_grad, int quantize, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    return backward2_bn<__hip_bfloat16>(gy, z, abmi, shift, dz, gshift, k12, dgamma, dbeta, N, C, H, W, sH, sW, pH, pW,
+                                        normalize_grad, quantize, ws, ws_bytes, stream);
+}
 
 }  // extern "C"

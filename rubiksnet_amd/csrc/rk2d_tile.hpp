@@ -88,6 +88,47 @@ template <typename G> __device__ __forceinline__ int dma_tile(const void* tile, 
     return G::PIECE_ROUNDS;
 }
 
+// Training fusion (round 5, fused_bn.bn_relu_shift2d): the tile holds z = conv2's output and the shift applies to
+// relu(bn2(z)) = max(a z + b, 0) rounded to the storage type -- the tensor the unfused path would have stored.  The wave
+// transforms the tile it DMA'd in place once it has landed (its own counted wait; LDS operations of one wave execute in
+// order, so the tap reads that follow see the transformed values); the slot's zero cell is not touched.
+template <typename G, typename T>
+__device__ __forceinline__ void bn_tile(char* slot, int lane, const float (&a)[G::GC], const float (&b)[G::GC]) {
+#pragma unroll
+    for (int i = 0; i < G::PIECE_ROUNDS; ++i) {
+        const int p = lane + kWave * i;
+        if (p >= G::PIECES) continue;
+        if constexpr (sizeof(T) == 4) {
+            float4* q = reinterpret_cast<float4*>(slot + 16 * p);
+            float4 v = *q;
+            v.x = fmaxf(fmaf(a[0], v.x, b[0]), 0.f); v.y = fmaxf(fmaf(a[0], v.y, b[0]), 0.f);
+            v.z = fmaxf(fmaf(a[0], v.z, b[0]), 0.f); v.w = fmaxf(fmaf(a[0], v.w, b[0]), 0.f);
+            *q = v;
+        } else {
+            using C4 = stage2d::Cell4<T>;
+            uint4* q = reinterpret_cast<uint4*>(slot + 16 * p);
+            const uint4 w = *q;
+            const unsigned in[4] = {w.x, w.y, w.z, w.w};
+            unsigned out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool g0 = 8 * p + 2 * j >= G::HW, g1 = 8 * p + 2 * j + 1 >= G::HW;      // second channel of the tile
+                const float a0 = (G::GC == 2 && g0) ? a[G::GC - 1] : a[0], b0 = (G::GC == 2 && g0) ? b[G::GC - 1] : b[0];
+                const float a1 = (G::GC == 2 && g1) ? a[G::GC - 1] : a[0], b1 = (G::GC == 2 && g1) ? b[G::GC - 1] : b[0];
+                const float v0 = fmaxf(fmaf(a0, raw16::Wide<T>::get(in[j], 0), b0), 0.f);
+                const float v1 = fmaxf(fmaf(a1, raw16::Wide<T>::get(in[j], 1), b1), 0.f);
+                out[j] = C4::bits(v0) | (C4::bits(v1) << 16);
+            }
+            *q = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+    }
+}
+// a value as the storage type holds it
+template <typename T> __device__ __forceinline__ float round_to(float v) {
+    if constexpr (sizeof(T) == 4) return v;
+    else return raw16::Wide<T>::get(stage2d::Cell4<T>::bits(v), 0);
+}
+
 // one channel of the tile in one walk: fractions, what it does in this walk
 struct ChanW { Frac<float> fH, fW; bool on, store; };
 
@@ -127,9 +168,9 @@ template <typename G> __device__ __forceinline__ Item my_item(const TDims2& d, i
 
 // ---------------------------------------------------------------------------------------------
 // Forward (NEGATE = false: src = x) and d(x) alone (NEGATE = true: src = gy, negated shift).
-template <typename T, typename S, int H, int W, int R, bool NEGATE>
+template <typename T, typename S, int H, int W, int R, bool NEGATE, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ src, const S* __restrict__ shift,
-                                                          T* __restrict__ dst, TDims2 d) {
+                                                          T* __restrict__ dst, TDims2 d, const float* __restrict__ ab = nullptr) {
     using G = Geo<T, H, W>;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (kWave - 1);
@@ -154,6 +195,9 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
         for (int rc = 0; rc < G::RC; ++rc) make_round<G>(rel[g * G::RC + rc], own, ooff[g * G::RC + rc], ch, g, lane, rc);
     }
     (void)own;
+    float bn_a[G::GC], bn_b[G::GC];
+#pragma unroll
+    for (int g = 0; g < G::GC; ++g) { bn_a[g] = BN ? ab[it.c0 + g] : 1.f; bn_b[g] = BN ? ab[d.C + it.c0 + g] : 0.f; }
     const size_t fstride = (size_t)d.C * G::HW;                       // elements between frames
     const T* col = src + ((size_t)it.f0 * d.C + it.c0) * G::HW;
     char* ocol = reinterpret_cast<char*>(dst + ((size_t)it.f0 * d.C + it.c0) * G::HW);
@@ -172,6 +216,7 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             wait_vmcnt((R - 1 - k) * G::PIECE_ROUNDS + k * G::ROUNDS);
+            if (BN) bn_tile<G, T>(ring + k * G::STRIDE, lane, bn_a, bn_b);
             char* out = ocol + (size_t)k * fstride * G::ES;
             float o0[G::ROUNDS], o1[G::ROUNDS];
 #pragma unroll
@@ -208,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
         for (int i = 0; i + 1 < R - 1; ++i) fifo[i] = fifo[i + 1];
         fifo[R - 2] = issued;
         const unsigned sb = ring_addr + (k % R) * G::STRIDE;
+        if (BN) bn_tile<G, T>(ring + (k % R) * G::STRIDE, lane, bn_a, bn_b);
         char* out = ocol + (size_t)k * fstride * G::ES;
         float o0[G::ROUNDS], o1[G::ROUNDS];
 #pragma unroll
@@ -232,13 +278,47 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // Backward: d(x) + d(shift); partials [C][2][P = ngroups] as granules, row-sum + K9 by the finalizer blocks.
-template <typename T, typename S, int H, int W, int R>
+// BN (training fusion): x holds z = bn2's input.  The activation relu(a z + b) (rounded to the storage type: what the forward
+// shifted) is recomputed where the d(shift) sums use it -- a lane needs x only at its OWN pair --, d(x) leaves masked by the
+// ReLU (= d(bn2's output), what k_bn_bwd_dx_pre expects), and bn2's two reduction sums (sum dz, sum dz zhat) ride along as
+// partials 2 and 3: [C][4][P]; the finalizer also writes k12 / d(gamma) / d(beta).
+struct BnFuse2 {
+    const float4* abmi;           // [C] (a, b, mean, invstd)
+    float* k12;                   // [2][C]
+    float* dgamma; float* dbeta;  // [C]
+    float inv_count;              // 1 / (F H W)
+};
+template <typename S>
+__device__ __forceinline__ void finalizer_wave2_bn(const Fin2<S>& fin, int c, int C, int P, const BnFuse2& bn) {
+    double s[4];
+    const bool ok = fin_collect<4>(fin.f, c, P, s);
+    if (threadIdx.x == 0) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+        float gH = (float)s[0], gW = (float)s[1];
+        if (fin.normalize) {
+            const float mag = sqrtf(gH * gH + gW * gW);
+            if (mag > 0) { gH = gH / mag; gW = gW / mag; }
+        }
+        if (!ok) gH = gW = nanv;
+        st(fin.gshift + c, gH);
+        st(fin.gshift + C + c, gW);
+        bn.dbeta[c] = ok ? (float)s[2] : nanv;
+        bn.dgamma[c] = ok ? (float)s[3] : nanv;
+        bn.k12[c] = ok ? (float)(s[2] * (double)bn.inv_count) : nanv;
+        bn.k12[C + c] = ok ? (float)(s[3] * (double)bn.inv_count) : nanv;
+    }
+}
+template <typename T, typename S, int H, int W, int R, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                             const S* __restrict__ shift, T* __restrict__ gx, TDims2 d,
-                                                            Fin2<S> fin) {
+                                                            Fin2<S> fin, BnFuse2 bn = BnFuse2{}) {
     using G = Geo<T, H, W>;
+    constexpr int ND = BN ? 4 : 2;
     if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
-        if (threadIdx.x < kWave) dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, d.ngroups);
+        if (threadIdx.x < kWave) {
+            if (BN) finalizer_wave2_bn(fin, (int)blockIdx.x - fin.f.producers, d.C, d.ngroups, bn);
+            else dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, d.ngroups);
+        }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -263,9 +343,13 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict_
         plan[g] = dma2d::plan_walks(ld(shift + it.c0 + g), ld(shift + d.C + it.c0 + g));
         extra = extra || plan[g].separate_gx || plan[g].hint || plan[g].wint;
     }
-    float sumH0[G::GC], sumW0[G::GC], sumH1[G::GC], sumW2[G::GC];
+    float sumH0[G::GC], sumW0[G::GC], sumH1[G::GC], sumW2[G::GC], sumB1[G::GC], sumB2[G::GC];
+    float4 bnp[G::GC];
 #pragma unroll
-    for (int g = 0; g < G::GC; ++g) sumH0[g] = sumW0[g] = sumH1[g] = sumW2[g] = 0.f;
+    for (int g = 0; g < G::GC; ++g) {
+        sumH0[g] = sumW0[g] = sumH1[g] = sumW2[g] = sumB1[g] = sumB2[g] = 0.f;
+        bnp[g] = BN ? bn.abmi[it.c0 + g] : make_float4(1.f, 0.f, 0.f, 1.f);
+    }
 
     // walk -1: d(x) alone with the true remainder (channels whose |r| < 1e-7 but != 0: K8 has no tolerance);
     // walk 0: sums (+ d(x) for every ordinary channel); walk 1 / 2: sums with the H / W floor lowered by one.
@@ -294,9 +378,9 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict_
                 make_round<G>(rel[g * G::RC + rc], own[g * G::RC + rc], ooff[g * G::RC + rc], ch, g, lane, rc);
         }
         if (!any) continue;                                          // wave-uniform
-        float aH[G::GC], aW[G::GC];
+        float aH[G::GC], aW[G::GC], bB1[G::GC], bB2[G::GC];
 #pragma unroll
-        for (int g = 0; g < G::GC; ++g) aH[g] = aW[g] = 0.f;
+        for (int g = 0; g < G::GC; ++g) aH[g] = aW[g] = bB1[g] = bB2[g] = 0.f;
 
         int issued = 0;
         auto fetch = [&](int k) {                                    // frame k: gy -> gy slot, x -> x slot k % R
@@ -330,6 +414,19 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict_
                     lds_pair<T>(own[r] + xb, x0, x1);
                     o0[r] = a0 * uH[g] * uW[g] + a1 * uH[g] * rW[g] + b0 * rH[g] * uW[g] + b1 * rH[g] * rW[g];   // K8
                     o1[r] = a1 * uH[g] * uW[g] + a2 * uH[g] * rW[g] + b1 * rH[g] * uW[g] + b2 * rH[g] * rW[g];
+                    if (BN) {
+                        const bool lv = own[r] != G::ZOFF;            // (a lane without a pair reads the zero cell: relu(b) is not 0)
+                        const float z0 = x0, z1 = x1;
+                        x0 = lv ? round_to<T>(fmaxf(fmaf(bnp[g].x, z0, bnp[g].y), 0.f)) : 0.f;
+                        x1 = lv ? round_to<T>(fmaxf(fmaf(bnp[g].x, z1, bnp[g].y), 0.f)) : 0.f;
+                        o0[r] = x0 > 0.f ? round_to<T>(o0[r]) : 0.f;  // d(bn2's output): the value as it is stored, ReLU-masked
+                        o1[r] = x1 > 0.f ? round_to<T>(o1[r]) : 0.f;
+                        if (st_on[g]) {                              // (wave-uniform) the walk that stores this channel's d(x)
+                            bB1[g] += o0[r] + o1[r];
+                            bB2[g] = fmaf(o0[r], (z0 - bnp[g].z) * bnp[g].w, bB2[g]);
+                            bB2[g] = fmaf(o1[r], (z1 - bnp[g].z) * bnp[g].w, bB2[g]);
+                        }
+                    }
                     const float c0 = fmaf(uH[g], a0, rH[g] * b0), c1 = fmaf(uH[g], a1, rH[g] * b1),
                                 c2 = fmaf(uH[g], a2, rH[g] * b2);
                     const float la0 = fmaf(a0, uW[g], a1 * rW[g]), lb0 = fmaf(b0, uW[g], b1 * rW[g]);
@@ -355,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict_
             if (walk == 0) { sumH0[g] = aH[g]; sumW0[g] = aW[g]; }
             else if (walk == 1) sumH1[g] = aH[g];
             else if (walk == 2) sumW2[g] = aW[g];
+            if (BN && st_on[g]) { sumB1[g] = bB1[g]; sumB2[g] = bB2[g]; }      // (exactly one walk stores a channel)
         }
     }
 
@@ -364,11 +462,14 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict_
         float accW = plan[g].wint ? 0.5f * (sumW0[g] + sumW2[g]) : sumW0[g];
         accH = wave_sum(accH);
         accW = wave_sum(accW);
+        float accB1 = 0.f, accB2 = 0.f;
+        if (BN) { accB1 = wave_sum(sumB1[g]); accB2 = wave_sum(sumB2[g]); }
         if (lane == 0) {
             const int P = d.ngroups;
-            const size_t at = (size_t)(it.c0 + g) * 2 * P + (size_t)(it.f0 / d.FG);
+            const size_t at = (size_t)(it.c0 + g) * ND * P + (size_t)(it.f0 / d.FG);
             fin_publish(fin.f, at, accH);
             fin_publish(fin.f, at + P, accW);
+            if (BN) { fin_publish(fin.f, at + 2 * (size_t)P, accB1); fin_publish(fin.f, at + 3 * (size_t)P, accB2); }
         }
     }
 }
@@ -422,6 +523,39 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
     fin.normalize = normalize;
     hipLaunchKernelGGL((k2d_tile_backward<T, S, 14, 14, R>), dim3((unsigned)(fin.f.producers + t.C)), dim3(kBlock), lds, stream, gy,
                        x, shift, gx, t, fin);
+    return true;
+}
+
+// training fusion: forward of relu(bn2(z)) (ab [2][C]) and its backward; false = shape not handled here
+template <typename T, typename S>
+inline bool launch_forward2_bn(const T* z, const float* ab, const S* shift, T* y, const Dims2& d, hipStream_t stream) {
+    constexpr int R = 4;
+    using G = Geo<T, 14, 14>;
+    TDims2 t;
+    if (!make_tdims<T, 14, 14>(t, d) || !aligned16(z) || !aligned16(y)) return false;
+    const long long waves = (long long)t.NG * t.ngroups;
+    const size_t lds = (size_t)4 * R * G::STRIDE;
+    hipLaunchKernelGGL((k2d_tile_interp<T, S, 14, 14, R, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), lds, stream,
+                       z, shift, y, t, ab);
+    return true;
+}
+template <typename T, typename S>
+inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, S* gshift, void* ws, int normalize,
+                                const BnFuse2& bn, const Dims2& d, hipStream_t stream) {
+    constexpr int R = 3;
+    using G = Geo<T, 14, 14>;
+    TDims2 t;
+    if (!make_tdims<T, 14, 14>(t, d) || !aligned16(gy) || !aligned16(z) || !aligned16(dz) || !aligned16(bn.abmi)) return false;
+    const long long waves = (long long)t.NG * t.ngroups;
+    const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
+    Fin2<S> fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = (int)((waves + 3) / 4);
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    hipLaunchKernelGGL((k2d_tile_backward<T, S, 14, 14, R, true>), dim3((unsigned)(fin.f.producers + t.C)), dim3(kBlock), lds, stream,
+                       gy, z, shift, dz, t, fin, bn);
     return true;
 }
 

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import _native, config
 
-__all__ = ["bn_relu", "bn_relu_skip", "bn_relu_tshift_skip", "fused_bn_enabled"]
+__all__ = ["bn_relu", "bn_relu_skip", "bn_relu_tshift_skip", "bn_relu_shift2d", "fused_bn_enabled"]
 
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
 
@@ -232,6 +232,96 @@ def bn_relu_tshift_skip(bn, shift, x):
     rv = bn.running_var if bn.track_running_stats else None
     return _BNReLUTShiftTrain.apply(x, bn.weight, bn.bias, shift.soft_taps(), rm, rv, momentum, bn.eps, S, _ptr(counter),
                                     take_stats(x))
+
+
+class _BNReLUShift2DTrain(torch.autograd.Function):
+    """shift2d(relu(batch_norm(z))): the -aq block's training-mode bn2 + ReLU folded into the RubiksShift2D that consumes
+    it (rk2d_*_bn_*): the activation is never stored.  Forward = statistics pass + ONE shift pass (instead of statistics,
+    normalise, shift: 5 -> 3 tensor passes); backward = the shift's backward, which recomputes the activation where d(shift)
+    needs it and emits the ReLU-masked gradient together with BatchNorm's two reduction sums, + the d(x) pass (8 -> 6)."""
+
+    _SHIFT_SFX = {torch.float32: "f32", torch.bfloat16: "bf16_sf32"}
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, shift, running_mean, running_var, momentum, eps, counter_ptr, normalize_grad, stats=None):
+        L = _native.lib()
+        Fr, C, H, W = z.shape
+        P = H * W
+        dev = z.device
+        sfx = _SFX[z.dtype]
+        y = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if stats is not None:
+                fin = _finish_tiles(L, stats, Fr * P, weight, bias, running_mean, running_var, momentum, eps, counter_ptr, dev,
+                                    stream)
+                save_mean, save_invstd, ab = fin[0], fin[1], fin[2:4]
+            else:
+                save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+                save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+                ws, nbytes = _ws(L, Fr, C, P, dev)
+                _native.check(getattr(L, "rk_bn_stats_finish_" + sfx)(
+                    z.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var), save_mean.data_ptr(),
+                    save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(),
+                    nbytes, stream), "rk_bn_stats_finish")
+            rc = getattr(L, "rk2d_forward_bn_" + _BNReLUShift2DTrain._SHIFT_SFX[z.dtype])(
+                z.data_ptr(), ab.data_ptr(), shift.data_ptr(), y.data_ptr(), Fr, C, H, W, 1, 1, 0, 0, 0, stream)
+        _native.check(rc, "rk2d_forward_bn")
+        ctx.save_for_backward(z, weight, bias, shift, save_mean, save_invstd, ab)
+        ctx.normalize_grad = bool(normalize_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, weight, bias, shift, save_mean, save_invstd, ab = ctx.saved_tensors
+        L = _native.lib()
+        Fr, C, H, W = z.shape
+        P = H * W
+        dev = z.device
+        sfx = _SFX[z.dtype]
+        gy = gy.contiguous()
+        if gy.dtype != z.dtype:
+            gy = gy.to(z.dtype)
+        dz = torch.empty_like(z)
+        gshift = torch.empty_like(shift)
+        k12 = torch.empty(2, C, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        abmi = torch.stack((ab[0], ab[1], save_mean, save_invstd), dim=1).contiguous()       # [C][4]
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nb = int(L.rk2d_backward_bn_workspace_bytes(Fr, C, H, W, 1, 1, 0, 0))
+            ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+            _native.check(getattr(L, "rk2d_backward_bn_" + _BNReLUShift2DTrain._SHIFT_SFX[z.dtype])(
+                gy.data_ptr(), z.data_ptr(), abmi.data_ptr(), shift.data_ptr(), dz.data_ptr(), gshift.data_ptr(), k12.data_ptr(),
+                dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, H, W, 1, 1, 0, 0, int(ctx.normalize_grad), 0, ws.data_ptr(), nb,
+                stream), "rk2d_backward_bn")
+            _native.check(getattr(L, "rk_bn_bwd_dx_pre_" + sfx)(
+                dz.data_ptr(), z.data_ptr(), weight.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), k12.data_ptr(),
+                None, dz.data_ptr(), Fr, C, P, stream), "rk_bn_bwd_dx_pre")                       # in place: dz -> d(z)
+        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gshift, None, None, None, None, None, None, None)
+
+
+def bn_relu_shift2d(bn, as3, z):
+    """`as3(relu(bn(z)))` for an -aq block in training mode with the activation never stored (`as3`: the block's
+    RubiksShift2D).  None when no fused kernel applies (the caller then takes bn_relu + as3)."""
+    sw = config.switches()
+    if not (sw.fused_train and sw.bn_shift2d and _fusable(bn, z) and bn.training and torch.is_grad_enabled()):
+        return None
+    shift = getattr(as3, "shift", None)
+    if (shift is None or not shift.is_cuda or shift.dtype != torch.float32 or shift.dim() != 2
+            or shift.shape != (2, z.shape[1]) or bn.num_features != z.shape[1]):
+        return None
+    if (getattr(as3, "quantize", False) or getattr(as3, "stride", 1) not in (1, (1, 1)) or getattr(as3, "padding", 0) not in (0, (0, 0))
+            or z.shape[2:] != (14, 14) or z.shape[1] % 2 or z.data_ptr() % 16):
+        return None                  # (the shapes rk2d_*_bn_* take today: 14 x 14 planes, stride 1, pad 0)
+    z = z.contiguous()
+    momentum, counter = _count_batch(bn)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNReLUShift2DTrain.apply(z, bn.weight, bn.bias, shift, rm, rv, momentum, bn.eps, _ptr(counter),
+                                     bool(getattr(as3, "normalize_grad", True)), take_stats(z))
 
 
 def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):

@@ -1,0 +1,94 @@
+"""bn2 + ReLU folded into the 2-D shift (rk2d_*_bn_*, fused_bn.bn_relu_shift2d; round 5): the fused pair against
+`RubiksShift2D(relu(BatchNorm2d(z)))` evaluated by PyTorch in fp64 + the oracle's 2-D shift (forward), and against the unfused
+HIP path (bn_relu, then the shift module) for every gradient -- fp32 at fp32 bars, bf16 at bf16 bars; running statistics and
+num_batches_tracked as nn.BatchNorm2d keeps them; integer shift components (the extra walks of rk2d_tile.hpp) included."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _setup(Fr, C, dtype, kind, seed):
+    from rubiksnet_amd.shiftlib import RubiksShift2D
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    z = (torch.randn(Fr, C, 14, 14, generator=g) * 1.7 + 0.3).to(DEV).to(dtype)
+    bn = torch.nn.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    as3 = RubiksShift2D(C).to(DEV)
+    with torch.no_grad():
+        s = torch.rand(2, C, generator=g) * 2 - 1
+        if kind == "integer":
+            s[0, ::3] = torch.round(s[0, ::3] * 1.4)
+            s[1, 1::4] = torch.round(s[1, 1::4] * 1.4)
+            s[:, 0] = 0.0
+        as3.shift.copy_(s)
+    gy = torch.randn(Fr, C, 14, 14, generator=g).to(DEV).to(dtype)
+    return z, bn, as3, gy
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["generic", "integer"])
+@pytest.mark.parametrize("Fr,C", [(8, 6), (256, 288), (13, 34)])
+def test_fused_pair_matches_unfused_pair(Fr, C, dtype, kind):
+    from rubiksnet_amd import fused_bn
+
+    z, bn, as3, gy = _setup(Fr, C, dtype, kind, Fr * 7 + C)
+    bn_u, as3_u = copy.deepcopy(bn), copy.deepcopy(as3)
+    zf = z.clone().requires_grad_(True)
+    zu = z.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        yf = fused_bn.bn_relu_shift2d(bn, as3, zf)
+        assert yf is not None, "14 x 14 planes must take the fused kernels"
+        yu = as3_u(fused_bn.bn_relu(bn_u, zu))
+    yf.backward(gy)
+    yu.backward(gy)
+    torch.cuda.synchronize()
+    b16 = dtype == torch.bfloat16
+
+    def close(a, b, tol, what):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        scale = max(1.0, float(b.abs().max()))
+        err = float((a - b).abs().max())
+        assert err <= tol * scale, "%s: max err %.3e (scale %.3g)" % (what, err, scale)
+
+    # forward: the same activation (a z + b in one fma, rounded to the storage type) through the same interpolation
+    close(yf, yu, 2e-2 if b16 else 2e-5, "y")
+    close(zf.grad, zu.grad, 3e-2 if b16 else 5e-5, "d(z)")
+    close(bn.weight.grad, bn_u.weight.grad, 2e-2 if b16 else 1e-4, "d(gamma)")
+    close(bn.bias.grad, bn_u.bias.grad, 2e-2 if b16 else 1e-4, "d(beta)")
+    close(as3.shift.grad, as3_u.shift.grad, 2e-2 if b16 else 1e-4, "d(shift)")      # unit vectors after K9
+    close(bn.running_mean, bn_u.running_mean, 1e-5, "running_mean")
+    close(bn.running_var, bn_u.running_var, 1e-5, "running_var")
+    assert int(bn.num_batches_tracked) == int(bn_u.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("kind", ["generic", "integer"])
+def test_fused_forward_against_fp64_and_the_oracle(oracle, kind):
+    """fp32: y == oracle.rk2d_forward(relu(bn(z)) in fp64 rounded to fp32) to fp32 round-off of the normalisation."""
+    from rubiksnet_amd import fused_bn
+
+    z, bn, as3, _ = _setup(16, 10, torch.float32, kind, 5)
+    y = fused_bn.bn_relu_shift2d(bn, as3, z.clone().requires_grad_(True))
+    zd = z.double()
+    mean = zd.mean(dim=(0, 2, 3), keepdim=True)
+    var = zd.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    act = torch.relu((zd - mean) / torch.sqrt(var + bn.eps) * bn.weight.double().view(1, -1, 1, 1) + bn.bias.double().view(1, -1, 1, 1))
+    y_ref = oracle.rk2d_forward(act.detach().float().cpu().numpy(), as3.shift.detach().cpu().numpy(), 1, 0)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(y_ref).max())))
+
+
+def test_other_planes_fall_back():
+    from rubiksnet_amd import fused_bn
+    from rubiksnet_amd.shiftlib import RubiksShift2D
+
+    bn = torch.nn.BatchNorm2d(8).to(DEV).train()
+    as3 = RubiksShift2D(8).to(DEV)
+    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 28, 28, device=DEV, requires_grad=True)) is None
+    assert fused_bn.bn_relu_shift2d(bn.eval(), as3, torch.randn(4, 8, 14, 14, device=DEV, requires_grad=True)) is None

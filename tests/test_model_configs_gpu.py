@@ -186,6 +186,51 @@ class _Taps:
 
         monkeypatch.setattr(BT, "forward", staticmethod(btfwd))
         monkeypatch.setattr(BT, "backward", staticmethod(btbwd))
+
+        # -aq blocks on 14 x 14 planes in training: bn2 + ReLU folded into the 2-D shift (fused_bn._BNReLUShift2DTrain): counted
+        # with the plain 2-D calls, recorded separately (f2_bn / b2_bn) with the activation materialised by the stand-alone
+        # normalise kernel -- so the checks read "normalise, then the oracle's shift", as for the 3-D fusion above
+        from rubiksnet_amd.fused_bn import _BNReLUShift2DTrain as B2
+        b2f, b2b = B2.forward, B2.backward
+        self.f2_bn, self.b2_bn = {}, {}
+
+        def _act2(z, ab):
+            from rubiksnet_amd import _native
+            Fr, C, H, W = z.shape
+            out = torch.empty_like(z)
+            sfx = "bf16" if z.dtype == torch.bfloat16 else "f32"
+            _native.check(getattr(_native.lib(), "rk_bn_apply_affine_" + sfx)(
+                z.data_ptr(), ab[0].contiguous().data_ptr(), ab[1].contiguous().data_ptr(), out.data_ptr(), Fr, C, H * W, 1,
+                torch.cuda.current_stream().cuda_stream), "apply")
+            return out
+
+        def b2fwd(ctx, z, weight, bias, shift, rm, rv, momentum, eps, counter, normalize_grad, stats=None):
+            y = b2f(ctx, z, weight, bias, shift, rm, rv, momentum, eps, counter, normalize_grad, stats)
+            taps.calls["f2"] += 1
+            key = (tuple(z.shape), z.dtype)
+            if key not in taps.f2_bn:
+                ab = ctx.to_save[6]
+                taps.f2_bn[key] = dict(x=_act2(z, ab).detach().cpu(), shift=shift.detach().cpu(), y=y.detach().cpu())
+            return y
+
+        def b2bwd(ctx, gy):
+            z, weight, bias, shift, save_mean, save_invstd, ab = ctx.saved_tensors
+            key = (tuple(z.shape), z.dtype)
+            first = key not in taps.b2_bn
+            rec = None
+            if first:
+                rec = dict(x=_act2(z, ab).detach().cpu(), z=z.detach().cpu(), shift=shift.detach().cpu(), gy=gy.detach().cpu(),
+                           w=weight.detach().cpu(), mean=save_mean.detach().cpu(), invstd=save_invstd.detach().cpu())
+            out = b2b(ctx, gy)
+            taps.calls["b2"] += 1
+            if first:
+                rec.update(dz=out[0].detach().cpu(), dgamma=out[1].detach().cpu(), dbeta=out[2].detach().cpu(),
+                           gs=out[3].detach().cpu())
+                taps.b2_bn[key] = rec
+            return out
+
+        monkeypatch.setattr(B2, "forward", staticmethod(b2fwd))
+        monkeypatch.setattr(B2, "backward", staticmethod(b2bwd))
         monkeypatch.setattr(rc, "rubiks_shift_3d_forward_float", fwd3)
         monkeypatch.setattr(rc, "rubiks_shift_3d_backward_float", bwd3)
         monkeypatch.setattr(rc, "rubiks2d_forward", fwd2)
@@ -328,8 +373,31 @@ def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp)
     assert torch.isfinite(loss)
     assert taps.calls == dict(f3=0, b3=0, f2=nblocks, b2=nblocks, fa=nblocks, ba=nblocks)
     st = torch.bfloat16 if amp is not None else torch.float32
-    assert {(k[0][1], k[0][2], k[1][0]) for k in taps.f2} == _expected_shapes(width)
+    # (the 14 x 14 identity blocks take the bn2-folded form: f2_bn / b2_bn)
+    assert ({(k[0][1], k[0][2], k[1][0]) for k in taps.f2} | {(k[0][1], k[0][2], 1) for k in taps.f2_bn}) == _expected_shapes(width)
     assert all(k[2] == st and k[0][0] == B * 8 for k in taps.f2) and set(taps.b2) == set(taps.f2)
+    assert len(taps.f2_bn) >= 1 and set(taps.b2_bn) == set(taps.f2_bn) and all(k[0][2:] == (14, 14) for k in taps.f2_bn)
+    for key, r in taps.f2_bn.items():                  # ---- bn2 + ReLU + RubiksShift2D as one operator: "normalise, then shift", bit for bit
+        y_ref = oracle.rk2d_forward(r["x"].float().numpy(), r["shift"].float().numpy(), [1, 1], [0, 0], False)
+        assert torch.equal(r["y"], _rounded(y_ref, st)), "bn2 + 2-D forward %s" % (key,)
+    for key, r in taps.b2_bn.items():
+        xf, sf, gf = r["x"].float().numpy(), r["shift"].float().numpy(), r["gy"].float().numpy()
+        gx_ref, _ = oracle.rk2d_backward(gf, xf, sf, [1, 1], [0, 0], quantize=False)
+        _, gs_ref = oracle.rk2d_backward(gf.astype(np.float64), xf.astype(np.float64), sf.astype(np.float64), [1, 1], [0, 0],
+                                         normalize_grad=True)
+        np.testing.assert_allclose(r["gs"].float().numpy(), gs_ref, rtol=0, atol=2e-5, err_msg="bn2 + 2-D d(shift) %s" % (key,))
+        # bn2's backward from the oracle's d(x): mask, the two sums, d(z) = gamma invstd (dz - k1 - zhat k2)
+        dzm = _rounded(gx_ref, st).double() * (r["x"].double() > 0)
+        zhat = (r["z"].double() - r["mean"].double().view(1, -1, 1, 1)) * r["invstd"].double().view(1, -1, 1, 1)
+        dbeta, dgamma = dzm.sum(dim=(0, 2, 3)), (dzm * zhat).sum(dim=(0, 2, 3))
+        cnt = dzm.numel() / dzm.shape[1]
+        dz = (r["w"].double() * r["invstd"].double()).view(1, -1, 1, 1) * (dzm - (dbeta / cnt).view(1, -1, 1, 1)
+                                                                           - zhat * (dgamma / cnt).view(1, -1, 1, 1))
+        tol = 2.0 ** -6 if st == torch.bfloat16 else 1e-5
+        for name, got, ref in (("dbeta", r["dbeta"], dbeta), ("dgamma", r["dgamma"], dgamma), ("dz", r["dz"], dz)):
+            np.testing.assert_allclose(got.double().numpy(), ref.numpy(), rtol=0,
+                                       atol=(5e-3 if name != "dz" and st == torch.bfloat16 else tol) * max(1e-6, float(ref.abs().max())),
+                                       err_msg="bn2 + 2-D %s %s" % (name, key))
 
     for key, r in taps.f2.items():                     # ---- RubiksShift2D forward
         xf, sf = r["x"].float().numpy(), r["shift"].float().numpy()
