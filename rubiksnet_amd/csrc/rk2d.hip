@@ -168,6 +168,10 @@ static int forward2_bn(const void* z, const float* ab, const float* shift, void*
     if (int rc = make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return rc;
     if (quantize) return RK_ERR_UNSUPPORTED;
     if (tile2d::launch_forward2_bn<T, float>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream)) return launch_status();
+    if constexpr (sizeof(T) == 2) {                                  // raw 16-bit planes: 56 x 56, 112 x 112
+        if (raw16::launch_forward2_bn<T, float>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream)) return launch_status();
+        if (stage2d::launch_forward2_bn<T, float>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream)) return launch_status();   // 28 x 28
+    }
     return RK_ERR_UNSUPPORTED;
 }
 template <typename T>
@@ -179,13 +183,21 @@ static int backward2_bn(const void* gy, const void* z, const float* abmi, const 
     if (int rc = make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return rc;
     if (quantize) return RK_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < 2 * workspace2(d, 4)) return RK_ERR_WORKSPACE;
-    tile2d::BnFuse2 bn;
+    dma2d::BnFuse2 bn;
     bn.abmi = reinterpret_cast<const float4*>(abmi);
     bn.k12 = k12; bn.dgamma = dgamma; bn.dbeta = dbeta;
     bn.inv_count = (float)(1.0 / ((double)N * H * W));
     if (tile2d::launch_backward2_bn<T, float>((const T*)gy, (const T*)z, shift, (T*)dz, gshift, ws, normalize_grad, bn, d,
                                               (hipStream_t)stream))
         return launch_status();
+    if constexpr (sizeof(T) == 2) {
+        if (raw16::launch_backward2_bn<T, float>((const T*)gy, (const T*)z, shift, (T*)dz, gshift, ws, normalize_grad, bn, d,
+                                                 (hipStream_t)stream))
+            return launch_status();
+        if (stage2d::launch_backward2_bn<T, float>((const T*)gy, (const T*)z, shift, (T*)dz, gshift, ws, normalize_grad, bn, d,
+                                                   (hipStream_t)stream))
+            return launch_status();
+    }
     return RK_ERR_UNSUPPORTED;
 }
 
@@ -235,6 +247,22 @@ RK_DEF_2D_MIXED(f16, __half)
 RK_DEF_2D_MIXED(bf16, __hip_bfloat16)
 #undef RK_DEF_2D_MIXED
 
+// 1 when rk2d_forward_bn_* / rk2d_backward_bn_* have a fused kernel for this shape and storage size (4: fp32, 2: bf16), else 0:
+// lets a caller decide BEFORE it runs bn2's statistics (whose side effects -- running statistics -- must happen once)
+int rk2d_bn_fused_shape(int N, int C, int H, int W, int elem_size) {
+    Dims2 d;
+    if (make_dims2(d, N, C, H, W, 1, 1, 0, 0)) return 0;
+    if (elem_size == 4) { tile2d::TDims2 t; return tile2d::make_tdims<float, 14, 14>(t, d) ? 1 : 0; }
+    if (elem_size != 2) return 0;
+    tile2d::TDims2 t;
+    if (tile2d::make_tdims<__hip_bfloat16, 14, 14>(t, d)) return 1;
+    dma2d::FDims f;
+    if (raw16::make_fdims8(f, d, raw16::kFramesRaw16) && bwd_ring_bytes(f.b, 1, 1) <= 64 * 1024 &&
+        raw16::make_fdims8(f, d, raw16::kFramesRaw16Fwd) && interp_ring_bytes(f.b, 2) <= 64 * 1024)
+        return 1;
+    if (dma2d::make_fdims(f, d, dma2d::kFrames16)) return 1;         // register-staged 16-bit planes: other W % 4 == 0 (28 x 28)
+    return 0;
+}
 size_t rk2d_backward_bn_workspace_bytes(int N, int C, int H, int W, int sH, int sW, int pH, int pW) {
     Dims2 d;
     if (make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return 0;

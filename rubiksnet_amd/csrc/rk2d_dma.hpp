@@ -285,6 +285,33 @@ __device__ __forceinline__ void finalizer_wave2(const Fin2<S>& fin, int c, int C
     }
 }
 
+// training fusion (bn2 + ReLU inside the 2-D shift, round 5): what the backward needs of bn2 and where bn2's constants go
+struct BnFuse2 {
+    const float4* abmi;           // [C] (a, b, mean, invstd)
+    float* k12;                   // [2][C]
+    float* dgamma; float* dbeta;  // [C]
+    float inv_count;              // 1 / (F H W)
+};
+template <typename S>
+__device__ __forceinline__ void finalizer_wave2_bn(const Fin2<S>& fin, int c, int C, int P, const BnFuse2& bn) {
+    double s[4];
+    const bool ok = fin_collect<4>(fin.f, c, P, s);
+    if (threadIdx.x == 0) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+        float gH = (float)s[0], gW = (float)s[1];
+        if (fin.normalize) {
+            const float mag = sqrtf(gH * gH + gW * gW);
+            if (mag > 0) { gH = gH / mag; gW = gW / mag; }
+        }
+        if (!ok) gH = gW = nanv;
+        st(fin.gshift + c, gH);
+        st(fin.gshift + C + c, gW);
+        bn.dbeta[c] = ok ? (float)s[2] : nanv;
+        bn.dgamma[c] = ok ? (float)s[3] : nanv;
+        bn.k12[c] = ok ? (float)(s[2] * (double)bn.inv_count) : nanv;
+        bn.k12[C + c] = ok ? (float)(s[3] * (double)bn.inv_count) : nanv;
+    }
+}
 template <int ROUNDS, int DG, int DX>
 __global__ __launch_bounds__(kBlock) void k2d_dma_backward(const float* __restrict__ gy,
                                                            const float* __restrict__ x,

@@ -57,6 +57,30 @@ template <typename T> __device__ __forceinline__ void widen8(const Raw8& q, floa
 #pragma unroll
     for (int m = 0; m < 8; ++m) t[m] = Wide<T>::get(q.w[m >> 1], m & 1);
 }
+// a value as the storage type holds it
+template <typename T> __device__ __forceinline__ float round16(float v) { return Wide<T>::get(stage2d::Cell4<T>::bits(v), 0); }
+// Training fusion (bn2 + ReLU inside the shift, fused_bn.bn_relu_shift2d): the planes a kernel reads are z = conv2's output
+// and the shift applies to max(a z + b, 0) rounded to the storage type.  The wave that DMA'd a cell transforms it in place
+// once it has landed (its own counted vmcnt wait) and before the step's barrier -- the slot's DMA'd cells only, so rows
+// outside the plane and the zero cell stay zero (the 16-bit twin of rk_dma.hpp's bn_taps).
+template <typename T, int ROUNDS>
+__device__ __forceinline__ void bn_taps16(float4* slot, const BCells<ROUNDS>& cs, float a, float b) {
+    char* base = reinterpret_cast<char*>(slot) + cs.off0;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+        if (cs.in_act[i]) {
+            uint4* p = reinterpret_cast<uint4*>(base + 4096 * i);
+            const uint4 w = *p;
+            const unsigned in[4] = {w.x, w.y, w.z, w.w};
+            unsigned out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v0 = fmaxf(fmaf(a, Wide<T>::get(in[j], 0), b), 0.f), v1 = fmaxf(fmaf(a, Wide<T>::get(in[j], 1), b), 0.f);
+                out[j] = stage2d::Cell4<T>::bits(v0) | (stage2d::Cell4<T>::bits(v1) << 16);
+            }
+            *p = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+}
 template <typename T> __device__ __forceinline__ void store8(void* p, const float (&q)[8]) {
     using C4 = stage2d::Cell4<T>;
     const uint2 lo = C4::narrow(q[0], q[1], q[2], q[3]), hi = C4::narrow(q[4], q[5], q[6], q[7]);
@@ -66,10 +90,10 @@ template <typename T> __device__ __forceinline__ void store8(void* p, const floa
 
 // ---------------------------------------------------------------------------------------------
 // Forward (src = x) and d(x) alone (src = gy, negated shift).  sp / dp: frame 0 of the group, this channel.
-template <typename T, int ROUNDS, int D, int OFF>
+template <typename T, int ROUNDS, int D, int OFF, bool BN = false>
 __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __restrict__ dp, float4* ring,
                                              const BDims& d, const Band& b, const Frac<float>& fH,
-                                             const Frac<float>& fW, size_t fstride, int nf) {
+                                             const Frac<float>& fW, size_t fstride, int nf, float bn_a = 1.f, float bn_b = 0.f) {
     constexpr int R = D + 1;
     __syncthreads();                                              // (a backward walk may have used the ring before)
     const int slot_f4 = b.cells_in + 1;
@@ -111,6 +135,7 @@ __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __rest
 #pragma nounroll
     for (int k = 0; k < nf; ++k) {
         wait_vmcnt(issued - mark[0]);                              // my pieces of frame k have landed
+        if (BN) bn_taps16<T, ROUNDS>(ring + slot * slot_f4, cs, bn_a, bn_b);
         __syncthreads();                                           // everyone's have; frame k-1 is retired
         {
             int sn = slot + D; if (sn >= R) sn -= R;
@@ -136,9 +161,9 @@ __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __rest
     }
 __device__ __forceinline__ int off8(int fl) { return ((fl % 8) + 8) % 8; }
 
-template <typename T, typename S, bool NEGATE, int ROUNDS, int D>
+template <typename T, typename S, bool NEGATE, int ROUNDS, int D, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_raw16_interp(const T* __restrict__ src, const S* __restrict__ shift,
-                                                           T* __restrict__ dst, FDims fd) {
+                                                           T* __restrict__ dst, FDims fd, const float* __restrict__ ab = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     const BDims& d = fd.b;
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
@@ -161,19 +186,24 @@ __global__ __launch_bounds__(kBlock) void k2d_raw16_interp(const T* __restrict__
                     reinterpret_cast<const uint4*>(sp + (size_t)k * fstride)[b.out0 + cell];
         return;
     }
-#define RK_CALL(O) interp2_loop<T, ROUNDS, D, O>(sp, dp, ring, d, b, fH, fW, fstride, nf)
+    const float bn_a = BN ? ab[c] : 1.f, bn_b = BN ? ab[d.C + c] : 0.f;
+#define RK_CALL(O) interp2_loop<T, ROUNDS, D, O, BN>(sp, dp, ring, d, b, fH, fW, fstride, nf, bn_a, bn_b)
     RK_OFF8_SWITCH(off8(fW.fl), RK_CALL)                           // wave-uniform
 #undef RK_CALL
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward: d(x) + d(shift) partials in one pass (adjoint form, see rk2d_dma.hpp).
-template <typename T, int ROUNDS, int OFF, bool WRITE_GX>
+// BN: x holds z = bn2's input; the activation max(a z + b, 0) (rounded: what the forward shifted) is recomputed at the thread's
+// own cell, d(x) leaves ReLU-masked and bn2's two sums ride along (accB1 = sum dz, accB2 = sum dz zhat; bnp = a, b, mean, invstd)
+template <typename T, int ROUNDS, int OFF, bool WRITE_GX, bool BN = false>
 __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T* __restrict__ gp,
                                                T* __restrict__ op, float4* ring, const BDims& d, const Band& b,
                                                const Frac<float>& fH, const Frac<float>& fW, size_t fstride, int nf,
-                                               float& accH, float& accW) {
+                                               float& accH, float& accW, float4 bnp = make_float4(1.f, 0.f, 0.f, 1.f),
+                                               float* accB1 = nullptr, float* accB2 = nullptr) {
     constexpr int DG = 1, DX = 1, RG = DG + 1, RX = DX;
+    float sB1 = 0.f, sB2 = 0.f;
     __syncthreads();                                              // a previous walk may still be reading the ring
     const int gslot_f4 = b.cells_in + 1, xslot_f4 = b.cells_out + 1;
     BCells<ROUNDS> cs;
@@ -213,13 +243,20 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
         if (j < DX) { feed_x(j, j); mark[j] = issued; }
     }
 
-    auto round = [&](int i, const float4* cur, const Raw8& xraw, T* out, bool store) {
+    auto round = [&](int i, const float4* cur, const Raw8& xraw, T* out, bool store, bool live) {
         const Raw8 qa0 = lds_raw(cur + cs.a0[i]), qa1 = lds_raw(cur + cs.a1[i]);
         const Raw8 qb0 = lds_raw(cur + cs.b0[i]), qb1 = lds_raw(cur + cs.b1[i]);
-        float ta[9], tb[9], xv[8], col[9], q[8];
+        float ta[9], tb[9], xv[8], col[9], q[8], zv[8];
         taps9<T, OFF>(qa0, qa1, ta);
         taps9<T, OFF>(qb0, qb1, tb);
         widen8<T>(xraw, xv);
+        if (BN) {                                                  // (a lane without a cell reads the zero cell: relu(b) is not 0)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                zv[m] = xv[m];
+                xv[m] = live ? round16<T>(fmaxf(fmaf(bnp.x, zv[m], bnp.y), 0.f)) : 0.f;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 9; ++m) col[m] = fmaf(uH, ta[m], rH * tb[m]);
 #pragma unroll
@@ -228,6 +265,11 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
             const float la = fmaf(ta[m], uW, ta[m + 1] * rW), lb = fmaf(tb[m], uW, tb[m + 1] * rW);
             sH = fmaf(la - lb, xv[m], sH);
             sW = fmaf(col[m] - col[m + 1], xv[m], sW);
+            if (BN && WRITE_GX) {                                  // d(bn2's output): as stored, ReLU-masked; bn2's sums
+                q[m] = xv[m] > 0.f ? round16<T>(q[m]) : 0.f;
+                sB1 += q[m];
+                sB2 = fmaf(q[m], (zv[m] - bnp.z) * bnp.w, sB2);
+            }
         }
         if (store) store8<T>(reinterpret_cast<char*>(out) + cs.off0 + 4096 * i, q);
     };
@@ -252,23 +294,28 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
         const float4* cur = gring + gslot * gslot_f4;
         T* out = out0 + (size_t)k * fstride;
 #pragma unroll
-        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, WRITE_GX);
-        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, WRITE_GX && cs.tail_live);
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, WRITE_GX, true);
+        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, WRITE_GX && cs.tail_live, cs.tail_live);
         issued += n_store_wave;
         if (++gslot == RG) gslot = 0;
     }
     accH = sH; accW = sW;
+    if (BN && WRITE_GX) { *accB1 = sB1; *accB2 = sB2; }
 }
 
-template <typename T, typename S, int ROUNDS>
+template <typename T, typename S, int ROUNDS, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_raw16_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const S* __restrict__ shift, T* __restrict__ gx,
-                                                             FDims fd, Fin2<S> fin) {
+                                                             FDims fd, Fin2<S> fin, dma2d::BnFuse2 bn = dma2d::BnFuse2{}) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
-    __shared__ float red[2][kBlock / kWave];
+    __shared__ float red[4][kBlock / kWave];
+    constexpr int ND = BN ? 4 : 2;
     const BDims& d = fd.b;
     if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
-        if (threadIdx.x < kWave) dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands);
+        if (threadIdx.x < kWave) {
+            if (BN) dma2d::finalizer_wave2_bn(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands, bn);
+            else dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands);
+        }
         return;
     }
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
@@ -281,18 +328,44 @@ __global__ __launch_bounds__(kBlock) void k2d_raw16_backward(const T* __restrict
     const size_t fstride = (size_t)d.C * HW;
     const size_t base = ((size_t)f0 * d.C + c) * HW;
     const dma2d::IntegerPlan plan = dma2d::plan_walks(s0, s1);   // integer shifts: see rk2d_dma.hpp
+    float4 bnp = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (BN) bnp = bn.abmi[c];
+    float sumB1 = 0.f, sumB2 = 0.f;
     if (plan.separate_gx) {
         const Band b = make_band(d, band, plan.gH.fl);
 #define RK_CALL(O) interp2_loop<T, ROUNDS, 1, O>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf)
         RK_OFF8_SWITCH(off8(plan.gW.fl), RK_CALL)
 #undef RK_CALL
+        if (BN) {
+            // (a remainder below 1e-7 that is not 0: never a trained parameter.)  d(x) was written unmasked by the d(x)-only
+            // walk: mask it in place -- every thread re-reads the cells the workgroup wrote -- and collect bn2's sums
+            __syncthreads();
+            for (int k = 0; k < nf; ++k) {
+                T* gp = gx + base + (size_t)k * fstride + (size_t)b.out0 * 8;
+                const T* zp = x + base + (size_t)k * fstride + (size_t)b.out0 * 8;
+                for (int cell = threadIdx.x; cell < b.cells_out; cell += kBlock) {
+                    const uint4 gw = reinterpret_cast<const uint4*>(gp)[cell], zw = reinterpret_cast<const uint4*>(zp)[cell];
+                    const Raw8 gr{{gw.x, gw.y, gw.z, gw.w}}, zr{{zw.x, zw.y, zw.z, zw.w}};
+                    float gv[8], zv[8];
+                    widen8<T>(gr, gv); widen8<T>(zr, zv);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const float act = round16<T>(fmaxf(fmaf(bnp.x, zv[m], bnp.y), 0.f));
+                        gv[m] = act > 0.f ? gv[m] : 0.f;
+                        sumB1 += gv[m];
+                        sumB2 = fmaf(gv[m], (zv[m] - bnp.z) * bnp.w, sumB2);
+                    }
+                    store8<T>(reinterpret_cast<char*>(gp) + 16 * cell, gv);
+                }
+            }
+        }
     }
     float sumH0 = 0.f, sumW0 = 0.f, sumH1 = 0.f, sumW2 = 0.f;
     if (!plan.separate_gx) {                                      // walk 0 with d(x): every ordinary channel ends here
         const Frac<float> fH = plan.sH, fW = plan.sW;
         const Band b = make_band(d, band, fH.fl);
         float aH = 0.f, aW = 0.f;
-#define RK_CALL(O) backward2_loop<T, ROUNDS, O, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW)
+#define RK_CALL(O) backward2_loop<T, ROUNDS, O, true, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp, &sumB1, &sumB2)
         RK_OFF8_SWITCH(off8(fW.fl), RK_CALL)
 #undef RK_CALL
         sumH0 = aH; sumW0 = aW;
@@ -306,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k2d_raw16_backward(const T* __restrict
             if (walk == 2) fW.fl -= 1;
             const Band b = make_band(d, band, fH.fl);
             float aH = 0.f, aW = 0.f;
-#define RK_CALL(O) backward2_loop<T, ROUNDS, O, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW)
+#define RK_CALL(O) backward2_loop<T, ROUNDS, O, false, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp)
             RK_OFF8_SWITCH(off8(fW.fl), RK_CALL)
 #undef RK_CALL
             if (walk == 0) { sumH0 = aH; sumW0 = aW; }
@@ -319,11 +392,13 @@ __global__ __launch_bounds__(kBlock) void k2d_raw16_backward(const T* __restrict
 
     accH = group_sum(accH, kBlock, red[0]);
     accW = group_sum(accW, kBlock, red[1]);
+    if (BN) { sumB1 = group_sum(sumB1, kBlock, red[2]); sumB2 = group_sum(sumB2, kBlock, red[3]); }
     if (threadIdx.x == 0) {
         const int P = fd.ngroups * d.nbands;
-        const size_t at = (size_t)c * 2 * P + (size_t)g * d.nbands + band;
+        const size_t at = (size_t)c * ND * P + (size_t)g * d.nbands + band;
         fin_publish(fin.f, at, accH);
         fin_publish(fin.f, at + P, accW);
+        if (BN) { fin_publish(fin.f, at + 2 * (size_t)P, sumB1); fin_publish(fin.f, at + 3 * (size_t)P, sumB2); }
     }
 }
 #undef RK_OFF8_SWITCH
@@ -390,6 +465,46 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
         case 2: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 2>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
         case 3: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 3>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
         default: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 4>), grid, block, lds, stream, gy, x, shift, gx, f, fin); break;
+    }
+    return true;
+}
+
+// training fusion: forward of relu(bn2(z)) (ab [2][C]) and its backward; false = not handled here
+template <typename T, typename S>
+inline bool launch_forward2_bn(const T* z, const float* ab, const S* shift, T* y, const Dims2& d, hipStream_t stream) {
+    constexpr int D = 2;
+    FDims f;
+    if (!make_fdims8(f, d, kFramesRaw16Fwd) || !aligned16(z) || !aligned16(y)) return false;
+    const size_t lds = interp_ring_bytes(f.b, D);
+    if (lds > 64 * 1024) return false;
+    const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
+    switch (rounds_of(f.b)) {
+        case 1: hipLaunchKernelGGL((k2d_raw16_interp<T, S, false, 1, D, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+        case 2: hipLaunchKernelGGL((k2d_raw16_interp<T, S, false, 2, D, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+        case 3: hipLaunchKernelGGL((k2d_raw16_interp<T, S, false, 3, D, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+        default: hipLaunchKernelGGL((k2d_raw16_interp<T, S, false, 4, D, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+    }
+    return true;
+}
+template <typename T, typename S>
+inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, S* gshift, void* ws, int normalize,
+                                const dma2d::BnFuse2& bn, const Dims2& d, hipStream_t stream) {
+    FDims f;
+    if (!make_fdims8(f, d, kFramesRaw16) || !aligned16(gy) || !aligned16(z) || !aligned16(dz) || !aligned16(bn.abmi)) return false;
+    const size_t lds = bwd_ring_bytes(f.b, 1, 1);
+    if (lds > 64 * 1024) return false;
+    Fin2<S> fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    const dim3 grid((unsigned)(fin.f.producers + f.b.C)), block(kBlock);
+    switch (rounds_of(f.b)) {
+        case 1: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 1, true>), grid, block, lds, stream, gy, z, shift, dz, f, fin, bn); break;
+        case 2: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 2, true>), grid, block, lds, stream, gy, z, shift, dz, f, fin, bn); break;
+        case 3: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 3, true>), grid, block, lds, stream, gy, z, shift, dz, f, fin, bn); break;
+        default: hipLaunchKernelGGL((k2d_raw16_backward<T, S, 4, true>), grid, block, lds, stream, gy, z, shift, dz, f, fin, bn); break;
     }
     return true;
 }

@@ -61,10 +61,16 @@ __device__ __forceinline__ void store_cell(void* p, const uint2& v) {
 
 // ---------------------------------------------------------------------------------------------
 // Forward (src = x) and d(x) alone (src = gy, negated shift).  sp / dp: frame 0 of the group, this channel.
-template <typename T, int ROUNDS, int OFF>
+// the activation of the training fusion (fused_bn.bn_relu_shift2d): max(a z + b, 0) as the storage type holds it
+template <typename T> __device__ __forceinline__ float4 bn_act4(const float4& z, float a, float b) {
+    return Cell4<T>::widen(Cell4<T>::narrow(fmaxf(fmaf(a, z.x, b), 0.f), fmaxf(fmaf(a, z.y, b), 0.f), fmaxf(fmaf(a, z.z, b), 0.f),
+                                            fmaxf(fmaf(a, z.w, b), 0.f)));
+}
+// BN: src holds z = conv2's output and the shift applies to relu(bn2(z)): the cell is transformed on its way into LDS
+template <typename T, int ROUNDS, int OFF, bool BN = false>
 __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __restrict__ dp, float4* ring,
                                              const BDims& d, const Band& b, const Frac<float>& fH,
-                                             const Frac<float>& fW, size_t fstride, int nf) {
+                                             const Frac<float>& fW, size_t fstride, int nf, float bn_a = 1.f, float bn_b = 0.f) {
     const int slot_f4 = b.cells_in + 1;
     BCells<ROUNDS> cs;
     make_bcells<ROUNDS>(cs, d, b, (fW.fl - OFF) / 4);
@@ -89,7 +95,10 @@ __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __rest
     auto deposit = [&](float4* slot) {
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i)
-            if (cs.in_act[i]) slot[threadIdx.x + kBlock * i] = Cell4<T>::widen(stash[i]);
+            if (cs.in_act[i]) {
+                const float4 v = Cell4<T>::widen(stash[i]);
+                slot[threadIdx.x + kBlock * i] = BN ? bn_act4<T>(v, bn_a, bn_b) : v;
+            }
     };
     auto round = [&](int i, const float4* cur, char* out, bool store) {
         const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
@@ -118,9 +127,9 @@ __device__ __forceinline__ void interp2_loop(const T* __restrict__ sp, T* __rest
     }
 }
 
-template <typename T, typename S, bool NEGATE, int ROUNDS>
+template <typename T, typename S, bool NEGATE, int ROUNDS, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_stage_interp(const T* __restrict__ src, const S* __restrict__ shift,
-                                                           T* __restrict__ dst, FDims fd) {
+                                                           T* __restrict__ dst, FDims fd, const float* __restrict__ ab = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
     const BDims& d = fd.b;
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
@@ -143,21 +152,26 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_interp(const T* __restrict__
                     reinterpret_cast<const uint2*>(sp + (size_t)k * fstride)[b.out0 + cell];
         return;
     }
+    const float bn_a = BN ? ab[c] : 1.f, bn_b = BN ? ab[d.C + c] : 0.f;
     switch (((fW.fl % 4) + 4) % 4) {                               // wave-uniform
-        case 0: interp2_loop<T, ROUNDS, 0>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
-        case 1: interp2_loop<T, ROUNDS, 1>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
-        case 2: interp2_loop<T, ROUNDS, 2>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
-        default: interp2_loop<T, ROUNDS, 3>(sp, dp, ring, d, b, fH, fW, fstride, nf); break;
+        case 0: interp2_loop<T, ROUNDS, 0, BN>(sp, dp, ring, d, b, fH, fW, fstride, nf, bn_a, bn_b); break;
+        case 1: interp2_loop<T, ROUNDS, 1, BN>(sp, dp, ring, d, b, fH, fW, fstride, nf, bn_a, bn_b); break;
+        case 2: interp2_loop<T, ROUNDS, 2, BN>(sp, dp, ring, d, b, fH, fW, fstride, nf, bn_a, bn_b); break;
+        default: interp2_loop<T, ROUNDS, 3, BN>(sp, dp, ring, d, b, fH, fW, fstride, nf, bn_a, bn_b); break;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward: d(x) + d(shift) partials in one pass (adjoint form, see rk2d_dma.hpp).
-template <typename T, int ROUNDS, int OFF, bool WRITE_GX>
+// BN: x holds z = bn2's input: the activation is recomputed at the thread's own cell, d(x) leaves ReLU-masked and bn2's two sums
+// ride along (rk2d_raw16.hpp, rk2d_tile.hpp: the same scheme)
+template <typename T, int ROUNDS, int OFF, bool WRITE_GX, bool BN = false>
 __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T* __restrict__ gp,
                                                T* __restrict__ op, float4* ring, const BDims& d, const Band& b,
                                                const Frac<float>& fH, const Frac<float>& fW, size_t fstride, int nf,
-                                               float& accH, float& accW) {
+                                               float& accH, float& accW, float4 bnp = make_float4(1.f, 0.f, 0.f, 1.f),
+                                               float* accB1 = nullptr, float* accB2 = nullptr) {
+    float sB1 = 0.f, sB2 = 0.f;
     __syncthreads();                                              // a previous walk may still be reading the ring
     const int slot_f4 = b.cells_in + 1;
     BCells<ROUNDS> cs;
@@ -195,10 +209,15 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
     };
 
     float sH = 0.f, sW = 0.f;
-    auto round = [&](int i, const float4* cur, const float4& xv4, char* out, bool live) {
+    auto round = [&](int i, const float4* cur, const float4& xv4, char* out, bool live, bool alive) {
         const float4 qa0 = lds_b128(cur + cs.a0[i]), qa1 = lds_b128(cur + cs.a1[i]);
         const float4 qb0 = lds_b128(cur + cs.b0[i]), qb1 = lds_b128(cur + cs.b1[i]);
-        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        const float zv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        if (BN) {                                                  // (a lane without a cell must contribute nothing: relu(b) is not 0)
+            const float4 act = bn_act4<T>(xv4, bnp.x, bnp.y);
+            xv[0] = alive ? act.x : 0.f; xv[1] = alive ? act.y : 0.f; xv[2] = alive ? act.z : 0.f; xv[3] = alive ? act.w : 0.f;
+        }
         float col[5], q[4];
 #pragma unroll
         for (int m = 0; m < 5; ++m) col[m] = fmaf(uH, tap<OFF>(qa0, qa1, m), rH * tap<OFF>(qb0, qb1, m));
@@ -210,6 +229,16 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
             const float la = fmaf(a0, uW, a1 * rW), lb = fmaf(b0, uW, b1 * rW);
             sH = fmaf(la - lb, xv[m], sH);
             sW = fmaf(col[m] - col[m + 1], xv[m], sW);
+        }
+        if (BN && WRITE_GX) {                                      // d(bn2's output): as stored, ReLU-masked; bn2's sums
+            const float4 qr = Cell4<T>::widen(Cell4<T>::narrow(q[0], q[1], q[2], q[3]));
+            const float r4[4] = {qr.x, qr.y, qr.z, qr.w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                q[m] = xv[m] > 0.f ? r4[m] : 0.f;
+                sB1 += q[m];
+                sB2 = fmaf(q[m], (zv[m] - bnp.z) * bnp.w, sB2);
+            }
         }
         if (live) store_cell(out + 2048 * i, Cell4<T>::narrow(q[0], q[1], q[2], q[3]));
     };
@@ -230,21 +259,27 @@ __device__ __forceinline__ void backward2_loop(const T* __restrict__ xp, const T
         if (k + 2 < nf) fetch_g(k + 2);
         char* out = out0 + (size_t)k * fbytes;
 #pragma unroll
-        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, WRITE_GX);
-        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, WRITE_GX && cs.tail_live);
+        for (int i = 0; i + 1 < ROUNDS; ++i) round(i, cur, xv[i], out, WRITE_GX, true);
+        if (cs.tail_on) round(ROUNDS - 1, cur, xv[ROUNDS - 1], out, WRITE_GX && cs.tail_live, cs.tail_live);
     }
     accH = sH; accW = sW;
+    if (BN && WRITE_GX) { *accB1 = sB1; *accB2 = sB2; }
 }
 
-template <typename T, typename S, int ROUNDS>
+template <typename T, typename S, int ROUNDS, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const S* __restrict__ shift, T* __restrict__ gx,
-                                                             FDims fd, Dims2 gd, dma2d::Fin2<S> fin) {
+                                                             FDims fd, Dims2 gd, dma2d::Fin2<S> fin,
+                                                             dma2d::BnFuse2 bn = dma2d::BnFuse2{}) {
     extern __shared__ __attribute__((aligned(16))) float4 ring[];
-    __shared__ float red[2][kBlock / kWave];
+    __shared__ float red[4][kBlock / kWave];
+    constexpr int ND = BN ? 4 : 2;
     const BDims& d = fd.b;
     if ((int)blockIdx.x >= fin.f.producers) {                         // row-sum + K9 inside the launch (rk_dma.hpp)
-        if (threadIdx.x < kWave) dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands);
+        if (threadIdx.x < kWave) {
+            if (BN) dma2d::finalizer_wave2_bn(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands, bn);
+            else dma2d::finalizer_wave2(fin, (int)blockIdx.x - fin.f.producers, d.C, fd.ngroups * d.nbands);
+        }
         return;
     }
     const int band = blockIdx.x % d.nbands, col = blockIdx.x / d.nbands;
@@ -267,16 +302,42 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict
             default: interp2_loop<T, ROUNDS, 3>(gy + base, gx + base, ring, d, b, plan.gH, plan.gW, fstride, nf); break;
         }
     }
+    float4 bnp = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (BN) bnp = bn.abmi[c];
+    float sumB1 = 0.f, sumB2 = 0.f;
+    if (BN && plan.separate_gx) {
+        // (a remainder below 1e-7 that is not 0: never a trained parameter.)  d(x) was written unmasked by the d(x)-only
+        // walk: mask it in place and collect bn2's sums
+        const Band b = make_band(d, band, plan.gH.fl);
+        __syncthreads();
+        for (int k = 0; k < nf; ++k) {
+            char* gp = reinterpret_cast<char*>(gx + base + (size_t)k * fstride + (size_t)b.out0 * 4);
+            const char* zp = reinterpret_cast<const char*>(x + base + (size_t)k * fstride + (size_t)b.out0 * 4);
+            for (int cell = threadIdx.x; cell < b.cells_out; cell += kBlock) {
+                const float4 g4 = Cell4<T>::widen(load_cell(gp + 8 * cell)), z4 = Cell4<T>::widen(load_cell(zp + 8 * cell));
+                const float4 a4 = bn_act4<T>(z4, bnp.x, bnp.y);
+                float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    gv[m] = av[m] > 0.f ? gv[m] : 0.f;
+                    sumB1 += gv[m];
+                    sumB2 = fmaf(gv[m], (zv[m] - bnp.z) * bnp.w, sumB2);
+                }
+                store_cell(gp + 8 * cell, Cell4<T>::narrow(gv[0], gv[1], gv[2], gv[3]));
+            }
+        }
+    }
     float sumH0 = 0.f, sumW0 = 0.f, sumH1 = 0.f, sumW2 = 0.f;
     if (!plan.separate_gx) {                                      // walk 0 with d(x): every ordinary channel ends here
         const Frac<float> fH = plan.sH, fW = plan.sW;
         const Band b = make_band(d, band, fH.fl);
         float aH = 0.f, aW = 0.f;
         switch (((fW.fl % 4) + 4) % 4) {
-            case 0: backward2_loop<T, ROUNDS, 0, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
-            case 1: backward2_loop<T, ROUNDS, 1, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
-            case 2: backward2_loop<T, ROUNDS, 2, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
-            default: backward2_loop<T, ROUNDS, 3, true>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+            case 0: backward2_loop<T, ROUNDS, 0, true, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp, &sumB1, &sumB2); break;
+            case 1: backward2_loop<T, ROUNDS, 1, true, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp, &sumB1, &sumB2); break;
+            case 2: backward2_loop<T, ROUNDS, 2, true, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp, &sumB1, &sumB2); break;
+            default: backward2_loop<T, ROUNDS, 3, true, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp, &sumB1, &sumB2); break;
         }
         sumH0 = aH; sumW0 = aW;
     }
@@ -290,10 +351,10 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict
             const Band b = make_band(d, band, fH.fl);
             float aH = 0.f, aW = 0.f;
             switch (((fW.fl % 4) + 4) % 4) {
-                case 0: backward2_loop<T, ROUNDS, 0, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
-                case 1: backward2_loop<T, ROUNDS, 1, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
-                case 2: backward2_loop<T, ROUNDS, 2, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
-                default: backward2_loop<T, ROUNDS, 3, false>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW); break;
+                case 0: backward2_loop<T, ROUNDS, 0, false, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp); break;
+                case 1: backward2_loop<T, ROUNDS, 1, false, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp); break;
+                case 2: backward2_loop<T, ROUNDS, 2, false, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp); break;
+                default: backward2_loop<T, ROUNDS, 3, false, BN>(x + base, gy + base, gx + base, ring, d, b, fH, fW, fstride, nf, aH, aW, bnp); break;
             }
             if (walk == 0) { sumH0 = aH; sumW0 = aW; }
             else if (walk == 1) sumH1 = aH;
@@ -305,11 +366,13 @@ __global__ __launch_bounds__(kBlock) void k2d_stage_backward(const T* __restrict
 
     accH = group_sum(accH, kBlock, red[0]);
     accW = group_sum(accW, kBlock, red[1]);
+    if (BN) { sumB1 = group_sum(sumB1, kBlock, red[2]); sumB2 = group_sum(sumB2, kBlock, red[3]); }
     if (threadIdx.x == 0) {
         const int P = fd.ngroups * d.nbands;
-        const size_t at = (size_t)c * 2 * P + (size_t)g * d.nbands + band;
+        const size_t at = (size_t)c * ND * P + (size_t)g * d.nbands + band;
         fin_publish(fin.f, at, accH);
         fin_publish(fin.f, at + P, accW);
+        if (BN) { fin_publish(fin.f, at + 2 * (size_t)P, sumB1); fin_publish(fin.f, at + 3 * (size_t)P, sumB2); }
     }
 }
 
@@ -351,6 +414,43 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
         case 2: hipLaunchKernelGGL((k2d_stage_backward<T, S, 2>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
         case 3: hipLaunchKernelGGL((k2d_stage_backward<T, S, 3>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
         default: hipLaunchKernelGGL((k2d_stage_backward<T, S, 4>), grid, block, lds, stream, gy, x, shift, gx, f, d, fin); break;
+    }
+    return true;
+}
+
+// training fusion: forward of relu(bn2(z)) (ab [2][C]) and its backward; false = not handled here
+template <typename T, typename S>
+inline bool launch_forward2_bn(const T* z, const float* ab, const S* shift, T* y, const Dims2& d, hipStream_t stream) {
+    FDims f;
+    if (!dma2d::make_fdims(f, d, dma2d::kFrames16) || !aligned8(z) || !aligned8(y)) return false;
+    const size_t lds = ring_bytes(f.b);
+    const dim3 grid((unsigned)(f.ngroups * f.b.C * f.b.nbands)), block(kBlock);
+    switch (rounds_of(f.b)) {
+        case 1: hipLaunchKernelGGL((k2d_stage_interp<T, S, false, 1, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+        case 2: hipLaunchKernelGGL((k2d_stage_interp<T, S, false, 2, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+        case 3: hipLaunchKernelGGL((k2d_stage_interp<T, S, false, 3, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+        default: hipLaunchKernelGGL((k2d_stage_interp<T, S, false, 4, true>), grid, block, lds, stream, z, shift, y, f, ab); break;
+    }
+    return true;
+}
+template <typename T, typename S>
+inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, S* gshift, void* ws, int normalize,
+                                const dma2d::BnFuse2& bn, const Dims2& d, hipStream_t stream) {
+    FDims f;
+    if (!dma2d::make_fdims(f, d, dma2d::kFrames16) || !aligned8(gy) || !aligned8(z) || !aligned8(dz) || !aligned16(bn.abmi)) return false;
+    const size_t lds = ring_bytes(f.b);
+    dma2d::Fin2<S> fin;
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    fin.f.tag = next_launch_tag();
+    fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
+    fin.gshift = gshift;
+    fin.normalize = normalize;
+    const dim3 grid((unsigned)(fin.f.producers + f.b.C)), block(kBlock);
+    switch (rounds_of(f.b)) {
+        case 1: hipLaunchKernelGGL((k2d_stage_backward<T, S, 1, true>), grid, block, lds, stream, gy, z, shift, dz, f, d, fin, bn); break;
+        case 2: hipLaunchKernelGGL((k2d_stage_backward<T, S, 2, true>), grid, block, lds, stream, gy, z, shift, dz, f, d, fin, bn); break;
+        case 3: hipLaunchKernelGGL((k2d_stage_backward<T, S, 3, true>), grid, block, lds, stream, gy, z, shift, dz, f, d, fin, bn); break;
+        default: hipLaunchKernelGGL((k2d_stage_backward<T, S, 4, true>), grid, block, lds, stream, gy, z, shift, dz, f, d, fin, bn); break;
     }
     return true;
 }

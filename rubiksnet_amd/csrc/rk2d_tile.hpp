@@ -22,6 +22,8 @@ namespace tile2d {
 using namespace dma;
 using dma2d::Fin2;
 using dma2d::IntegerPlan;
+using dma2d::BnFuse2;
+using dma2d::finalizer_wave2_bn;
 using g2d::Dims2;
 
 template <typename T, int H_, int W_> struct Geo {
@@ -282,32 +284,6 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
 // shifted) is recomputed where the d(shift) sums use it -- a lane needs x only at its OWN pair --, d(x) leaves masked by the
 // ReLU (= d(bn2's output), what k_bn_bwd_dx_pre expects), and bn2's two reduction sums (sum dz, sum dz zhat) ride along as
 // partials 2 and 3: [C][4][P]; the finalizer also writes k12 / d(gamma) / d(beta).
-struct BnFuse2 {
-    const float4* abmi;           // [C] (a, b, mean, invstd)
-    float* k12;                   // [2][C]
-    float* dgamma; float* dbeta;  // [C]
-    float inv_count;              // 1 / (F H W)
-};
-template <typename S>
-__device__ __forceinline__ void finalizer_wave2_bn(const Fin2<S>& fin, int c, int C, int P, const BnFuse2& bn) {
-    double s[4];
-    const bool ok = fin_collect<4>(fin.f, c, P, s);
-    if (threadIdx.x == 0) {
-        const float nanv = __uint_as_float(0x7fc00000u);
-        float gH = (float)s[0], gW = (float)s[1];
-        if (fin.normalize) {
-            const float mag = sqrtf(gH * gH + gW * gW);
-            if (mag > 0) { gH = gH / mag; gW = gW / mag; }
-        }
-        if (!ok) gH = gW = nanv;
-        st(fin.gshift + c, gH);
-        st(fin.gshift + C + c, gW);
-        bn.dbeta[c] = ok ? (float)s[2] : nanv;
-        bn.dgamma[c] = ok ? (float)s[3] : nanv;
-        bn.k12[c] = ok ? (float)(s[2] * (double)bn.inv_count) : nanv;
-        bn.k12[C + c] = ok ? (float)(s[3] * (double)bn.inv_count) : nanv;
-    }
-}
 template <typename T, typename S, int H, int W, int R, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                             const S* __restrict__ shift, T* __restrict__ gx, TDims2 d,

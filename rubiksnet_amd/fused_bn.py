@@ -314,8 +314,11 @@ def bn_relu_shift2d(bn, as3, z):
             or shift.shape != (2, z.shape[1]) or bn.num_features != z.shape[1]):
         return None
     if (getattr(as3, "quantize", False) or getattr(as3, "stride", 1) not in (1, (1, 1)) or getattr(as3, "padding", 0) not in (0, (0, 0))
-            or z.shape[2:] != (14, 14) or z.shape[1] % 2 or z.data_ptr() % 16):
-        return None                  # (the shapes rk2d_*_bn_* take today: 14 x 14 planes, stride 1, pad 0)
+            or z.data_ptr() % 16 or z.numel() >= 1 << 31):
+        return None
+    # (asked BEFORE bn2's statistics run: their side effects -- the running statistics -- must happen exactly once)
+    if not _native.lib().rk2d_bn_fused_shape(z.shape[0], z.shape[1], z.shape[2], z.shape[3], z.element_size()):
+        return None                  # today: 14 x 14 planes (fp32 / bf16), bf16 planes with W % 8 == 0 (56 x 56, 112 x 112)
     z = z.contiguous()
     momentum, counter = _count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None

@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _setup(Fr, C, dtype, kind, seed):
+def _setup(Fr, C, dtype, kind, seed, H=14):
     from rubiksnet_amd.shiftlib import RubiksShift2D
 
     g = torch.Generator(device="cpu").manual_seed(seed)
-    z = (torch.randn(Fr, C, 14, 14, generator=g) * 1.7 + 0.3).to(DEV).to(dtype)
+    z = (torch.randn(Fr, C, H, H, generator=g) * 1.7 + 0.3).to(DEV).to(dtype)
     bn = torch.nn.BatchNorm2d(C).to(DEV).train()
     with torch.no_grad():
         bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
@@ -29,23 +29,25 @@ def _setup(Fr, C, dtype, kind, seed):
             s[1, 1::4] = torch.round(s[1, 1::4] * 1.4)
             s[:, 0] = 0.0
         as3.shift.copy_(s)
-    gy = torch.randn(Fr, C, 14, 14, generator=g).to(DEV).to(dtype)
+    gy = torch.randn(Fr, C, H, H, generator=g).to(DEV).to(dtype)
     return z, bn, as3, gy
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["generic", "integer"])
-@pytest.mark.parametrize("Fr,C", [(8, 6), (256, 288), (13, 34)])
-def test_fused_pair_matches_unfused_pair(Fr, C, dtype, kind):
+@pytest.mark.parametrize("Fr,C,H", [(8, 6, 14), (256, 288, 14), (13, 34, 14), (10, 6, 56), (5, 3, 112), (9, 5, 16), (12, 7, 28), (3, 4, 12)])
+def test_fused_pair_matches_unfused_pair(Fr, C, H, dtype, kind):
     from rubiksnet_amd import fused_bn
 
-    z, bn, as3, gy = _setup(Fr, C, dtype, kind, Fr * 7 + C)
+    if H != 14 and dtype == torch.float32:
+        pytest.skip("the raw-plane / register-staged kernels are the 16-bit families")
+    z, bn, as3, gy = _setup(Fr, C, dtype, kind, Fr * 7 + C, H)
     bn_u, as3_u = copy.deepcopy(bn), copy.deepcopy(as3)
     zf = z.clone().requires_grad_(True)
     zu = z.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
         yf = fused_bn.bn_relu_shift2d(bn, as3, zf)
-        assert yf is not None, "14 x 14 planes must take the fused kernels"
+        assert yf is not None, "14 x 14 planes (and 16-bit planes with W % 8 == 0) must take the fused kernels"
         yu = as3_u(fused_bn.bn_relu(bn_u, zu))
     yf.backward(gy)
     yu.backward(gy)
@@ -90,5 +92,7 @@ def test_other_planes_fall_back():
 
     bn = torch.nn.BatchNorm2d(8).to(DEV).train()
     as3 = RubiksShift2D(8).to(DEV)
-    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 28, 28, device=DEV, requires_grad=True)) is None
+    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 28, 28, device=DEV, requires_grad=True)) is None     # fp32
+    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 7, 7, device=DEV).bfloat16().requires_grad_(True)) is None
+    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 56, 56, device=DEV, requires_grad=True)) is None     # fp32: 14 x 14 only
     assert fused_bn.bn_relu_shift2d(bn.eval(), as3, torch.randn(4, 8, 14, 14, device=DEV, requires_grad=True)) is None
