@@ -182,11 +182,13 @@ size_t rk2d_backward_workspace_bytes(int N, int C, int H, int W,
  *             bn2's backward constants k12 [2][C] = (sum dz, sum dz zhat) / count, d(gamma), d(beta): what
  *             rk_bn_bwd_dx_pre_* needs to finish bn2's d(x) in one pass.  abmi [C][4] = (a, b, mean, invstd).
  * Shift table and d(shift) in fp32 (as rk2d_*_sf32).  RK_ERR_UNSUPPORTED (nothing launched) when no fused kernel takes the
- * configuration -- today stride 1, pad 0, quantize off on 14 x 14 planes (fp32 / bf16) and on bf16 planes with W % 8 == 0
- * (56 x 56, 112 x 112: the raw-plane kernels); the caller then normalises with
- * rk_bn_apply_affine_* and calls the plain entry points. */
-/* 1 when a fused kernel takes this shape (stride 1, pad 0) at this storage size (4 = fp32, 2 = bf16), else 0 */
-int rk2d_bn_fused_shape(int N, int C, int H, int W, int elem_size);
+ * configuration: quantize on, or fp32 planes the LDS-DMA kernels stream (stride 1, pad 0, W % 4 == 0 other than 14 x 14 --
+ * normalise pass + streaming kernel is the faster pair there), or a shape only the column kernels take with RK_COLUMN=0;
+ * the caller then normalises with rk_bn_apply_affine_* and calls the plain entry points.  Fused today: 14 x 14 planes
+ * (fp32 / bf16), bf16 56 x 56 / 112 x 112 (raw-plane kernels), bf16 28 x 28 (register-staged), and every other stride /
+ * padding / plane through the column kernels (the stride-2 layers, 7 x 7). */
+/* 1 when a fused kernel takes this configuration at this storage size (4 = fp32, 2 = bf16), else 0 */
+int rk2d_bn_fused_shape(int N, int C, int H, int W, int sH, int sW, int pH, int pW, int elem_size);
 size_t rk2d_backward_bn_workspace_bytes(int N, int C, int H, int W, int stride_H, int stride_W, int pad_H, int pad_W);
 int rk2d_forward_bn_f32(const float* z, const float* ab, const float* shift, float* y, int N, int C, int H, int W,
                         int stride_H, int stride_W, int pad_H, int pad_W, int quantize, rk_stream_t stream);

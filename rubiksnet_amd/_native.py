@@ -36,7 +36,7 @@ SIGNATURES = {
     "rk3d_backward_finalize_f32": (_i, [_p, _i, _i, _p, _i, ctypes.c_float, _p]),
     "rk2d_backward_workspace_bytes": (_sz, _DIMS2 + [_i]),
     "rk2d_backward_bn_workspace_bytes": (_sz, _DIMS2),
-    "rk2d_bn_fused_shape": (_i, [_i, _i, _i, _i, _i]),
+    "rk2d_bn_fused_shape": (_i, [_i] * 9),
     "rk2d_forward_bn_f32": (_i, [_p] * 4 + _DIMS2 + [_i, _p]),
     "rk2d_forward_bn_bf16_sf32": (_i, [_p] * 4 + _DIMS2 + [_i, _p]),
     "rk2d_backward_bn_f32": (_i, [_p] * 9 + _DIMS2 + [_i, _i, _p, _sz, _p]),

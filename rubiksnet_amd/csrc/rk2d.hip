@@ -158,8 +158,18 @@ int backward2(const void* gy_, const void* x_, const void* shift_, void* gx_, vo
 
 // ---- training fusion (round 5): the shift applied to relu(bn2(z)) without the activation ever being stored
 // (fused_bn.bn_relu_shift2d; backbone.py:129-131 under models.py:71-79's 2-D variant).  RK_ERR_UNSUPPORTED (nothing launched) when
-// no fused kernel covers the configuration (today: 14 x 14 planes, stride 1, pad 0, no quantize); the caller then normalises
+// no fused kernel covers the configuration (quantize; column kernels switched off and a shape the streaming kernels do not take); the caller then normalises
 // with rk_bn_apply_affine_* and calls the plain entry points.
+// the column kernels' fused variants take what no streaming kernel does (fp32 planes the LDS-DMA kernels stream keep the
+// normalise pass + those kernels: they are the faster pair there)
+static bool col_bn_takes(const Dims2& d, int elem_size) {
+    if (!col2d::supported(0)) return false;
+    if (elem_size == 4) {
+        dma2d::FDims f;
+        if (dma2d::make_fdims(f, d, dma2d::kFramesF32, true) && bwd_ring_bytes(f.b, 1, 1) <= 64 * 1024) return false;
+    }
+    return true;
+}
 template <typename T>
 static int forward2_bn(const void* z, const float* ab, const float* shift, void* y, int N, int C, int H, int W, int sH, int sW,
                        int pH, int pW, int quantize, rk_stream_t stream) {
@@ -171,6 +181,10 @@ static int forward2_bn(const void* z, const float* ab, const float* shift, void*
     if constexpr (sizeof(T) == 2) {                                  // raw 16-bit planes: 56 x 56, 112 x 112
         if (raw16::launch_forward2_bn<T, float>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream)) return launch_status();
         if (stage2d::launch_forward2_bn<T, float>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream)) return launch_status();   // 28 x 28
+    }
+    if (col_bn_takes(d, (int)sizeof(T))) {                           // the strided layers and the 7 x 7 planes
+        col2d::launch_forward_bn<T>((const T*)z, ab, shift, (T*)y, d, (hipStream_t)stream);
+        return launch_status();
     }
     return RK_ERR_UNSUPPORTED;
 }
@@ -197,6 +211,13 @@ static int backward2_bn(const void* gy, const void* z, const float* abmi, const 
         if (stage2d::launch_backward2_bn<T, float>((const T*)gy, (const T*)z, shift, (T*)dz, gshift, ws, normalize_grad, bn, d,
                                                    (hipStream_t)stream))
             return launch_status();
+    }
+    if (col_bn_takes(d, (int)sizeof(T))) {
+        const int P = col2d::launch_backward_bn<T>((const T*)gy, (const T*)z, shift, (T*)dz, (float*)ws, bn.abmi, d,
+                                                   (hipStream_t)stream);
+        hipLaunchKernelGGL(col2d::k2d_finalize_bn, dim3(C), dim3(finalize_block(P)), 0, (hipStream_t)stream, (const float*)ws,
+                           gshift, k12, dgamma, dbeta, C, P, normalize_grad, bn.inv_count);
+        return launch_status();
     }
     return RK_ERR_UNSUPPORTED;
 }
@@ -249,11 +270,12 @@ RK_DEF_2D_MIXED(bf16, __hip_bfloat16)
 
 // 1 when rk2d_forward_bn_* / rk2d_backward_bn_* have a fused kernel for this shape and storage size (4: fp32, 2: bf16), else 0:
 // lets a caller decide BEFORE it runs bn2's statistics (whose side effects -- running statistics -- must happen once)
-int rk2d_bn_fused_shape(int N, int C, int H, int W, int elem_size) {
+int rk2d_bn_fused_shape(int N, int C, int H, int W, int sH, int sW, int pH, int pW, int elem_size) {
     Dims2 d;
-    if (make_dims2(d, N, C, H, W, 1, 1, 0, 0)) return 0;
+    if (make_dims2(d, N, C, H, W, sH, sW, pH, pW)) return 0;
+    if (elem_size != 4 && elem_size != 2) return 0;
+    if (col_bn_takes(d, elem_size)) return 1;                       // the column kernels take what the others below do not
     if (elem_size == 4) { tile2d::TDims2 t; return tile2d::make_tdims<float, 14, 14>(t, d) ? 1 : 0; }
-    if (elem_size != 2) return 0;
     tile2d::TDims2 t;
     if (tile2d::make_tdims<__hip_bfloat16, 14, 14>(t, d)) return 1;
     dma2d::FDims f;

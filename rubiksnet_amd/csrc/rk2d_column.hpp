@@ -50,17 +50,28 @@ __device__ __forceinline__ Col2Id my_column2(const C2Dims& cd, int& e) {
 
 template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
 
+// training fusion (bn2 + ReLU inside the shift, fused_bn.bn_relu_shift2d): the value the unfused path would have stored
+// -- rounded to the storage type -- so that both paths see the same activation
+template <typename T> __device__ __forceinline__ float as_stored(float v) { T t; st(&t, v); return ld(&t); }
+template <typename T> __device__ __forceinline__ float bn_relu_of(float z, float a, float b) {
+    return as_stored<T>(fmaxf(fmaf(a, z, b), 0.f));
+}
+
 // ------------------------------------------------------------------------------------ forward
 // VEC (kM == 4, output planes of a multiple of 4 elements, aligned y): a thread owns 4 CONSECUTIVE outputs and stores
 // them as one 8- / 16-byte access; frames are taken in batches, every tap of a batch requested before the first is used.
-template <typename T, typename S, int kM, bool VEC = false>
+// BN: x holds z (bn2's input) and every tap is relu(a z + b) (ab = [2][C]), the activation that is never stored.
+template <typename T, typename S, int kM, bool VEC = false, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict__ x, const S* __restrict__ shift,
-                                                             T* __restrict__ y, C2Dims cd) {
+                                                             T* __restrict__ y, C2Dims cd,
+                                                             const float* __restrict__ ab = nullptr) {
     using CT = typename Compute<T>::type;
     const Dims2& d = cd.d;
     int e;
     const Col2Id id = my_column2(cd, e);
     if (!id.valid) return;
+    float bnA = 1.f, bnB = 0.f;
+    if constexpr (BN) { bnA = ab[id.c]; bnB = ab[d.C + id.c]; }
     const CT offH = ld(shift + id.c), offW = ld(shift + d.C + id.c);
     const int iH = floor_fast(offH), iW = floor_fast(offW);
     const CT rH = offH - (CT)iH, rW = offW - (CT)iW;
@@ -103,8 +114,13 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
 #pragma unroll
         for (int m = 0; m < kM; ++m) {
             const unsigned mk = mask[m];
-            const CT p00 = (mk & 1u) ? f.q[m][0] : (CT)0, p01 = (mk & 2u) ? f.q[m][1] : (CT)0;
-            const CT p10 = (mk & 4u) ? f.q[m][2] : (CT)0, p11 = (mk & 8u) ? f.q[m][3] : (CT)0;
+            CT t0 = f.q[m][0], t1 = f.q[m][1], t2 = f.q[m][2], t3 = f.q[m][3];
+            if constexpr (BN) {
+                t0 = bn_relu_of<T>(t0, bnA, bnB); t1 = bn_relu_of<T>(t1, bnA, bnB);
+                t2 = bn_relu_of<T>(t2, bnA, bnB); t3 = bn_relu_of<T>(t3, bnA, bnB);
+            }
+            const CT p00 = (mk & 1u) ? t0 : (CT)0, p01 = (mk & 2u) ? t1 : (CT)0;
+            const CT p10 = (mk & 4u) ? t2 : (CT)0, p11 = (mk & 8u) ? t3 : (CT)0;
             const CT v = interp2d(p00, p01, p10, p11, rH, rW);
             if constexpr (VEC) st(&oq.v[m & 3], v);
             else if (oidx[m] >= 0) st(out + oidx[m], v);
@@ -138,27 +154,47 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
 // 16-byte (fp32) access per thread and frame instead of four 2- / 4-byte ones; the gy taps stay scalar (L1-served).
 // Frames are taken four at a time, every load of the four requested before the first is used.  Same arithmetic per
 // element, bit-identical.
-template <typename T, typename S, int kM, bool SINGLE, bool VEC = false>
+// BN (training fusion): x holds z = bn2's input.  d(shift) uses the recomputed activation relu(a z + b); what is stored is
+// d(bn2's output) = d(activation) masked by the ReLU (rounded to the storage type first, as the unfused path stores it), and
+// BatchNorm's two reduction sums over it (sum dz, sum dz (z - mean) invstd) leave as partials 2 and 3: part[c][4][P].
+template <typename T, typename S, int kM, bool SINGLE, bool VEC = false, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restrict__ gy, const T* __restrict__ x,
-                                                              const S* __restrict__ shift, T* __restrict__ gx,
+                                                              const S* __restrict__ shift, T* gx,
                                                               typename Compute<T>::type* __restrict__ part,
-                                                              C2Dims cd) {
+                                                              C2Dims cd, const float4* __restrict__ abmi = nullptr) {
     using CT = typename Compute<T>::type;
-    __shared__ CT red[2][kBlock / kWave];
+    constexpr int ND = BN ? 4 : 2;
+    __shared__ CT red[ND][kBlock / kWave];
     const Dims2& d = cd.d;
     int e;
     const Col2Id id = my_column2(cd, e);
-    CT accH = 0, accW = 0;
+    CT accH = 0, accW = 0, accB1 = 0, accB2 = 0;
     if (id.valid) {
         const CT s0 = ld(shift + id.c), s1 = ld(shift + d.C + id.c);
         const int f0 = id.g * cd.FG, nf = min(cd.FG, d.N - f0);
         const CT u0 = s0 - (CT)floor_fast(s0), u1 = s1 - (CT)floor_fast(s1);
+        float4 bnp = make_float4(1.f, 0.f, 0.f, 1.f);
+        if constexpr (BN) bnp = abmi[id.c];
         if (u0 < (CT)1e-7f || u1 < (CT)1e-7f) {
             // central-difference branch: the reference's per-element formulation; chunk 0 does the whole planes
             if (id.chunk == 0)
                 for (int k = 0; k < nf; ++k) {
                     backward_input_plane2<T, false>(gy, shift, gx, d, f0 + k, id.c, e, cd.E);
-                    shift_grad_plane2<T>(gy, x, shift, d, f0 + k, id.c, e, cd.E, accH, accW);
+                    if constexpr (BN) {
+                        shift_grad_plane2<T>(gy, x, shift, d, f0 + k, id.c, e, cd.E, accH, accW,
+                                             [&](CT z) { return (CT)bn_relu_of<T>((float)z, bnp.x, bnp.y); });
+                        // mask what this thread just stored (the same elements: e, e + E, ...) and take bn2's sums
+                        const size_t pl = ((size_t)(f0 + k) * d.C + id.c) * (d.H * d.W);
+                        for (int i = e; i < d.H * d.W; i += cd.E) {
+                            const float z = (float)ld(x + pl + i);
+                            const float g = bn_relu_of<T>(z, bnp.x, bnp.y) > 0.f ? (float)ld(gx + pl + i) : 0.f;
+                            st(gx + pl + i, (CT)g);
+                            accB1 += g;
+                            accB2 = fmaf(g, (z - bnp.z) * bnp.w, accB2);
+                        }
+                    } else {
+                        shift_grad_plane2<T>(gy, x, shift, d, f0 + k, id.c, e, cd.E, accH, accW);
+                    }
                 }
         } else {
             const CT nH = -s0, nW = -s1;
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                     tap[m][SINGLE ? 0 : 3] = (live && r1 >= 0 && c1 >= 0) ? r1 * d.Wo + c1 : -1;
                 }
             }
-            CT sH = 0, sW = 0;
+            CT sH = 0, sW = 0, sB1 = 0, sB2 = 0;
             constexpr int NTAP = SINGLE ? 1 : 4;
             struct Frame { CT xv[kM]; CT q[kM][NTAP]; };
             auto load_frame = [&](int k, Frame& f) {                          // addresses clamped into the plane, values masked at use
@@ -217,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                 Quad<T> oq;
 #pragma unroll
                 for (int m = 0; m < kM; ++m) {
-                    const CT xv = iidx[m] >= 0 ? f.xv[m] : (CT)0;
+                    CT xv = iidx[m] >= 0 ? f.xv[m] : (CT)0;
+                    if constexpr (BN) xv = iidx[m] >= 0 ? (CT)bn_relu_of<T>((float)f.xv[m], bnp.x, bnp.y) : (CT)0;
                     CT Q, QH, QW;
                     if (SINGLE) {
                         const CT v = tap[m][0] >= 0 ? f.q[m][0] : (CT)0;
@@ -236,6 +273,11 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                     }
                     sH += QH * xv;
                     sW += QW * xv;
+                    if constexpr (BN) {
+                        Q = xv > 0 ? (CT)as_stored<T>((float)Q) : (CT)0;
+                        sB1 += Q;
+                        sB2 = fmaf((float)Q, ((float)f.xv[m] - bnp.z) * bnp.w, (float)sB2);
+                    }
                     if constexpr (VEC) st(&oq.v[m & 3], Q);
                     else if (iidx[m] >= 0) st(out + iidx[m], Q);
                 }
@@ -261,16 +303,49 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                 load_frame(k, f);
                 use_frame(k, f);
             }
-            accH = sH; accW = sW;
+            accH = sH; accW = sW; accB1 = sB1; accB2 = sB2;
         }
     }
     accH = group_sum(accH, cd.E, red[0]);
     accW = group_sum(accW, cd.E, red[1]);
+    if constexpr (BN) {
+        accB1 = group_sum(accB1, cd.E, red[ND - 2]);
+        accB2 = group_sum(accB2, cd.E, red[ND - 1]);
+    }
     if (id.valid && e == 0) {
         const int P = cd.ngroups * cd.nchunks;
-        CT* o = part + (size_t)id.c * 2 * P + (size_t)id.g * cd.nchunks + id.chunk;
+        CT* o = part + (size_t)id.c * ND * P + (size_t)id.g * cd.nchunks + id.chunk;
         o[0] = accH;
         o[P] = accW;
+        if constexpr (BN) { o[2 * (size_t)P] = accB1; o[3 * (size_t)P] = accB2; }
+    }
+}
+
+// row-sum + K9 (as k2d_finalize) + bn2's constants from partials 2 and 3: d(beta), d(gamma) and the two means
+// rk_bn_bwd_dx_pre_* takes (k12 = [2][C])
+__global__ __launch_bounds__(kBlock) void k2d_finalize_bn(const float* __restrict__ part, float* __restrict__ gshift,
+                                                          float* __restrict__ k12, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int C, int P, int normalize,
+                                                          float inv_count) {
+    __shared__ double red[4][kBlock / kWave];
+    const int c = blockIdx.x;
+    const float* p = part + (size_t)c * 4 * P;
+    double s[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k)
+        for (int i = threadIdx.x; i < P; i += blockDim.x) s[k] += (double)p[(size_t)k * P + i];
+    for (int k = 0; k < 4; ++k) s[k] = group_sum(s[k], (int)blockDim.x, red[k]);
+    if (threadIdx.x == 0) {
+        float gH = (float)s[0], gW = (float)s[1];
+        if (normalize) {
+            const float mag = sqrtf(gH * gH + gW * gW);
+            if (mag > 0) { gH = gH / mag; gW = gW / mag; }
+        }
+        gshift[c] = gH;
+        gshift[C + c] = gW;
+        dbeta[c] = (float)s[2];
+        dgamma[c] = (float)s[3];
+        k12[c] = (float)(s[2] * (double)inv_count);
+        k12[C + c] = (float)(s[3] * (double)inv_count);
     }
 }
 
@@ -313,6 +388,21 @@ inline void launch_forward(const T* x, const S* shift, T* y, const Dims2& d, hip
         hipLaunchKernelGGL((k2d_forward_column<T, S, 4>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, x, shift, y, cd);
 }
 
+template <typename T>
+inline void launch_forward_bn(const T* z, const float* ab, const float* shift, T* y, const Dims2& d, hipStream_t stream) {
+    const C2Dims cd = make_c2dims(d, d.Ho * d.Wo);
+    const bool vec = cd.M == 4 && (d.Ho * d.Wo) % 4 == 0 && ((uintptr_t)y & 15) == 0;
+    if (cd.M == 1)
+        hipLaunchKernelGGL((k2d_forward_column<T, float, 1, false, true>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, z, shift,
+                           y, cd, ab);
+    else if (vec)
+        hipLaunchKernelGGL((k2d_forward_column<T, float, 4, true, true>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, z, shift,
+                           y, cd, ab);
+    else
+        hipLaunchKernelGGL((k2d_forward_column<T, float, 4, false, true>), dim3(grid_of(cd)), dim3(kBlock), 0, stream, z, shift,
+                           y, cd, ab);
+}
+
 inline int backward_partials(const Dims2& d) {
     const C2Dims cd = make_c2dims(d, d.H * d.W);
     return cd.ngroups * cd.nchunks;
@@ -327,6 +417,22 @@ inline int launch_backward(const T* gy, const T* x, const S* shift, T* gx, typen
     const bool vec = cd.M == 4 && (d.H * d.W) % 4 == 0 && (((uintptr_t)x | (uintptr_t)gx) & 15) == 0;
 #define RK_C2_BWD(MM, SG, VC) hipLaunchKernelGGL((k2d_backward_column<T, S, MM, SG, VC>), dim3(grid_of(cd)), dim3(kBlock), 0, \
                                                  stream, gy, x, shift, gx, ws, cd)
+    if (cd.M == 1) { if (single) RK_C2_BWD(1, true, false); else RK_C2_BWD(1, false, false); }
+    else if (vec) { if (single) RK_C2_BWD(4, true, true); else RK_C2_BWD(4, false, true); }
+    else { if (single) RK_C2_BWD(4, true, false); else RK_C2_BWD(4, false, false); }
+#undef RK_C2_BWD
+    return cd.ngroups * cd.nchunks;
+}
+
+// the training fusion: d(bn2's output) + d(shift) + bn2's sums into ws[C][4][P]; returns P
+template <typename T>
+inline int launch_backward_bn(const T* gy, const T* z, const float* shift, T* dz, float* ws, const float4* abmi,
+                              const Dims2& d, hipStream_t stream) {
+    const C2Dims cd = make_c2dims(d, d.H * d.W);
+    const bool single = d.sH >= 2 && d.sW >= 2;
+    const bool vec = cd.M == 4 && (d.H * d.W) % 4 == 0 && (((uintptr_t)z | (uintptr_t)dz) & 15) == 0;
+#define RK_C2_BWD(MM, SG, VC) hipLaunchKernelGGL((k2d_backward_column<T, float, MM, SG, VC, true>), dim3(grid_of(cd)), \
+                                                 dim3(kBlock), 0, stream, gy, z, shift, dz, ws, cd, abmi)
     if (cd.M == 1) { if (single) RK_C2_BWD(1, true, false); else RK_C2_BWD(1, false, false); }
     else if (vec) { if (single) RK_C2_BWD(4, true, true); else RK_C2_BWD(4, false, true); }
     else { if (single) RK_C2_BWD(4, true, false); else RK_C2_BWD(4, false, false); }

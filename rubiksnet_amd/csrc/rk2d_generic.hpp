@@ -115,11 +115,13 @@ __global__ __launch_bounds__(kBlock) void k2d_forward(const T* __restrict__ x, c
 
 // ------------------------------------------------------------------------------ K7
 // this thread's share of the d(shift) terms of one (n, c) plane (E cooperating threads)
-template <typename T, typename S>
+// act: what an element of x stands for (identity; the training fusion passes relu(bn2(.)), rk2d_column.hpp)
+struct SameValue { template <typename V> __device__ __forceinline__ V operator()(V v) const { return v; } };
+template <typename T, typename S, typename Act = SameValue>
 __device__ __forceinline__ void shift_grad_plane2(const T* __restrict__ gy, const T* __restrict__ x,
                                                   const S* __restrict__ shift, const Dims2& d, int n, int c, int e,
                                                   int E, typename Compute<T>::type& aH,
-                                                  typename Compute<T>::type& aW) {
+                                                  typename Compute<T>::type& aW, Act act = Act()) {
     using CT = typename Compute<T>::type;
     const CT offH = ld(shift + c), offW = ld(shift + d.C + c);
     const int iH = floor_fast(offH), iW = floor_fast(offW);
@@ -134,7 +136,7 @@ __device__ __forceinline__ void shift_grad_plane2(const T* __restrict__ gy, cons
     int ho = e / d.Wo, wo = e - ho * d.Wo;
     const int dh = E / d.Wo, dw = E - dh * d.Wo;
     auto at = [&](int h, int w) -> CT {
-        return (h >= 0 && h < d.H && w >= 0 && w < d.W) ? ld(xp + h * d.W + w) : (CT)0;
+        return (h >= 0 && h < d.H && w >= 0 && w < d.W) ? act(ld(xp + h * d.W + w)) : (CT)0;
     };
     for (int i = e; i < HWo; i += E) {
         const int h0 = ho * d.sH - d.pH + iH, w0 = wo * d.sW - d.pW + iW;

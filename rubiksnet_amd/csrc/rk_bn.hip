@@ -616,6 +616,78 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre_flat(const T* __restri
     }
 }
 
+// 16-bit storage: the same sweep with 16-BYTE cells (8 elements per lane; the 4-element form above moves 8 bytes per lane and
+// access, and measured ~2/3 of the per-channel k_bn_bwd_dx's rate on the same tensors -- it is the largest kernel of the bf16 -aq
+// train step).  P % 4 == 0, so a cell's two halves may sit in two planes (14 x 14: 196 = 4 * 49): each half looks its plane up.
+typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kFlat16Elems = 8192;
+inline bool flat16_on() {                                   // RK_BN_FLAT16=0: the 4-element sweep for 16-bit storage too
+    static const bool on = [] { const char* e = getenv("RK_BN_FLAT16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+__device__ __forceinline__ void flat16_unpack(const bn_u32x4& r, float (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(r[q] << 16); v[2 * q + 1] = __uint_as_float(r[q] & 0xffff0000u); }
+}
+template <bool NT> __device__ __forceinline__ bn_u32x4 flat16_load(const void* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const bn_u32x4*>(p));
+    else return *reinterpret_cast<const bn_u32x4*>(p);
+}
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_dx_pre_flat16(const __hip_bfloat16* __restrict__ dz,
+                                                                 const __hip_bfloat16* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                                 const float* __restrict__ save_invstd, const float* __restrict__ k12,
+                                                                 const __hip_bfloat16* __restrict__ skip, __hip_bfloat16* __restrict__ dx,
+                                                                 int C, int P, long long total) {
+    __shared__ float4 coef[kFlatPlanes + 2];               // (mean, invstd, a, k1) ... and k2 in a second table
+    __shared__ float coef2[kFlatPlanes + 2];
+    using B = Pack<__hip_bfloat16, 4>;
+    const long long e0 = (long long)blockIdx.x * kFlat16Elems;
+    const long long plane0 = e0 / P;
+    long long eend = e0 + kFlat16Elems;
+    eend = eend < total ? eend : total;
+    const int nplanes = (int)((eend - 1) / P - plane0) + 1;
+    for (int i = threadIdx.x; i < nplanes; i += kBlock) {
+        const int c = (int)((plane0 + i) % C);
+        const float invstd = save_invstd[c];
+        coef[i] = make_float4(save_mean[c], invstd, gamma[c] * invstd, k12[c]);
+        coef2[i] = k12[C + c];
+    }
+    __syncthreads();
+    const int r0 = (int)(e0 - plane0 * P);
+#pragma unroll 4
+    for (int u = 0; u < kFlat16Elems / (8 * kBlock); ++u) {
+        const int rel = 8 * ((int)threadIdx.x + kBlock * u);
+        const long long e = e0 + rel;
+        if (e >= eend) break;                               // (total % 8 == 0: a cell is whole)
+        const int la = (r0 + rel) / P, lb = (r0 + rel + 4) / P;
+        float xv[8], gv[8];
+        flat16_unpack(flat16_load<(RK_BNF_NT & 2) != 0>(x + e), xv);
+        flat16_unpack(flat16_load<(RK_BNF_NT & 1) != 0>(dz + e), gv);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 cf = coef[h ? lb : la];
+            const float k2 = coef2[h ? lb : la];
+#pragma unroll
+            for (int q = 4 * h; q < 4 * h + 4; ++q) {
+                const float xh = (xv[q] - cf.x) * cf.y;
+                gv[q] = cf.z * (gv[q] - cf.w - xh * k2);
+            }
+        }
+        if (skip) {
+            float sv[8];
+            flat16_unpack(flat16_load<(RK_BNF_NT & 1) != 0>(skip + e), sv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gv[q] += sv[q];
+        }
+        bn_u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = B::bits(gv[2 * q]) | (B::bits(gv[2 * q + 1]) << 16);
+        if constexpr ((RK_BNF_NT & 4) != 0) __builtin_nontemporal_store(o, reinterpret_cast<bn_u32x4*>(dx + e));
+        else *reinterpret_cast<bn_u32x4*>(dx + e) = o;
+    }
+}
+
 template <typename T>
 int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save_mean, const float* save_invstd,
                   const float* k12, const T* skip, T* dx, int F, int C, int P, rk_stream_t stream) {
@@ -625,6 +697,14 @@ int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save
     const dim3 grid(grid_bn(d)), block(kBlock);
     const bool v4 = vec4_ok<T>(d, x, dz, dx) && !((uintptr_t)skip & (4 * sizeof(T) - 1));
     const long long total = (long long)F * C * P;
+    if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+        if (v4 && total % 8 == 0 && kFlat16Elems / P + 2 <= kFlatPlanes &&
+            !(((uintptr_t)dz | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)skip) & 15) && flat16_on()) {
+            hipLaunchKernelGGL(k_bn_bwd_dx_pre_flat16, dim3((unsigned)((total + kFlat16Elems - 1) / kFlat16Elems)), block, 0,
+                               (hipStream_t)stream, dz, x, gamma, save_mean, save_invstd, k12, skip, dx, C, P, total);
+            return launch_status();
+        }
+    }
     if (v4 && kFlatElems / P + 2 <= kFlatPlanes) {
         hipLaunchKernelGGL((k_bn_bwd_dx_pre_flat<T>), dim3((unsigned)((total + kFlatElems - 1) / kFlatElems)), block, 0,
                            (hipStream_t)stream, dz, x, gamma, save_mean, save_invstd, k12, skip, dx, C, P, total);

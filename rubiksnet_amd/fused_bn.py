@@ -243,13 +243,16 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
     _SHIFT_SFX = {torch.float32: "f32", torch.bfloat16: "bf16_sf32"}
 
     @staticmethod
-    def forward(ctx, z, weight, bias, shift, running_mean, running_var, momentum, eps, counter_ptr, normalize_grad, stats=None):
+    def forward(ctx, z, weight, bias, shift, running_mean, running_var, momentum, eps, counter_ptr, normalize_grad, stats=None,
+                stride=(1, 1), padding=(0, 0)):
         L = _native.lib()
         Fr, C, H, W = z.shape
         P = H * W
         dev = z.device
         sfx = _SFX[z.dtype]
-        y = torch.empty_like(z)
+        (sH, sW), (pH, pW) = stride, padding
+        # (rubiks.cpp:18's output size, not the convolution formula)
+        y = torch.empty((Fr, C, (H + 2 * pH - 1) // sH + 1, (W + 2 * pW - 1) // sW + 1), dtype=z.dtype, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if stats is not None:
@@ -266,10 +269,11 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
                     save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(),
                     nbytes, stream), "rk_bn_stats_finish")
             rc = getattr(L, "rk2d_forward_bn_" + _BNReLUShift2DTrain._SHIFT_SFX[z.dtype])(
-                z.data_ptr(), ab.data_ptr(), shift.data_ptr(), y.data_ptr(), Fr, C, H, W, 1, 1, 0, 0, 0, stream)
+                z.data_ptr(), ab.data_ptr(), shift.data_ptr(), y.data_ptr(), Fr, C, H, W, sH, sW, pH, pW, 0, stream)
         _native.check(rc, "rk2d_forward_bn")
         ctx.save_for_backward(z, weight, bias, shift, save_mean, save_invstd, ab)
         ctx.normalize_grad = bool(normalize_grad)
+        ctx.geometry = (sH, sW, pH, pW)
         return y
 
     @staticmethod
@@ -289,18 +293,26 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         abmi = torch.stack((ab[0], ab[1], save_mean, save_invstd), dim=1).contiguous()       # [C][4]
+        sH, sW, pH, pW = ctx.geometry
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            nb = int(L.rk2d_backward_bn_workspace_bytes(Fr, C, H, W, 1, 1, 0, 0))
+            nb = int(L.rk2d_backward_bn_workspace_bytes(Fr, C, H, W, sH, sW, pH, pW))
             ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
             _native.check(getattr(L, "rk2d_backward_bn_" + _BNReLUShift2DTrain._SHIFT_SFX[z.dtype])(
                 gy.data_ptr(), z.data_ptr(), abmi.data_ptr(), shift.data_ptr(), dz.data_ptr(), gshift.data_ptr(), k12.data_ptr(),
-                dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, H, W, 1, 1, 0, 0, int(ctx.normalize_grad), 0, ws.data_ptr(), nb,
+                dgamma.data_ptr(), dbeta.data_ptr(), Fr, C, H, W, sH, sW, pH, pW, int(ctx.normalize_grad), 0, ws.data_ptr(), nb,
                 stream), "rk2d_backward_bn")
             _native.check(getattr(L, "rk_bn_bwd_dx_pre_" + sfx)(
                 dz.data_ptr(), z.data_ptr(), weight.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), k12.data_ptr(),
                 None, dz.data_ptr(), Fr, C, P, stream), "rk_bn_bwd_dx_pre")                       # in place: dz -> d(z)
-        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gshift, None, None, None, None, None, None, None)
+        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gshift) + (None,) * 9
+
+
+def _pair(v):
+    if isinstance(v, int):
+        return (v, v)
+    v = tuple(int(k) for k in v)
+    return v if len(v) == 2 else None
 
 
 def bn_relu_shift2d(bn, as3, z):
@@ -313,18 +325,20 @@ def bn_relu_shift2d(bn, as3, z):
     if (shift is None or not shift.is_cuda or shift.dtype != torch.float32 or shift.dim() != 2
             or shift.shape != (2, z.shape[1]) or bn.num_features != z.shape[1]):
         return None
-    if (getattr(as3, "quantize", False) or getattr(as3, "stride", 1) not in (1, (1, 1)) or getattr(as3, "padding", 0) not in (0, (0, 0))
+    stride, padding = _pair(getattr(as3, "stride", 1)), _pair(getattr(as3, "padding", 0))
+    if (getattr(as3, "quantize", False) or stride is None or padding is None or min(stride) < 1 or min(padding) < 0
             or z.data_ptr() % 16 or z.numel() >= 1 << 31):
         return None
     # (asked BEFORE bn2's statistics run: their side effects -- the running statistics -- must happen exactly once)
-    if not _native.lib().rk2d_bn_fused_shape(z.shape[0], z.shape[1], z.shape[2], z.shape[3], z.element_size()):
-        return None                  # today: 14 x 14 planes (fp32 / bf16), bf16 planes with W % 8 == 0 (56 x 56, 112 x 112)
+    if not _native.lib().rk2d_bn_fused_shape(z.shape[0], z.shape[1], z.shape[2], z.shape[3], stride[0], stride[1], padding[0],
+                                             padding[1], z.element_size()):
+        return None                  # (fp32 planes the LDS-DMA kernels stream keep normalise + shift)
     z = z.contiguous()
     momentum, counter = _count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BNReLUShift2DTrain.apply(z, bn.weight, bn.bias, shift, rm, rv, momentum, bn.eps, _ptr(counter),
-                                     bool(getattr(as3, "normalize_grad", True)), take_stats(z))
+                                     bool(getattr(as3, "normalize_grad", True)), take_stats(z), stride, padding)
 
 
 def _eval_forward(x, weight, bias, running_mean, running_var, eps, relu):

@@ -254,3 +254,58 @@ def test_bn_relu_temporal_filter_randomised_shapes():
                                ("dbeta", bn.bias.grad, b.grad)):
             np.testing.assert_allclose(got.double().cpu().numpy(), ref.numpy(), rtol=0, atol=bar * max(1e-3, float(ref.abs().max())),
                                        err_msg=tag + " " + name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip", [False, True])
+@pytest.mark.parametrize("inplace", [False, True])
+@pytest.mark.parametrize("shape", [(8, 6, 196), (256, 288, 196), (13, 34, 196), (10, 6, 3136), (3, 5, 784), (7, 3, 12), (5, 2, 8),
+                                   (9, 7, 4), (6, 5, 49), (33, 3, 100)])
+def test_bf16_dx_pass_is_the_fp32_expression_rounded_once(shape, inplace, skip):
+    """rk_bn_bwd_dx_pre_bf16 -- 16-byte cells (k_bn_bwd_dx_pre_flat16: a cell's two halves may sit in two planes, P = 196), the
+    4-element sweep and the per-channel kernel (P % 4 != 0) -- against the same fp32 expression evaluated by PyTorch, element for
+    element: dx = bf16(a (dz - k1 - xhat k2) [+ skip]), a = gamma invstd.  Bit-exact: one fp32 expression, one rounding."""
+    from rubiksnet_amd import _native
+
+    L = _native.lib()
+    Fr, C, P = shape
+    g = torch.Generator(device="cpu").manual_seed(Fr * 31 + C * 7 + P)
+    dz = torch.randn(Fr, C, P, generator=g).cuda().bfloat16()
+    x = (torch.randn(Fr, C, P, generator=g) * 1.3 + 0.2).cuda().bfloat16()
+    sk = torch.randn(Fr, C, P, generator=g).cuda().bfloat16() if skip else None
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    mean, invstd = (torch.randn(C, generator=g) * 0.2).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    k12 = (torch.randn(2, C, generator=g) * 0.05).cuda()
+    v = lambda t: t.view(1, C, 1)
+    xh = (x.float() - v(mean)) * v(invstd)
+    # the kernel's order of operations, fp32 without contraction (torch evaluates each op separately)
+    ref = v(gamma * invstd) * (dz.float() - v(k12[0]) - xh * v(k12[1]))
+    if skip:
+        ref = ref + sk.float()
+    ref = ref.bfloat16()
+    out = dz.clone() if inplace else torch.empty_like(dz)
+    src = out if inplace else dz
+    _native.check(L.rk_bn_bwd_dx_pre_bf16(src.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                          k12.data_ptr(), sk.data_ptr() if skip else None, out.data_ptr(), Fr, C, P,
+                                          torch.cuda.current_stream().cuda_stream), "dx_pre")
+    torch.cuda.synchronize()
+    # (fma contraction inside the kernel may differ from torch's separate ops by an fp32 ulp before the bf16 rounding: allow one
+    # bf16 ulp on the few elements that sit on a rounding boundary)
+    a, b = out.float(), ref.float()
+    ulp = torch.maximum(b.abs(), torch.tensor(1e-30, device=b.device)) * 2.0 ** -7
+    assert bool(((a - b).abs() <= ulp).all())
+    assert float((a != b).float().mean()) < 2e-3
+
+    # the element-at-a-time per-channel kernel (what buffers off 8-byte alignment get) writes the same bits
+    def off(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        buf[1:].copy_(t.reshape(-1))
+        return buf[1:].view_as(t)
+    dz1, x1 = off(dz), off(x)
+    sk1 = off(sk) if skip else None
+    out1 = off(torch.zeros_like(dz))
+    _native.check(L.rk_bn_bwd_dx_pre_bf16(dz1.data_ptr(), x1.data_ptr(), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                          k12.data_ptr(), sk1.data_ptr() if skip else None, out1.data_ptr(), Fr, C, P,
+                                          torch.cuda.current_stream().cuda_stream), "dx_pre (unaligned)")
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out)

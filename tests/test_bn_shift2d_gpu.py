@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _setup(Fr, C, dtype, kind, seed, H=14):
+def _setup(Fr, C, dtype, kind, seed, H=14, stride=1, padding=0):
     from rubiksnet_amd.shiftlib import RubiksShift2D
+    from rubiksnet_amd.shiftlib.rubiks2d.primitive import compute_output_shape
 
     g = torch.Generator(device="cpu").manual_seed(seed)
     z = (torch.randn(Fr, C, H, H, generator=g) * 1.7 + 0.3).to(DEV).to(dtype)
@@ -21,7 +22,7 @@ def _setup(Fr, C, dtype, kind, seed, H=14):
     with torch.no_grad():
         bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
         bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
-    as3 = RubiksShift2D(C).to(DEV)
+    as3 = RubiksShift2D(C, stride=stride, padding=padding).to(DEV)
     with torch.no_grad():
         s = torch.rand(2, C, generator=g) * 2 - 1
         if kind == "integer":
@@ -29,25 +30,30 @@ def _setup(Fr, C, dtype, kind, seed, H=14):
             s[1, 1::4] = torch.round(s[1, 1::4] * 1.4)
             s[:, 0] = 0.0
         as3.shift.copy_(s)
-    gy = torch.randn(Fr, C, H, H, generator=g).to(DEV).to(dtype)
+    gy = torch.randn(*compute_output_shape(z, as3.stride, as3.padding), generator=g).to(DEV).to(dtype)
     return z, bn, as3, gy
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["generic", "integer"])
-@pytest.mark.parametrize("Fr,C,H", [(8, 6, 14), (256, 288, 14), (13, 34, 14), (10, 6, 56), (5, 3, 112), (9, 5, 16), (12, 7, 28), (3, 4, 12)])
-def test_fused_pair_matches_unfused_pair(Fr, C, H, dtype, kind):
+@pytest.mark.parametrize("Fr,C,H,stride,padding", [
+    (8, 6, 14, 1, 0), (256, 288, 14, 1, 0), (13, 34, 14, 1, 0), (10, 6, 56, 1, 0), (5, 3, 112, 1, 0), (9, 5, 16, 1, 0),
+    (12, 7, 28, 1, 0), (3, 4, 12, 1, 0),
+    # the column kernels (rk2d_column.hpp): the stride-2 layers of the -aq networks, 7 x 7, odd planes, padding
+    (5, 3, 112, 2, 0), (10, 6, 56, 2, 0), (12, 7, 28, 2, 0), (13, 34, 14, 2, 0), (64, 40, 7, 1, 0), (9, 5, 7, 1, 0),
+    (5, 3, 9, 2, 1), (4, 5, 13, (1, 2), (1, 0)), (6, 4, 30, 1, 1), (7, 3, 15, (2, 1), 0), (33, 2, 5, 3, 2)])
+def test_fused_pair_matches_unfused_pair(Fr, C, H, stride, padding, dtype, kind):
     from rubiksnet_amd import fused_bn
 
-    if H != 14 and dtype == torch.float32:
-        pytest.skip("the raw-plane / register-staged kernels are the 16-bit families")
-    z, bn, as3, gy = _setup(Fr, C, dtype, kind, Fr * 7 + C, H)
+    if H in (56, 112, 16, 28, 12) and (stride, padding) == (1, 0) and dtype == torch.float32:
+        pytest.skip("fp32 planes the LDS-DMA kernels stream keep normalise + shift (test_other_planes_fall_back)")
+    z, bn, as3, gy = _setup(Fr, C, dtype, kind, Fr * 7 + C, H, stride, padding)
     bn_u, as3_u = copy.deepcopy(bn), copy.deepcopy(as3)
     zf = z.clone().requires_grad_(True)
     zu = z.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
         yf = fused_bn.bn_relu_shift2d(bn, as3, zf)
-        assert yf is not None, "14 x 14 planes (and 16-bit planes with W % 8 == 0) must take the fused kernels"
+        assert yf is not None, "this configuration must take a fused kernel"
         yu = as3_u(fused_bn.bn_relu(bn_u, zu))
     yf.backward(gy)
     yu.backward(gy)
@@ -93,6 +99,8 @@ def test_other_planes_fall_back():
     bn = torch.nn.BatchNorm2d(8).to(DEV).train()
     as3 = RubiksShift2D(8).to(DEV)
     assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 28, 28, device=DEV, requires_grad=True)) is None     # fp32
-    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 7, 7, device=DEV).bfloat16().requires_grad_(True)) is None
-    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 56, 56, device=DEV, requires_grad=True)) is None     # fp32: 14 x 14 only
+    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 56, 56, device=DEV, requires_grad=True)) is None     # fp32, streamed
+    asq = RubiksShift2D(8, quantize=True).to(DEV)
+    assert fused_bn.bn_relu_shift2d(bn, asq, torch.randn(4, 8, 14, 14, device=DEV, requires_grad=True)) is None     # quantize
+    assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 14, 14, device=DEV)) is not None
     assert fused_bn.bn_relu_shift2d(bn.eval(), as3, torch.randn(4, 8, 14, 14, device=DEV, requires_grad=True)) is None

@@ -204,10 +204,11 @@ class _Taps:
                 torch.cuda.current_stream().cuda_stream), "apply")
             return out
 
-        def b2fwd(ctx, z, weight, bias, shift, rm, rv, momentum, eps, counter, normalize_grad, stats=None):
-            y = b2f(ctx, z, weight, bias, shift, rm, rv, momentum, eps, counter, normalize_grad, stats)
+        def b2fwd(ctx, z, weight, bias, shift, rm, rv, momentum, eps, counter, normalize_grad, stats=None, stride=(1, 1),
+                  padding=(0, 0)):
+            y = b2f(ctx, z, weight, bias, shift, rm, rv, momentum, eps, counter, normalize_grad, stats, stride, padding)
             taps.calls["f2"] += 1
-            key = (tuple(z.shape), z.dtype)
+            key = (tuple(z.shape), tuple(stride) + tuple(padding), z.dtype)
             if key not in taps.f2_bn:
                 ab = ctx.to_save[6]
                 taps.f2_bn[key] = dict(x=_act2(z, ab).detach().cpu(), shift=shift.detach().cpu(), y=y.detach().cpu())
@@ -215,7 +216,7 @@ class _Taps:
 
         def b2bwd(ctx, gy):
             z, weight, bias, shift, save_mean, save_invstd, ab = ctx.saved_tensors
-            key = (tuple(z.shape), z.dtype)
+            key = (tuple(z.shape), tuple(ctx.geometry), z.dtype)
             first = key not in taps.b2_bn
             rec = None
             if first:
@@ -373,17 +374,23 @@ def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp)
     assert torch.isfinite(loss)
     assert taps.calls == dict(f3=0, b3=0, f2=nblocks, b2=nblocks, fa=nblocks, ba=nblocks)
     st = torch.bfloat16 if amp is not None else torch.float32
-    # (the stride-1 blocks on 14 x 14 planes -- and, in bf16, on 56 x 56 / 112 x 112 -- take the bn2-folded form: f2_bn / b2_bn)
-    assert ({(k[0][1], k[0][2], k[1][0]) for k in taps.f2} | {(k[0][1], k[0][2], 1) for k in taps.f2_bn}) == _expected_shapes(width)
+    # (every block takes the bn2-folded form -- f2_bn / b2_bn -- except, in fp32, the stride-1 planes the LDS-DMA kernels stream:
+    # 112 x 112, 56 x 56, 28 x 28)
+    assert ({(k[0][1], k[0][2], k[1][0]) for k in taps.f2} | {(k[0][1], k[0][2], k[1][0]) for k in taps.f2_bn}) == _expected_shapes(width)
     assert all(k[2] == st and k[0][0] == B * 8 for k in taps.f2) and set(taps.b2) == set(taps.f2)
-    assert len(taps.f2_bn) >= 1 and set(taps.b2_bn) == set(taps.f2_bn) and any(k[0][2:] == (14, 14) for k in taps.f2_bn)
+    assert set(taps.b2_bn) == set(taps.f2_bn) and any(k[0][2:] == (14, 14) for k in taps.f2_bn)
+    assert any(k[1][0] == 2 for k in taps.f2_bn) and any(k[0][2:] == (7, 7) for k in taps.f2_bn)
+    assert all(k[2] == st and k[0][0] == B * 8 for k in taps.f2_bn)
+    if amp is not None:
+        assert not taps.f2                             # bf16: all 51 blocks fused
     for key, r in taps.f2_bn.items():                  # ---- bn2 + ReLU + RubiksShift2D as one operator: "normalise, then shift", bit for bit
-        y_ref = oracle.rk2d_forward(r["x"].float().numpy(), r["shift"].float().numpy(), [1, 1], [0, 0], False)
+        y_ref = oracle.rk2d_forward(r["x"].float().numpy(), r["shift"].float().numpy(), list(key[1][:2]), list(key[1][2:]), False)
         assert torch.equal(r["y"], _rounded(y_ref, st)), "bn2 + 2-D forward %s" % (key,)
     for key, r in taps.b2_bn.items():
         xf, sf, gf = r["x"].float().numpy(), r["shift"].float().numpy(), r["gy"].float().numpy()
-        gx_ref, _ = oracle.rk2d_backward(gf, xf, sf, [1, 1], [0, 0], quantize=False)
-        _, gs_ref = oracle.rk2d_backward(gf.astype(np.float64), xf.astype(np.float64), sf.astype(np.float64), [1, 1], [0, 0],
+        sp, pp = list(key[1][:2]), list(key[1][2:])
+        gx_ref, _ = oracle.rk2d_backward(gf, xf, sf, sp, pp, quantize=False)
+        _, gs_ref = oracle.rk2d_backward(gf.astype(np.float64), xf.astype(np.float64), sf.astype(np.float64), sp, pp,
                                          normalize_grad=True)
         np.testing.assert_allclose(r["gs"].float().numpy(), gs_ref, rtol=0, atol=2e-5, err_msg="bn2 + 2-D d(shift) %s" % (key,))
         # bn2's backward from the oracle's d(x): mask, the two sums, d(z) = gamma invstd (dz - k1 - zhat k2)
