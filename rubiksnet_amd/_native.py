@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librubiks_hip.so")
+# RK_HIP_LIB: another build of the same library (kernel A/B runs of tools/; never a different implementation)
+LIB_PATH = os.environ.get("RK_HIP_LIB") or os.path.join(_HERE, "csrc", "librubiks_hip.so")
 
 _lock = threading.Lock()
 _lib = None

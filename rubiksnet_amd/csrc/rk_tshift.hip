@@ -45,6 +45,52 @@ __device__ __forceinline__ void unpack(const Pack<T, VEC>& q, typename Compute<T
 #pragma unroll
     for (int k = 0; k < VEC; ++k) o[k] = ld(&q.v[k]);
 }
+// Streaming access for the n_segment = 8 path (NT bit 0: loads, bit 1: stores non-temporal: every element is touched
+// once by one thread) and a fence for the register allocator: the packs are converted to fp32 where they are USED.  Left to
+// itself hipcc widens every pack as soon as it lands -- 8 time steps x VEC fp32 values per tensor live at once: the bf16
+// backward took 212 VGPRs (2 waves per SIMD), its bn1-fused form 256 (ONE wave per SIMD, half the plain kernel's rate).
+// Measured (bf16, [256,C,H,H], us, loads+stores / stores only / loads only / neither): forward 112x112 173.7 / 174.6 / 180.4 /
+// 176.6, 28x28 21.9 / 19.0 / 21.4 / 22.7, 14x14 12.9 / 11.2 / 12.6 / 11.9; fused backward 112x112 272 / 278 / 460 / 534, 56x56 73 /
+// 79 / 146 / 165, 28x28 43 / 48 / 93 / 103, 14x14 25.1 / 24.4 / 40.7 / 42.5 -- the forward streams its stores only, the backward both.
+#ifndef RK_TS_NT_FWD
+#define RK_TS_NT_FWD 2
+#endif
+#ifndef RK_TS_NT_BWD
+#define RK_TS_NT_BWD 3
+#endif
+template <int BYTES> struct RawVec { typedef unsigned type __attribute__((ext_vector_type(BYTES / 4))); };
+template <> struct RawVec<4> { typedef unsigned type; };
+template <typename T, int VEC, int NT>
+__device__ __forceinline__ Pack<T, VEC> load_stream(const T* p) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B % 4 == 0 && B <= 16 && (NT & 1)) {
+        using V = typename RawVec<B>::type;
+        const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+        return __builtin_bit_cast(Pack<T, VEC>, v);
+    } else return *reinterpret_cast<const Pack<T, VEC>*>(p);
+}
+template <typename T, int VEC, int NT>
+__device__ __forceinline__ void store_stream(T* p, const typename Compute<T>::type (&o)[VEC]) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    Pack<T, VEC> q;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) st(&q.v[k], o[k]);
+    if constexpr (B % 4 == 0 && B <= 16 && (NT & 2)) {
+        using V = typename RawVec<B>::type;
+        __builtin_nontemporal_store(__builtin_bit_cast(V, q), reinterpret_cast<V*>(p));
+    } else *reinterpret_cast<Pack<T, VEC>*>(p) = q;
+}
+// the pack stays packed up to here
+template <typename T, int VEC> __device__ __forceinline__ void pin(Pack<T, VEC>& q) {
+    constexpr int B = (int)sizeof(T) * VEC;
+    if constexpr (B % 4 == 0) {
+        unsigned w[B / 4];
+        __builtin_memcpy(w, &q, B);
+#pragma unroll
+        for (int k = 0; k < B / 4; ++k) asm volatile("" : "+v"(w[k]));
+        __builtin_memcpy(&q, w, B);
+    }
+}
 // n_segment = 8 (every network of the reference): the whole column of a thread -- 8 packs per tensor -- is requested
 // before the first one is used.  With one plane of look-ahead a wave had 0.5-1 KB in flight and the kernels sat at
 // 3-4 TB/s, latency-bound; the arithmetic (and its order) is that of the generic walk below.
@@ -91,12 +137,13 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
         if (d.S == kSeg) {
             Pack<T, VEC> raw[kSeg];
 #pragma unroll
-            for (int t = 0; t < kSeg; ++t) raw[t] = load_raw<T, VEC>(xp + (size_t)t * tstride);
+            for (int t = 0; t < kSeg; ++t) raw[t] = load_stream<T, VEC, RK_TS_NT_FWD>(xp + (size_t)t * tstride);
+            pin(raw[0]);
             unpack<T, VEC>(raw[0], cur);
             act(cur);
 #pragma unroll
             for (int t = 0; t < kSeg; ++t) {
-                if (t + 1 < kSeg) { unpack<T, VEC>(raw[t + 1 < kSeg ? t + 1 : 0], nxt); act(nxt); }
+                if (t + 1 < kSeg) { pin(raw[t + 1 < kSeg ? t + 1 : 0]); unpack<T, VEC>(raw[t + 1 < kSeg ? t + 1 : 0], nxt); act(nxt); }
                 else {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) nxt[k] = 0;
@@ -107,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_forward(const T* __restrict_
                     prev[k] = cur[k];
                     cur[k] = nxt[k];
                 }
-                store_pack<T, VEC>(yp + (size_t)t * tstride, out);
+                store_stream<T, VEC, RK_TS_NT_FWD>(yp + (size_t)t * tstride, out);
             }
             continue;
         }
@@ -143,7 +190,8 @@ struct BnBwdT {
     float2* bred;               // [C][n_batch]
 };
 template <typename T, int VEC, bool FUSED, bool BN = false>
-__global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(T) * VEC >= 16 ? 3 : 4)))
+void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const typename Compute<T>::type* __restrict__ taps,
                                                              T* __restrict__ gx,
                                                              typename Compute<T>::type* __restrict__ part, DimsT d,
@@ -207,39 +255,48 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_backward(const T* __restrict
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { xprev[k] = 0; gprev[k] = 0; }
             if (d.S == kSeg) {
+                // The tap sums regrouped by the x they use: a0 += gy[t+1] x[t], a1 += gy[t] x[t], a2 += gy[t-1] x[t] -- the same
+                // products in the same order as the walk below (whose t = 0 / t = S - 1 terms against the zero padding are
+                // +-0), but only ONE time step of x is live (the walk carries three, and the fused form their xhat as well:
+                // 256 VGPRs, one wave per SIMD).
                 Pack<T, VEC> xr[kSeg], gr[kSeg];
 #pragma unroll
                 for (int t = 0; t < kSeg; ++t) {
-                    gr[t] = load_raw<T, VEC>(gp + (size_t)t * tstride);
-                    xr[t] = load_raw<T, VEC>(xp + (size_t)t * tstride);
+                    gr[t] = load_stream<T, VEC, RK_TS_NT_BWD>(gp + (size_t)t * tstride);
+                    xr[t] = load_stream<T, VEC, RK_TS_NT_BWD>(xp + (size_t)t * tstride);
                 }
-                unpack<T, VEC>(xr[0], xcur);
-                act(xcur, hcur);
+                pin(gr[0]);
                 unpack<T, VEC>(gr[0], gcur);
 #pragma unroll
                 for (int t = 0; t < kSeg; ++t) {
+                    pin(xr[t]);
+                    unpack<T, VEC>(xr[t], xcur);
+                    if constexpr (BN) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            hcur[k] = (xcur[k] - mu) * iv;
+                            const CT v = fmaf(pa, xcur[k], pb);
+                            xcur[k] = v > 0 ? v : 0;
+                        }
+                    }
                     if (t + 1 < kSeg) {
-                        unpack<T, VEC>(xr[t + 1 < kSeg ? t + 1 : 0], xnxt);
-                        act(xnxt, hnxt);
+                        pin(gr[t + 1 < kSeg ? t + 1 : 0]);
                         unpack<T, VEC>(gr[t + 1 < kSeg ? t + 1 : 0], gnxt);
                     } else {
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) { xnxt[k] = 0; gnxt[k] = 0; }
+                        for (int k = 0; k < VEC; ++k) gnxt[k] = 0;
                     }
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         out[k] = s0 * gnxt[k] + s1 * gcur[k] + s2 * gprev[k];
-                        a0 += gcur[k] * xprev[k];
+                        a0 += gnxt[k] * xcur[k];
                         a1 += gcur[k] * xcur[k];
-                        a2 += gcur[k] * xnxt[k];
+                        a2 += gprev[k] * xcur[k];
                     }
                     mask(out, xcur, hcur);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        xprev[k] = xcur[k]; xcur[k] = xnxt[k]; hcur[k] = hnxt[k];
-                        gprev[k] = gcur[k]; gcur[k] = gnxt[k];
-                    }
-                    store_pack<T, VEC>(op + (size_t)t * tstride, out);
+                    for (int k = 0; k < VEC; ++k) { gprev[k] = gcur[k]; gcur[k] = gnxt[k]; }
+                    store_stream<T, VEC, RK_TS_NT_BWD>(op + (size_t)t * tstride, out);
                 }
                 continue;
             }
