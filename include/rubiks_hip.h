@@ -306,6 +306,10 @@ int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F
  *   rk_pw_gemm_packed_bf16: Y[f] = A X[f] (+ R[f]) with A packed (M rows, depth K); R may be NULL or Y itself. */
 size_t rk_pw_packed_bytes(int rows, int depth);
 int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_stream_t stream);
+/* The same for n weights in one launch (once per train step, pointwise.prepacked): `jobs` = device array of n 40-byte
+ * records {const float* W; int64_t fwd_off, bwd_off; int32_t Cout, Cin, nf, nb}: the two images go to base + fwd_off /
+ * base + bwd_off (multiples of 16), nf / nb = rk_pw_packed_bytes(..) / 16 of each; max_units = max over jobs of nf + nb. */
+int rk_pw_pack_many_bf16(const void* jobs, int n, void* base, int max_units, rk_stream_t stream);
 int rk_pw_gemm_packed_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P,
                            rk_stream_t stream);
 /* training (round 5): the same GEMM + the tile statistics of Y for the BatchNorm that consumes it (backbone.py:50-53 after

@@ -34,6 +34,7 @@ class Switches:
     wgrad_overlap: bool = True
     pw16_stats: bool = False
     bn_shift2d: bool = True
+    prepack: bool = True
 
     @staticmethod
     def from_env(env=None):
@@ -46,7 +47,8 @@ class Switches:
                         fused_train=env.get("RK_FUSED_TRAIN", "1") != "0",
                         wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0",
                         pw16_stats=env.get("RK_PW16_STATS", "0") == "1",
-                        bn_shift2d=env.get("RK_BN_SHIFT2D", "1") != "0")
+                        bn_shift2d=env.get("RK_BN_SHIFT2D", "1") != "0",
+                        prepack=env.get("RK_PREPACK", "1") != "0")
 
 
 _current = Switches.from_env()

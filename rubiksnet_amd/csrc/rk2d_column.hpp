@@ -49,6 +49,19 @@ __device__ __forceinline__ Col2Id my_column2(const C2Dims& cd, int& e) {
 }
 
 template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
+// a quad leaves as one streaming store (the result is written once and is far larger than L2; RK_C2_NT=0 at build time: plain)
+#ifndef RK_C2_NT
+#define RK_C2_NT 1
+#endif
+template <typename T> __device__ __forceinline__ void store_quad(T* p, const Quad<T>& q) {
+    if constexpr (RK_C2_NT && sizeof(T) == 2) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, q), reinterpret_cast<u32x2*>(p));
+    } else if constexpr (RK_C2_NT && sizeof(T) == 4) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, q), reinterpret_cast<u32x4*>(p));
+    } else *reinterpret_cast<Quad<T>*>(p) = q;
+}
 
 // training fusion (bn2 + ReLU inside the shift, fused_bn.bn_relu_shift2d): the value the unfused path would have stored
 // -- rounded to the storage type -- so that both paths see the same activation
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
             else if (oidx[m] >= 0) st(out + oidx[m], v);
         }
         if constexpr (VEC) {
-            if (oidx[0] >= 0) *reinterpret_cast<Quad<T>*>(out + oidx[0]) = oq;
+            if (oidx[0] >= 0) store_quad<T>(out + oidx[0], oq);
         }
     };
     constexpr int kRegsPerFrame = kM * 4 * (int)(sizeof(CT) / 4);
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                     else if (iidx[m] >= 0) st(out + iidx[m], Q);
                 }
                 if constexpr (VEC) {
-                    if (iidx[0] >= 0) *reinterpret_cast<Quad<T>*>(out + iidx[0]) = oq;
+                    if (iidx[0] >= 0) store_quad<T>(out + iidx[0], oq);
                 }
             };
             // frames in flight at once: as many (<= 4) as fit ~40 registers of loaded values

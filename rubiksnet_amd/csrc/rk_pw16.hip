@@ -78,6 +78,16 @@ __global__ __launch_bounds__(kBlock) void k_pw16_pack(const float* __restrict__ 
     else if (u < nf + nb) pack_unit(W, Cin, Cout, 0, (Cin + 15) / 16, u - nf, bwd);
 }
 
+// every 1x1 weight of a network in ONE launch (pointwise.prepacked: once per train step instead of once per forward of every
+// layer -- k_pw16_pack x 100 was 0.5 ms of the Large-AQ step): blockIdx.y = the weight, outputs at offsets of one buffer
+struct PackJob { const float* W; long long fwd_off, bwd_off; int Cout, Cin, nf, nb; };
+__global__ __launch_bounds__(kBlock) void k_pw16_pack_many(const PackJob* __restrict__ jobs, char* __restrict__ base) {
+    const PackJob j = jobs[blockIdx.y];
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u < j.nf) pack_unit(j.W, j.Cout, j.Cin, 1, (j.Cout + 15) / 16, u, reinterpret_cast<uint4*>(base + j.fwd_off));
+    else if (u < j.nf + j.nb) pack_unit(j.W, j.Cin, j.Cout, 0, (j.Cin + 15) / 16, u - j.nf, reinterpret_cast<uint4*>(base + j.bwd_off));
+}
+
 __device__ __forceinline__ const char* uniform_bytes(const char* p) {
     return reinterpret_cast<const char*>(dma::uniform_ptr(reinterpret_cast<const float*>(p)));
 }
@@ -604,6 +614,18 @@ int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_
     const int nb = bwd ? ((Cin + 15) / 16) * ((Cout + kCh - 1) / kCh) * 64 : 0;
     hipLaunchKernelGGL(k_pw16_pack, dim3((nf + nb + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, W, Cout, Cin, nf, nb,
                        (uint4*)fwd, (uint4*)bwd);                  // one launch for both operands
+    return launch_status();
+}
+
+// jobs: device array of n records {const float* W; int64 fwd_off, bwd_off; int Cout, Cin, nf, nb} (40 bytes, nf / nb = 16-byte
+// units of the two images = rk_pw_packed_bytes / 16; offsets into `base`, multiples of 16); max_units = the largest nf + nb
+int rk_pw_pack_many_bf16(const void* jobs, int n, void* base, int max_units, rk_stream_t stream_) {
+    if (!jobs || !base) return RK_ERR_NULL_POINTER;
+    if (n <= 0 || max_units <= 0 || n > 65535) return RK_ERR_BAD_DIMS;
+    if (((uintptr_t)base & 15) || ((uintptr_t)jobs & 7)) return RK_ERR_BAD_DIMS;
+    static_assert(sizeof(PackJob) == 40, "the record layout pointwise.py writes");
+    hipLaunchKernelGGL(k_pw16_pack_many, dim3((max_units + kBlock - 1) / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream_,
+                       (const PackJob*)jobs, (char*)base);
     return launch_status();
 }
 

@@ -7,12 +7,15 @@ replica's backward exactly as under the reference's DataParallel.  T
 exchange is the gradient all-reduce of a training step, done by DDP buckets (backend "nccl"
 is RCCL on ROCm; "gloo" on CPU for tests).
 """
+import contextlib
 import os
 import time
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+from . import pointwise
 
 __all__ = [
     "DistEnv", "init_distributed", "shard_range", "wrap_ddp", "make_optimizer", "train_step",
@@ -124,8 +127,11 @@ def train_step(model, optimizer, clips, labels, criterion=None):
     (scripts/example_finetune.py:85-97)."""
     criterion = criterion or nn.functional.cross_entropy
     optimizer.zero_grad(set_to_none=True)
-    loss = criterion(model(clips), labels)
-    loss.backward()
+    bf16_step = (clips.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+    # (bf16 autocast: the 1x1 weights packed for the bf16 GEMMs once for the whole step, pointwise.prepacked)
+    with (pointwise.prepacked(model) if bf16_step else contextlib.nullcontext()):
+        loss = criterion(model(clips), labels)
+        loss.backward()
     optimizer.step()
     return loss
 

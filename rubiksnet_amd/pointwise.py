@@ -11,6 +11,8 @@ memory-bound 112x112 / 56x56 stages; elsewhere they stay on aten (MIOpen).  Othe
 shortcuts, CPU tensors: `conv(x)`.  `RK_PW=0` disables the HIP path, `RK_PW=all` forces the HIP GEMM wherever
 the kernel's constraints allow (config.py).  Forward, d(input) and d(weight) are HIP MFMA kernels.
 """
+import contextlib
+import struct
 import threading
 
 import torch
@@ -31,10 +33,64 @@ def pointwise_mode():
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}      # storage of the activations; weights are fp32
 
 
+_PREPACKED = None            # inside `prepacked(module)`: {weight.data_ptr(): (weight shape, fwd image, bwd image)}
+
+
+@contextlib.contextmanager
+def prepacked(module):
+    """Every 1x1 weight of `module` packed for the bf16 GEMMs in ONE launch (rk_pw_pack_many_bf16), valid inside the `with`
+    block: dp.train_step wraps forward + backward of a bf16-autocast step in it (the optimizer -- the only writer of the weights
+    -- runs after the block), so `_pack` finds its operands instead of launching k_pw16_pack per layer and forward (x 100 in
+    Large-AQ: 0.5 ms of the step).  Outside a block nothing is cached: no key would see an edit made through `.data`.
+    The images live in one fresh buffer per block; the d(input) operands saved for backward are views of it."""
+    global _PREPACKED
+    if _PREPACKED is not None or not config.switches().prepack or pointwise_mode() == "0":
+        yield
+        return
+    weights = [m.weight for m in module.modules()
+               if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.groups == 1 and m.weight.is_cuda
+               and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
+    if not weights or len(weights) > 65535 or len({w.device for w in weights}) != 1:
+        yield
+        return
+    L = _native.lib()
+    dev = weights[0].device
+    key = tuple((w.data_ptr(), w.shape[0], w.shape[1]) for w in weights)
+    plan = getattr(module, "_rk_prepack_plan", None)
+    if plan is None or plan[0] != key:
+        recs, off, max_units, views = [], 0, 0, []
+        for w in weights:
+            Cout, Cin = int(w.shape[0]), int(w.shape[1])
+            bf, bb = int(L.rk_pw_packed_bytes(Cout, Cin)), int(L.rk_pw_packed_bytes(Cin, Cout))
+            recs.append(struct.pack("<Qqqiiii", w.data_ptr(), off, off + bf, Cout, Cin, bf // 16, bb // 16))
+            views.append((off, bf, bb))
+            max_units = max(max_units, (bf + bb) // 16)
+            off += bf + bb
+        jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        plan = (key, jobs, off, max_units, views)
+        module._rk_prepack_plan = plan                      # (rebuilt when a weight moves: .to(), a reloaded parameter)
+    _, jobs, total, max_units, views = plan
+    with torch.cuda.device(dev):
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        _native.check(L.rk_pw_pack_many_bf16(jobs.data_ptr(), len(weights), buf.data_ptr(), max_units,
+                                             torch.cuda.current_stream(dev).cuda_stream), "rk_pw_pack_many_bf16")
+    _PREPACKED = {w.data_ptr(): (tuple(w.shape[:2]), buf[o:o + bf], buf[o + bf:o + bf + bb])
+                  for w, (o, bf, bb) in zip(weights, views)}
+    try:
+        yield
+    finally:
+        _PREPACKED = None
+
+
 def _pack(weight):
     """The weight of a 1x1 convolution packed for rk_pw_gemm_packed_bf16 (rk_pw16.hip): both operands -- W for the forward,
     W^T for d(input) -- in ONE small launch.  Redone on every forward (the d(input) operand rides to the backward in the
-    autograd context): no cache key sees in-place edits made through `.data` (cf. _bn_affine)."""
+    autograd context): no cache key sees in-place edits made through `.data` (cf. _bn_affine) -- except inside
+    `prepacked(module)`, whose images of this step's weights are used when present."""
+    if _PREPACKED is not None:
+        hit = _PREPACKED.get(weight.data_ptr())
+        if hit is not None and hit[0] == tuple(weight.shape[:2]):
+            return hit[1], hit[2]
     L = _native.lib()
     Cout, Cin = weight.shape[0], weight.shape[1]
     dev = weight.device
