@@ -310,6 +310,16 @@ int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_
  * records {const float* W; int64_t fwd_off, bwd_off; int32_t Cout, Cin, nf, nb}: the two images go to base + fwd_off /
  * base + bwd_off (multiples of 16), nf / nb = rk_pw_packed_bytes(..) / 16 of each; max_units = max over jobs of nf + nb. */
 int rk_pw_pack_many_bf16(const void* jobs, int n, void* base, int max_units, rk_stream_t stream);
+/* bf16 activations on planes without a 16-byte unit in a row (P % 4 != 0, P <= 64: the 7x7 planes of layer4, backbone.py:44-45
+ * on [NT, 576, 7, 7]; rk_pw16_odd.hip): a workgroup per frame (a whole frame [K][P] IS contiguous and aligned).
+ *   rk_pw_odd16_supported(F, K, M, P): 1 when the GEMM takes [F, K -> M, P] (K % 32 == 0, M % 8 == 0, P <= 64, LDS);
+ *   rk_pw_gemm_packed_odd_bf16: Y[f] = A X[f] (+ R[f]), A packed by rk_pw_pack_bf16 (M rows, depth K); tensors 16-byte aligned;
+ *   rk_pw_wgrad_odd16_bf16: dW [M][K] fp32 = sum_f dY[f] X[f]^T (K % 8 == M % 8 == 0); ws of .._workspace_bytes(). */
+int rk_pw_odd16_supported(int F, int K, int M, int P);
+int rk_pw_gemm_packed_odd_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P, rk_stream_t stream);
+size_t rk_pw_wgrad_odd16_workspace_bytes(int F, int K, int M, int P);
+int rk_pw_wgrad_odd16_bf16(const void* dY, const void* X, float* dW, int F, int K, int M, int P, void* workspace,
+                           size_t workspace_bytes, rk_stream_t stream);
 int rk_pw_gemm_packed_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P,
                            rk_stream_t stream);
 /* training (round 5): the same GEMM + the tile statistics of Y for the BatchNorm that consumes it (backbone.py:50-53 after

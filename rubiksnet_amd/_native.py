@@ -55,6 +55,10 @@ SIGNATURES = {
     "rk_pw_packed_bytes": (_sz, [_i, _i]),
     "rk_pw_pack_bf16": (_i, [_p, _i, _i, _p, _p, _p]),
     "rk_pw_pack_many_bf16": (_i, [_p, _i, _p, _i, _p]),
+    "rk_pw_odd16_supported": (_i, [_i, _i, _i, _i]),
+    "rk_pw_gemm_packed_odd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_pw_wgrad_odd16_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rk_pw_wgrad_odd16_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_pw_gemm_packed_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rk_pw16_stat_tiles": (_i, [_i, _i]),
     "rk_pw_gemm_packed_stats_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),

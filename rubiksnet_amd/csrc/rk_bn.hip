@@ -18,6 +18,7 @@
 // Variance: sums of (x - K) and (x - K)^2 with K = x[0, c, 0], combined in fp64 -- the shifted-data form, immune
 // to the E[x^2] - mean^2 cancellation.  Parameters and statistics are fp32 whatever the storage type.
 #include "rk_common.hpp"
+#include "rk_dma.hpp"
 
 namespace rk {
 namespace bn {
@@ -48,6 +49,14 @@ template <> struct Pack<__hip_bfloat16, 4> {
     }
     __device__ static __forceinline__ void store(__hip_bfloat16* p, const float (&v)[4]) {
         *reinterpret_cast<uint2*>(p) = make_uint2(bits(v[0]) | (bits(v[1]) << 16), bits(v[2]) | (bits(v[3]) << 16));
+    }
+};
+template <> struct Pack<__hip_bfloat16, 8> {                     // 16-byte cells (planes of a multiple of 8 elements)
+    __device__ static __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
     }
 };
 template <typename T> struct Pack<T, 1> {
@@ -115,6 +124,61 @@ __global__ __launch_bounds__(kBlock) void k_bn_stats(const T* __restrict__ x, fl
         for (int e = 0; e < VEC; ++e) { const float t = v[e] - K; s += t; q = fmaf(t, t, q); }
     });
     block_pair_sum(s, q, part + ((size_t)w.c * d.G + w.g) * 2, red);
+}
+
+// The statistics pass + its finisher in ONE launch (rk_bn_stats_finish_*: the -aq blocks' bn1 / bn2, 98 calls per Large-AQ
+// step): the producers publish their partial pair as granules (rk_dma.hpp) and C more blocks at the end of the grid -- one
+// wave each -- sum a channel's G pairs in fp64 in a fixed order and do k_bn_finish_parts' arithmetic.  No second launch.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_bn_stats_fused(const T* __restrict__ x, BnDims d, dma::Fin fin,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ ab, float eps, float momentum,
+                                                           long long* __restrict__ num_batches_tracked) {
+    if ((int)blockIdx.x >= fin.producers) {
+        if (threadIdx.x >= kWave) return;
+        const int c = (int)blockIdx.x - fin.producers;
+        if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+        double S[2];
+        const bool ok = dma::fin_collect<2>(fin, c, d.G, S);
+        if (threadIdx.x != 0) return;
+        const float nanv = __uint_as_float(0x7fc00000u);
+        const double M = (double)d.F * d.P;
+        const double ms = S[0] / M;
+        double var = S[1] / M - ms * ms;
+        var = var < 0 ? 0 : var;
+        const float mean = ok ? (float)((double)ld(x + (size_t)c * d.P) + ms) : nanv;
+        const float invstd = ok ? 1.0f / sqrtf((float)var + eps) : nanv;
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        const float a = gamma[c] * invstd;                              // (affine() below, declared after this kernel)
+        ab[c] = a;
+        ab[d.C + c] = fmaf(-mean, a, beta[c]);
+        if (running_mean) {
+            const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+        return;
+    }
+    __shared__ float red[2][kBlock / kWave];
+    const Where w = where_am_i(d);
+    const float K = ld(x + (size_t)w.c * d.P);
+    float s = 0.f, q = 0.f;
+    sweep<VEC>(d, w, [&](size_t o) {
+        float v[VEC];
+        Pack<T, VEC>::load(x + o, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float t = v[e] - K; s += t; q = fmaf(t, t, q); }
+    });
+    s = group_sum(s, kBlock, red[0]);
+    q = group_sum(q, kBlock, red[1]);
+    if (threadIdx.x == 0) {
+        const size_t at = (size_t)w.c * 2 * d.G + w.g;
+        dma::fin_publish(fin, at, s);
+        dma::fin_publish(fin, at + d.G, q);
+    }
 }
 
 // a, b of y = a x + b, identical in forward and backward (the ReLU mask depends on it)
@@ -459,7 +523,8 @@ int make_bn(BnDims& d, int F, int C, int P) {
     return RK_OK;
 }
 unsigned grid_bn(const BnDims& d) { return (unsigned)((long long)d.C * d.G); }
-size_t ws_bn(const BnDims& d) { return (size_t)d.C * d.G * 2 * sizeof(float); }
+// (16 bytes per partial: the fused statistics kernel hands its pairs over as granules, rk_dma.hpp)
+size_t ws_bn(const BnDims& d) { return (size_t)d.C * d.G * 2 * 16; }
 template <typename T> bool vec4_ok(const BnDims& d, const void* a, const void* b, const void* c = nullptr) {
     const uintptr_t m = 4 * sizeof(T) - 1;
     return d.P % 4 == 0 && !((uintptr_t)a & m) && !((uintptr_t)b & m) && !((uintptr_t)c & m);
@@ -523,6 +588,10 @@ int bn_backward(const void* dy_, const void* x_, const float* gamma, const float
     return launch_status();
 }
 
+inline bool stats_fused_on() {                              // RK_BN_STATS_FUSED=0: statistics kernel + finisher kernel
+    static const bool on = [] { const char* e = getenv("RK_BN_STATS_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
 template <typename T>
 int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
@@ -533,6 +602,22 @@ int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* ru
     if (int rc = make_bn(d, F, C, P)) return rc;
     if (!ws || ws_bytes < ws_bn(d)) return RK_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (stats_fused_on() && !((uintptr_t)ws & 15)) {
+        dma::Fin fin;
+        fin.gran = reinterpret_cast<unsigned long long*>(ws);
+        fin.tag = dma::next_launch_tag();
+        fin.producers = (int)grid_bn(d);
+        const dim3 grid(grid_bn(d) + C), block(kBlock);
+#define RK_BN_SF(VEC) hipLaunchKernelGGL((k_bn_stats_fused<T, VEC>), grid, block, 0, stream, x, d, fin, gamma, beta, running_mean, \
+                                         running_var, save_mean, save_invstd, ab, eps, momentum, nbt)
+        if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+            if (P % 8 == 0 && !((uintptr_t)x & 15)) { RK_BN_SF(8); return launch_status(); }
+        }
+        if (vec4_ok<T>(d, x, x)) RK_BN_SF(4);
+        else RK_BN_SF(1);
+#undef RK_BN_SF
+        return launch_status();
+    }
     float* part = (float*)ws;
     if (vec4_ok<T>(d, x, x)) hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid_bn(d)), dim3(kBlock), 0, stream, x, part, d);
     else hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid_bn(d)), dim3(kBlock), 0, stream, x, part, d);

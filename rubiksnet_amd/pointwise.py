@@ -436,6 +436,83 @@ class _ConvS2OddFunc(torch.autograd.Function):
         return dx, dw
 
 
+class _Conv1x1Odd16Func(torch.autograd.Function):
+    """1x1 convolution (+ residual) of bf16 activations on planes with H * W % 4 != 0 (the 7x7 planes of layer4 under
+    autocast; `stride` 2: the 14x14 -> 7x7 projecting shortcut, its even pixels gathered first as in _ConvS2Bf16Func) on
+    rk_pw16_odd.hip: a workgroup per frame, the packed weight of rk_pw_pack_bf16.  MIOpen ran these as NHWC implicit GEMMs
+    between two layout transposes of each tensor: 58 / 173 us forward / forward + backward at [256, 576 -> 576, 7, 7]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, residual, stride):
+        if stride == 2:
+            H, W = x.shape[2], x.shape[3]
+            ctx.full = (H, W)
+            x = x[:, :, ::2, ::2].contiguous()
+        else:
+            ctx.full = None
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty(Fr, Cout, H, W, dtype=x.dtype, device=x.device)
+        fwd, ctx.packed_bwd = _pack(weight)
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_pw_gemm_packed_odd_bf16(fwd.data_ptr(), x.data_ptr(),
+                                                          residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                                          Fr, Cin, Cout, H * W, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_pw_gemm_packed_odd_bf16")
+        ctx.save_for_backward(x, weight)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        Fr, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        L = _native.lib()
+        dx = dw = None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _native.check(L.rk_pw_gemm_packed_odd_bf16(ctx.packed_bwd.data_ptr(), dy.data_ptr(), None, dx.data_ptr(), Fr, Cout,
+                                                           Cin, H * W, stream), "rk_pw_gemm_packed_odd_bf16")
+                if ctx.full is not None:
+                    full = torch.zeros(Fr, Cin, ctx.full[0], ctx.full[1], dtype=x.dtype, device=dev)
+                    full[:, :, ::2, ::2] = dx
+                    dx = full
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                nbytes = int(L.rk_pw_wgrad_odd16_workspace_bytes(Fr, Cin, Cout, H * W))
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                _native.check(L.rk_pw_wgrad_odd16_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Fr, Cin, Cout, H * W,
+                                                       ws.data_ptr(), nbytes, stream), "rk_pw_wgrad_odd16_bf16")
+        return dx, dw, (dy if ctx.has_residual and ctx.needs_input_grad[2] else None), None
+
+
+def _eligible_odd16(conv, x, stride):
+    if not (pointwise_mode() != "0" and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.numel() > 0
+            and x.data_ptr() % 16 == 0
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (stride, stride)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.weight.is_cuda):
+        return False
+    H, W = x.shape[2], x.shape[3]
+    if stride == 2:
+        if H % 2 or W % 2:
+            return False
+        H, W = H // 2, W // 2
+    P = H * W
+    L = _native.lib()
+    # (both directions: the forward's [K -> M] and d(input)'s [M -> K])
+    return (P % 4 != 0 and bool(L.rk_pw_odd16_supported(x.shape[0], conv.in_channels, conv.out_channels, P))
+            and bool(L.rk_pw_odd16_supported(x.shape[0], conv.out_channels, conv.in_channels, P)))
+
+
 _ODD_PMIN, _ODD_PMAX = 37, 64        # k_pw_gemm_odd: frames per 256-column tile / LDS
 
 
@@ -469,6 +546,12 @@ def conv1x1(conv, x, residual=None):
         return _ConvS2Func.apply(x.contiguous(), conv.weight)
     if residual is None and _eligible_s2_bf16(conv, x):
         return _ConvS2Bf16Func.apply(x, conv.weight)
+    if x.dim() == 4 and x.is_contiguous() and x.dtype == torch.bfloat16:
+        if residual is None and _eligible_odd16(conv, x, 2):
+            return _Conv1x1Odd16Func.apply(x, conv.weight, None, 2)
+        if (_eligible_odd16(conv, x, 1) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype
+                                                                     and residual.data_ptr() % 16 == 0))):
+            return _Conv1x1Odd16Func.apply(x, conv.weight, residual, 1)
     if x.dim() == 4 and x.is_contiguous():
         if residual is None and _eligible_s2_odd(conv, x):
             return _ConvS2OddFunc.apply(x, conv.weight)

@@ -50,7 +50,7 @@ def test_bf16_train_step_is_unchanged(monkeypatch):
         monkeypatch.setenv("RK_PREPACK", on)
         config.reload()
         net = _net()
-        opt = dp.make_optimizer(net, lr=1e-3, kind="adam")
+        opt = dp.make_optimizer(net, lr=1e-2, kind="sgd", momentum=0.0)     # (updates proportional to the gradients)
         calls = {"many": 0}
         real = pointwise.prepacked
 
@@ -71,9 +71,9 @@ def test_bf16_train_step_is_unchanged(monkeypatch):
     exact = 0
     for k, v in out["1"][1].items():
         w = out["0"][1][k]
-        # (the bf16 stem and the 7x7 layers are MIOpen's, whose d(weight) uses atomics: not reproducible run to run; everything
-        # on the HIP kernels is, bit for bit)
-        assert torch.allclose(v.float(), w.float(), rtol=0, atol=1e-5 * max(1.0, float(w.float().abs().max()))), k
+        # (the bf16 stem and Tiny's 7x7 layers -- 432 channels: not a multiple of 32 -- are MIOpen's, whose d(weight) uses
+        # atomics: not reproducible run to run; everything on the HIP kernels is, bit for bit)
+        assert torch.allclose(v.float(), w.float(), rtol=0, atol=1e-4 * max(1.0, float(w.float().abs().max()))), k
         exact += int(torch.equal(v, w))
         if not ("layer4" in k or k.startswith("backbone.conv1") or k.startswith("backbone.bn1")):
             assert torch.equal(v, w), k
