@@ -315,6 +315,14 @@ int rk_pw_pack_many_bf16(const void* jobs, int n, void* base, int max_units, rk_
  *   rk_pw_odd16_supported(F, K, M, P): 1 when the GEMM takes [F, K -> M, P] (K % 32 == 0, M % 8 == 0, P <= 64, LDS);
  *   rk_pw_gemm_packed_odd_bf16: Y[f] = A X[f] (+ R[f]), A packed by rk_pw_pack_bf16 (M rows, depth K); tensors 16-byte aligned;
  *   rk_pw_wgrad_odd16_bf16: dW [M][K] fp32 = sum_f dY[f] X[f]^T (K % 8 == M % 8 == 0); ws of .._workspace_bytes(). */
+/* The 3x3 / stride-2 / pad-1 stem (backbone.py:154) under bf16 autocast (rk_stem16.hip): fp32 clip X [F, 3, Hin, Win] and fp32
+ * weight W [Cout][3][3][3], both rounded to bf16 as autocast rounds them, Y / dY [F, Cout, Hin/2, Win/2] bf16, dW fp32.
+ * Win % 32 == 0, Hin % 16 == 0, Cout <= 128 (rk_stem16_supported). */
+int rk_stem16_supported(int F, int Cin, int Cout, int Hin, int Win);
+int rk_stem_conv3x3s2_bf16out(const float* W, const float* X, void* Y, int F, int Cin, int Cout, int Hin, int Win, rk_stream_t stream);
+size_t rk_stem_wgrad16_workspace_bytes(int F, int Cin, int Cout, int Hin, int Win);
+int rk_stem_wgrad3x3s2_bf16(const void* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* workspace,
+                            size_t workspace_bytes, rk_stream_t stream);
 int rk_pw_odd16_supported(int F, int K, int M, int P);
 int rk_pw_gemm_packed_odd_bf16(const void* Apk, const void* X, const void* R, void* Y, int F, int K, int M, int P, rk_stream_t stream);
 size_t rk_pw_wgrad_odd16_workspace_bytes(int F, int K, int M, int P);

@@ -11,7 +11,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$root/inc
        -Wall -Wno-unused-function -Wno-implicit-fallthrough)
 objs=()
 pids=()
-for src in rk_misc rk3d rk3d_slab rk2d rk_tshift rk_bn rk_pw rk_pw2 rk_pw3 rk_pw4 rk_pw16 rk_pw16_odd rk_clip; do
+for src in rk_misc rk3d rk3d_slab rk2d rk_tshift rk_bn rk_pw rk_pw2 rk_pw3 rk_pw4 rk_pw16 rk_pw16_odd rk_stem16 rk_clip; do
   rm -f "$here/$src.o"
   "$HIPCC" "${FLAGS[@]}" ${RK_EXTRA_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
   pids+=($!)
