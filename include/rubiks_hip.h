@@ -319,6 +319,9 @@ int rk_pw_pack_many_bf16(const void* jobs, int n, void* base, int max_units, rk_
  * weight W [Cout][3][3][3], both rounded to bf16 as autocast rounds them, Y / dY [F, Cout, Hin/2, Win/2] bf16, dW fp32.
  * Win % 32 == 0, Hin % 16 == 0, Cout <= 128 (rk_stem16_supported). */
 int rk_stem16_supported(int F, int Cin, int Cout, int Hin, int Win);
+/* out [planes][H][W] bf16 = main (NULL: zeros) + small [planes][H/2][W/2] scattered to the even (h, w) -- the gradient of the
+ * stride-2 gather in front of a projecting shortcut (backbone.py:98-104) joined to the other consumer's gradient in one pass. */
+int rk_scatter2x2_add_bf16(const void* main, const void* small, void* out, long long planes, int H, int W, rk_stream_t stream);
 int rk_stem_conv3x3s2_bf16out(const float* W, const float* X, void* Y, int F, int Cin, int Cout, int Hin, int Win, rk_stream_t stream);
 size_t rk_stem_wgrad16_workspace_bytes(int F, int Cin, int Cout, int Hin, int Win);
 int rk_stem_wgrad3x3s2_bf16(const void* dY, const float* X, float* dW, int F, int Cin, int Cout, int Hin, int Win, void* workspace,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "rk_pw_packed_bytes": (_sz, [_i, _i]),
     "rk_pw_pack_bf16": (_i, [_p, _i, _i, _p, _p, _p]),
     "rk_pw_pack_many_bf16": (_i, [_p, _i, _p, _i, _p]),
+    "rk_scatter2x2_add_bf16": (_i, [_p, _p, _p, ctypes.c_longlong, _i, _i, _p]),
     "rk_stem16_supported": (_i, [_i] * 5),
     "rk_stem_conv3x3s2_bf16out": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_stem_wgrad16_workspace_bytes": (_sz, [_i] * 5),

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import _native, config
 from .fused_bn import bn_relu, bn_relu_shift2d, bn_relu_skip, bn_relu_tshift_skip
-from .pointwise import all_frozen, conv1x1, fused_eval_block, stem_conv
+from .pointwise import all_frozen, conv1x1, fork_shortcut, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 from .train_block import bn_relu_from_stats, fused_train_block
 
@@ -173,7 +173,9 @@ class RubiksShiftBlock(nn.Module):
             out, shortcut = bn_relu_skip(self.bn1, x)
         else:
             out = bn_relu(self.bn1, x)
-            shortcut = conv1x1(self.shortcut, out)
+            # (stride-2 projecting shortcut on bf16 activations: one autograd node for the two consumers of `out`, their
+            # gradients joined in one pass)
+            out, shortcut = fork_shortcut(self.shortcut, out)
         z2 = conv1x1(self.conv2, out)
         out = bn_relu_shift2d(self.bn2, self.as3, z2) if self.training else None
         if out is None:

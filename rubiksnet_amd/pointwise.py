@@ -513,6 +513,59 @@ def _eligible_odd16(conv, x, stride):
             and bool(L.rk_pw_odd16_supported(x.shape[0], conv.out_channels, conv.in_channels, P)))
 
 
+class _ForkS2(torch.autograd.Function):
+    """x -> (x, x[:, :, ::2, ::2] gathered): the two consumers of a downsampling block's activation -- the main path and the
+    stride-2 projecting shortcut (backbone.py:98-104) -- as one node, so that their gradients are joined in ONE pass
+    (rk_scatter2x2_add_bf16: main + the small gradient scattered to the even pixels).  As separate nodes the shortcut's backward
+    wrote zeros, scattered into them, and autograd added the two full-size tensors: three passes, 0.9 ms of a Large-AQ step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return x.view_as(x), x[:, :, ::2, ::2].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_main, g_small):
+        if g_small is None:
+            return g_main
+        Fr, C, H, W = ctx.shape
+        g_small = g_small.contiguous()
+        if g_main is not None:
+            g_main = g_main.contiguous()
+            if g_main.dtype != g_small.dtype:
+                g_main = g_main.to(g_small.dtype)
+        out = torch.empty(ctx.shape, dtype=g_small.dtype, device=g_small.device)
+        dev = g_small.device
+        with torch.cuda.device(dev):
+            rc = _native.lib().rk_scatter2x2_add_bf16(g_main.data_ptr() if g_main is not None else None, g_small.data_ptr(),
+                                                      out.data_ptr(), Fr * C, H, W, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "rk_scatter2x2_add_bf16")
+        return out
+
+
+def fork_shortcut(conv, x):
+    """`(x', conv(x))` for the stride-2 projecting shortcut `conv` of a downsampling block whose activation x also feeds the
+    main path: the caller continues with x' (an autograd alias of x).  bf16 activations on the HIP kernels; otherwise
+    `(x, conv1x1(conv, x))`."""
+    ok = (pointwise_mode() != "0" and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.bfloat16
+          and x.dim() == 4 and x.is_contiguous() and x.numel() > 0 and x.data_ptr() % 16 == 0
+          and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+          and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
+          and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+          and conv.weight.is_cuda)
+    if ok:
+        Fr, K, M = x.shape[0], conv.in_channels, conv.out_channels
+        P = (x.shape[2] // 2) * (x.shape[3] // 2)
+        L = _native.lib()
+        if P % 4 == 0 and P >= 8 and K % 2 == 0 and M % 2 == 0 and _pw16_fits(Fr, max(K, M), P):
+            x_main, xs = _ForkS2.apply(x)
+            return x_main, _Conv1x1Func.apply(xs, conv.weight, True, None, True)
+        if P % 4 != 0 and L.rk_pw_odd16_supported(Fr, K, M, P) and L.rk_pw_odd16_supported(Fr, M, K, P):
+            x_main, xs = _ForkS2.apply(x)
+            return x_main, _Conv1x1Odd16Func.apply(xs, conv.weight, None, 1)
+    return x, conv1x1(conv, x)
+
+
 _ODD_PMIN, _ODD_PMAX = 37, 64        # k_pw_gemm_odd: frames per 256-column tile / LDS
 
 

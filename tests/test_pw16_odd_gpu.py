@@ -76,3 +76,42 @@ def test_unsupported_shapes_stay_on_aten():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = pointwise.conv1x1(conv, x)
     assert y.shape == (2, 64, 7, 7)
+
+
+@pytest.mark.parametrize("Fr,K,M,H,W", [(8, 72, 144, 56, 56), (4, 64, 96, 28, 28), (6, 288, 576, 14, 14), (3, 32, 64, 10, 6), (2, 16, 32, 16, 24)])
+def test_forked_shortcut_equals_separate_consumers(Fr, K, M, H, W):
+    """pointwise.fork_shortcut: the activation of a downsampling block as ONE autograd node for its two consumers (main path,
+    stride-2 projecting shortcut): same outputs, and d(activation) = the two gradients added -- bit for bit what autograd's own
+    accumulation of the separate nodes' gradients gives (one fp32 add, one rounding)."""
+    from rubiksnet_amd import pointwise
+
+    g = torch.Generator(device="cpu").manual_seed(Fr + K + H)
+    conv = torch.nn.Conv2d(K, M, 1, stride=2, bias=False).to(DEV)
+    x0 = torch.randn(Fr, K, H, W, generator=g).to(DEV).bfloat16()
+    gm = torch.randn(Fr, K, H, W, generator=g).to(DEV).bfloat16()
+    gs = torch.randn(Fr, M, H // 2, W // 2, generator=g).to(DEV).bfloat16()
+    res = []
+    for forked in (True, False):
+        conv.weight.grad = None
+        x = x0.clone().requires_grad_(True)
+        a = x * 1.0                                              # a non-leaf, as relu(bn1(.)) is
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if forked:
+                main, y = pointwise.fork_shortcut(conv, a)
+                assert main is not a and "ForkS2" in type(main.grad_fn).__name__
+            else:
+                main, y = a, pointwise.conv1x1(conv, a)
+        torch.autograd.backward([main, y], [gm, gs])
+        res.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone()))
+    torch.cuda.synchronize()
+    (yf, dxf, dwf), (yu, dxu, dwu) = res
+    assert torch.equal(yf, yu) and torch.equal(dwf, dwu)
+    assert torch.equal(dxf, dxu)
+    # scatter alone (no gradient from the main path)
+    x = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        main, y = pointwise.fork_shortcut(conv, x * 1.0)
+    y.backward(gs)
+    mask = torch.ones_like(x0, dtype=torch.bool)
+    mask[:, :, ::2, ::2] = False
+    assert float(x.grad[mask].abs().max()) == 0.0 and float(x.grad.abs().max()) > 0
