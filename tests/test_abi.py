@@ -47,7 +47,7 @@ def test_version_shape_helper_and_error_strings():
     assert L.rk3d_backward_workspace_bytes(32, 8, 64, 56, 56, 1, 1, 1, 0, 0, 0, 8) == 64 * 3 * 32 * 56 * 8
     assert L.rk2d_backward_workspace_bytes(4, 10, 7, 7, 1, 1, 0, 0, 4) == 10 * 2 * 4 * 16     # 16-byte granule pairs
     assert L.rk_tshift3_backward_workspace_bytes(16, 8, 5, 49) == 5 * 3 * 2 * 16
-    assert L.rk_bn_workspace_bytes(256, 54, 56 * 56) == 54 * 86 * 2 * 4      # 3 frames per workgroup -> 86 groups
+    assert L.rk_bn_workspace_bytes(256, 54, 56 * 56) == 54 * 86 * 2 * 16     # 3 frames per workgroup -> 86 groups; 16-byte granule pairs (fused statistics)
     assert L.rk_bn_workspace_bytes(0, 54, 49) == 0
 
 
