@@ -242,6 +242,16 @@ int rk_tshift3_bn_backward_bf16(const void* gy, const void* x, const float* taps
                                 const float* save_invstd, void* dz, float* gtaps, void* bred, int NT, int S, int C, int HW,
                                 void* ws, size_t ws_bytes, rk_stream_t stream);
 
+/* The same with BatchNorm's backward constants finished inside the launch (the two sums travel as granules next to the tap
+ * sums): k12 [2][C] = (sum dz, sum dz xhat) / (NT HW), dgamma / dbeta [C] -- what rk_bn_bwd_finish_tiles_f32 made of bred. */
+size_t rk_tshift3_bn_backward_fin_workspace_bytes(int NT, int n_segment, int C, int HW);
+int rk_tshift3_bn_backward_fin_f32(const float* gy, const float* x, const float* taps, const float* ab, const float* save_mean,
+                                   const float* save_invstd, float* dz, float* gtaps, float* k12, float* dgamma, float* dbeta,
+                                   int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream);
+int rk_tshift3_bn_backward_fin_bf16(const void* gy, const void* x, const float* taps, const float* ab, const float* save_mean,
+                                    const float* save_invstd, void* dz, float* gtaps, float* k12, float* dgamma, float* dbeta,
+                                    int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream);
+
 /* The [C,3] half of AttentionShift (attention_shift.py:29-30): taps = softmax((weight / (std(weight, dim=1) + 1e-6)) / T)
  * over the three taps of a channel (std unbiased), and its backward (gweight from gtaps).  fp32; T is the module's
  * one-element device tensor (no host read); one launch each instead of ~15 + ~25 PyTorch kernels per layer. */

@@ -75,13 +75,13 @@ __device__ __forceinline__ Where where_am_i(const BnDims& d) {
 }
 
 // visit the workgroup's elements VEC at a time: fn(element offset into the tensor)
-template <int VEC, typename Fn>
+template <int VEC, int UNROLL = 4, typename Fn>
 __device__ __forceinline__ void sweep(const BnDims& d, const Where& w, Fn fn) {
     const int PV = d.P / VEC;
     const int total = w.nf * PV;
     const size_t base = ((size_t)w.f0 * d.C + w.c) * d.P;
     const size_t fstride = (size_t)d.C * d.P;
-#pragma unroll 4
+#pragma unroll UNROLL
     for (int j = threadIdx.x; j < total; j += kBlock) {
         const int fr = j / PV, i = j - fr * PV;
         fn(base + (size_t)fr * fstride + (size_t)i * VEC);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_stats_fused(const T* __restrict__
     const Where w = where_am_i(d);
     const float K = ld(x + (size_t)w.c * d.P);
     float s = 0.f, q = 0.f;
-    sweep<VEC>(d, w, [&](size_t o) {
+    sweep<VEC>(d, w, [&](size_t o) {                                 // (unroll 8 instead of 4 measured worse: 24 -> 28 us at 56x56)
         float v[VEC];
         Pack<T, VEC>::load(x + o, v);
 #pragma unroll

@@ -187,7 +187,10 @@ struct BnBwdT {
     const float* ab;            // [2][C]
     const float* mean;          // [C]
     const float* invstd;        // [C]
-    float2* bred;               // [C][n_batch]
+    float2* bred;               // [C][n_batch] (nullptr with k12: the sums travel as granules 3 and 4 and are finished in the launch)
+    float* k12;                 // [2][C] or nullptr: BatchNorm's backward constants (sum dz, sum dz xhat) / count ...
+    float* dgamma; float* dbeta;    // ... and d(gamma), d(beta) [C], written by the finalizer waves (k_bn_bwd_finish_tiles' job)
+    float inv_count;            // 1 / (NT H W)
 };
 template <typename T, int VEC, bool FUSED, bool BN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(T) * VEC >= 16 ? 3 : 4)))
@@ -196,17 +199,31 @@ void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              T* __restrict__ gx,
                                                              typename Compute<T>::type* __restrict__ part, DimsT d,
                                                              dma::Fin fin, typename Compute<T>::type* __restrict__ gtaps,
-                                                             BnBwdT bn = BnBwdT{nullptr, nullptr, nullptr, nullptr}) {
+                                                             BnBwdT bn = BnBwdT{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                                                nullptr, 0.f}) {
     using CT = typename Compute<T>::type;
     __shared__ CT red[BN ? 5 : 3][kBlock / kWave];
     if constexpr (FUSED) {
         if ((int)blockIdx.x >= fin.producers) {
             if (threadIdx.x < kWave) {
                 const int cf = (int)blockIdx.x - fin.producers;
-                double s[3];
-                const bool ok = dma::fin_collect<3>(fin, cf, d.NB, s);
-                if (threadIdx.x == 0)
-                    for (int k = 0; k < 3; ++k) gtaps[cf * 3 + k] = ok ? (CT)s[k] : (CT)__uint_as_float(0x7fc00000u);
+                const CT nanv = (CT)__uint_as_float(0x7fc00000u);
+                if (BN && bn.k12) {                                  // + BatchNorm's two sums: k_bn_bwd_finish_tiles inside the launch
+                    double s[5];
+                    const bool ok = dma::fin_collect<5>(fin, cf, d.NB, s);
+                    if (threadIdx.x == 0) {
+                        for (int k = 0; k < 3; ++k) gtaps[cf * 3 + k] = ok ? (CT)s[k] : nanv;
+                        bn.dbeta[cf] = ok ? (float)s[3] : (float)nanv;
+                        bn.dgamma[cf] = ok ? (float)s[4] : (float)nanv;
+                        bn.k12[cf] = ok ? (float)(s[3] * (double)bn.inv_count) : (float)nanv;
+                        bn.k12[d.C + cf] = ok ? (float)(s[4] * (double)bn.inv_count) : (float)nanv;
+                    }
+                } else {
+                    double s[3];
+                    const bool ok = dma::fin_collect<3>(fin, cf, d.NB, s);
+                    if (threadIdx.x == 0)
+                        for (int k = 0; k < 3; ++k) gtaps[cf * 3 + k] = ok ? (CT)s[k] : nanv;
+                }
             }
             return;
         }
@@ -330,20 +347,25 @@ void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
             }
         }
     }
+    const bool bnfin = BN && bn.k12 != nullptr;                      // (uniform)
     if constexpr (BN) {
         z1 = group_sum(z1, d.E, red[3]);
         z2 = group_sum(z2, d.E, red[4]);
-        if (valid && e == 0) bn.bred[(size_t)c * d.NB + n] = make_float2((float)z1, (float)z2);
+        if (valid && e == 0 && !bnfin) bn.bred[(size_t)c * d.NB + n] = make_float2((float)z1, (float)z2);
     }
     a0 = group_sum(a0, d.E, red[0]);
     a1 = group_sum(a1, d.E, red[1]);
     a2 = group_sum(a2, d.E, red[2]);
     if (valid && e == 0) {
-        const size_t at = (size_t)c * 3 * d.NB + n;
+        const size_t at = (size_t)c * (bnfin ? 5 : 3) * d.NB + n;
         if constexpr (FUSED) {
             dma::fin_publish(fin, at, (float)a0);
             dma::fin_publish(fin, at + d.NB, (float)a1);
             dma::fin_publish(fin, at + 2 * d.NB, (float)a2);
+            if (bnfin) {
+                dma::fin_publish(fin, at + 3 * (size_t)d.NB, (float)z1);
+                dma::fin_publish(fin, at + 4 * (size_t)d.NB, (float)z2);
+            }
         } else {
             part[at] = a0;
             part[at + d.NB] = a1;
@@ -540,13 +562,15 @@ int forward_bnT(const void* x_, const float* taps, const float* ab, void* y_, in
 template <typename T>
 int backward_bnT(const void* gy_, const void* x_, const float* taps, const float* ab, const float* mean, const float* invstd,
                  void* dz_, float* gtaps, void* bred, int NT, int S, int C, int HW, void* ws, size_t ws_bytes,
-                 rk_stream_t stream_) {
+                 rk_stream_t stream_, float* k12 = nullptr, float* dgamma = nullptr, float* dbeta = nullptr) {
     const T* gy = (const T*)gy_; const T* x = (const T*)x_; T* dz = (T*)dz_;
-    if (!gy || !x || !taps || !ab || !mean || !invstd || !dz || !gtaps || !bred) return RK_ERR_NULL_POINTER;
+    if (!gy || !x || !taps || !ab || !mean || !invstd || !dz || !gtaps) return RK_ERR_NULL_POINTER;
+    if (k12 ? (!dgamma || !dbeta) : !bred) return RK_ERR_NULL_POINTER;
     if (HW <= 0 || S <= 0) return RK_ERR_BAD_DIMS;
-    if (!ws || ws_bytes < rk_tshift3_backward_workspace_bytes(NT, S, C, HW)) return RK_ERR_WORKSPACE;
+    const size_t need = rk_tshift3_backward_workspace_bytes(NT, S, C, HW);
+    if (!ws || ws_bytes < (k12 ? need / 3 * 5 : need)) return RK_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    const BnBwdT bn{ab, mean, invstd, (float2*)bred};
+    const BnBwdT bn{ab, mean, invstd, (float2*)bred, k12, dgamma, dbeta, (float)(1.0 / ((double)NT * HW))};
     switch (pick_vec<T>(HW, gy, x, dz)) {
         case 8: if constexpr (max_vec<T>() >= 8) return bwd_bn_launch<T, 8>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
         case 4: return bwd_bn_launch<T, 4>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
@@ -601,6 +625,26 @@ int rk_tshift3_bn_backward_bf16(const void* gy, const void* x, const float* taps
                                 void* ws, size_t ws_bytes, rk_stream_t stream) {
     return backward_bnT<__hip_bfloat16>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, bred, NT, S, C, HW, ws, ws_bytes,
                                         stream);
+}
+
+// The same with BatchNorm's backward constants finished inside the launch (no bred, no rk_bn_bwd_finish_tiles_f32): k12 [2][C] =
+// (sum dz, sum dz xhat) / (NT HW), dgamma / dbeta [C]; workspace of rk_tshift3_bn_backward_fin_workspace_bytes() bytes.
+size_t rk_tshift3_bn_backward_fin_workspace_bytes(int NT, int S, int C, int HW) {
+    return rk_tshift3_backward_workspace_bytes(NT, S, C, HW) / 3 * 5;
+}
+int rk_tshift3_bn_backward_fin_f32(const float* gy, const float* x, const float* taps, const float* ab, const float* save_mean,
+                                   const float* save_invstd, float* dz, float* gtaps, float* k12, float* dgamma, float* dbeta,
+                                   int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!k12) return RK_ERR_NULL_POINTER;
+    return backward_bnT<float>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, nullptr, NT, S, C, HW, ws, ws_bytes, stream,
+                               k12, dgamma, dbeta);
+}
+int rk_tshift3_bn_backward_fin_bf16(const void* gy, const void* x, const float* taps, const float* ab, const float* save_mean,
+                                    const float* save_invstd, void* dz, float* gtaps, float* k12, float* dgamma, float* dbeta,
+                                    int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!k12) return RK_ERR_NULL_POINTER;
+    return backward_bnT<__hip_bfloat16>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, nullptr, NT, S, C, HW, ws, ws_bytes,
+                                        stream, k12, dgamma, dbeta);
 }
 
 int rk_soft_taps_forward_f32(const float* weight, const float* T, float* taps, int C, rk_stream_t stream) {

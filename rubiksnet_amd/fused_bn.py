@@ -194,20 +194,19 @@ class _BNReLUTShiftTrain(torch.autograd.Function):
                 dskip = dskip.to(x.dtype)
         dz = torch.empty_like(x)
         gtaps = torch.empty_like(taps32)
-        bred = torch.empty(C, Fr // S, 2, dtype=torch.float32, device=dev)
         k12 = torch.empty(2, C, dtype=torch.float32, device=dev)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            nb = int(L.rk_tshift3_backward_workspace_bytes(Fr, S, C, P))
+            # (BatchNorm's two sums ride as granules next to the tap sums and are finished by the same finalizer waves: no
+            # rk_bn_bwd_finish_tiles launch)
+            nb = int(L.rk_tshift3_bn_backward_fin_workspace_bytes(Fr, S, C, P))
             ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
-            _native.check(getattr(L, "rk_tshift3_bn_backward_" + sfx)(
+            _native.check(getattr(L, "rk_tshift3_bn_backward_fin_" + sfx)(
                 gy.data_ptr(), x.data_ptr(), taps32.data_ptr(), ab.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
-                dz.data_ptr(), gtaps.data_ptr(), bred.data_ptr(), Fr, S, C, P, ws.data_ptr(), nb, stream),
-                "rk_tshift3_bn_backward")
-            _native.check(L.rk_bn_bwd_finish_tiles_f32(bred.data_ptr(), Fr // S, Fr * P, k12.data_ptr(), dgamma.data_ptr(),
-                                                       dbeta.data_ptr(), C, stream), "rk_bn_bwd_finish_tiles_f32")
+                dz.data_ptr(), gtaps.data_ptr(), k12.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, S, C, P, ws.data_ptr(),
+                nb, stream), "rk_tshift3_bn_backward_fin")
             _native.check(getattr(L, "rk_bn_bwd_dx_pre_" + sfx)(
                 dz.data_ptr(), x.data_ptr(), weight.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), k12.data_ptr(),
                 _ptr(dskip), dz.data_ptr(), Fr, C, P, stream), "rk_bn_bwd_dx_pre")            # in place: dz -> d(x)
