@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "rk_common.hpp"
 #include "rk_dma.hpp"
+#include "rk_reduce.hpp"
 
 namespace rk {
 namespace pw16 {
@@ -712,7 +713,8 @@ int rk_pw_wgrad16_bf16(const void* dY_, const void* X_, float* dW, int F, int K,
     else rc = launch_wgrad<3, 3>(dY, X, (float*)ws, d, stream);
     if (rc) return rc;
     const int MK = M * K;
-    hipLaunchKernelGGL(k_pw16_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
+    if (!launch_reduce_partials4((const float*)ws, dW, MK, d.S, stream))
+        hipLaunchKernelGGL(k_pw16_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
     return launch_status();
 }
 

@@ -22,6 +22,7 @@
 // Arithmetic as rk_pw16.hip: bf16 operands, fp32 accumulation (v_mfma_f32_16x16x32_bf16), one rounding of the result.
 #include <type_traits>
 #include "rk_common.hpp"
+#include "rk_reduce.hpp"
 
 namespace rk {
 namespace pw16odd {
@@ -422,7 +423,8 @@ int rk_pw_wgrad_odd16_bf16(const void* dY_, const void* X_, float* dW, int F, in
     else rc = launch_wgrad<3, 3>(dY, X, (float*)ws, d, stream);
     if (rc) return rc;
     const int MK = M * K;
-    hipLaunchKernelGGL(k_pw16_odd_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
+    if (!launch_reduce_partials4((const float*)ws, dW, MK, d.S, stream))
+        hipLaunchKernelGGL(k_pw16_odd_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
     return launch_status();
 }
 

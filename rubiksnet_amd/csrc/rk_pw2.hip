@@ -28,6 +28,7 @@
 #include "rk_common.hpp"
 #include "rk_dma.hpp"
 #include "rk_pw2.hpp"
+#include "rk_reduce.hpp"
 
 namespace rk {
 namespace pw2 {
@@ -852,7 +853,8 @@ int wgrad(const float* dY, const float* X, float* dW, int F, int K, int M, int P
     d.ka = ka; d.kb = kb; d.relu_in = relu_in;
     if (int rc = launch_wgrad(c.id, c.ns, ka && kb, dY, X, (float*)ws, d, stream)) return rc;
     const int MK = M * K;
-    hipLaunchKernelGGL(k_pw2_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
+    if (!launch_reduce_partials4((const float*)ws, dW, MK, d.S, stream))
+        hipLaunchKernelGGL(k_pw2_reduce, dim3((MK + 63) / 64), dim3(kBlock), 0, stream, (const float*)ws, dW, MK, d.S);
     return launch_status();
 }
 
