@@ -252,6 +252,20 @@ int rk_tshift3_bn_backward_fin_bf16(const void* gy, const void* x, const float* 
                                     const float* save_invstd, void* dz, float* gtaps, float* k12, float* dgamma, float* dbeta,
                                     int NT, int S, int C, int HW, void* ws, size_t ws_bytes, rk_stream_t stream);
 
+/* Downsampling -aq blocks (the activation also feeds the stride-2 projecting shortcut, backbone.py:98-104): the shortcut reads
+ * rk_bn_relu_gather2_* (relu(a x + b) at the even pixels, ab = [2][C]); its gradient gsmall [NT, C, H/2, W/2] joins
+ * d(activation) inside the temporal filter's backward, before the ReLU mask and BatchNorm's sums. */
+int rk_bn_relu_gather2_f32(const float* x, const float* ab, float* xs, int F, int C, int H, int W, rk_stream_t stream);
+int rk_bn_relu_gather2_bf16(const void* x, const float* ab, void* xs, int F, int C, int H, int W, rk_stream_t stream);
+int rk_tshift3_bn_backward_fork_f32(const float* gy, const float* x, const float* taps, const float* ab, const float* save_mean,
+                                    const float* save_invstd, const float* gsmall, float* dz, float* gtaps, float* k12,
+                                    float* dgamma, float* dbeta, int NT, int S, int C, int H, int W, void* ws, size_t ws_bytes,
+                                    rk_stream_t stream);
+int rk_tshift3_bn_backward_fork_bf16(const void* gy, const void* x, const float* taps, const float* ab, const float* save_mean,
+                                     const float* save_invstd, const void* gsmall, void* dz, float* gtaps, float* k12,
+                                     float* dgamma, float* dbeta, int NT, int S, int C, int H, int W, void* ws, size_t ws_bytes,
+                                     rk_stream_t stream);
+
 /* The [C,3] half of AttentionShift (attention_shift.py:29-30): taps = softmax((weight / (std(weight, dim=1) + 1e-6)) / T)
  * over the three taps of a channel (std unbiased), and its backward (gweight from gtaps).  fp32; T is the module's
  * one-element device tensor (no host read); one launch each instead of ~15 + ~25 PyTorch kernels per layer. */

@@ -47,6 +47,10 @@ SIGNATURES = {
     "rk_tshift3_bn_forward_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rk_tshift3_bn_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_tshift3_bn_backward_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "rk_bn_relu_gather2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_bn_relu_gather2_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "rk_tshift3_bn_backward_fork_f32": (_i, [_p] * 12 + [_i] * 5 + [_p, _sz, _p]),
+    "rk_tshift3_bn_backward_fork_bf16": (_i, [_p] * 12 + [_i] * 5 + [_p, _sz, _p]),
     "rk_tshift3_bn_backward_fin_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rk_tshift3_bn_backward_fin_f32": (_i, [_p] * 11 + [_i, _i, _i, _i, _p, _sz, _p]),
     "rk_tshift3_bn_backward_fin_bf16": (_i, [_p] * 11 + [_i, _i, _i, _i, _p, _sz, _p]),

@@ -12,8 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import _native, config
-from .fused_bn import bn_relu, bn_relu_shift2d, bn_relu_skip, bn_relu_tshift_skip
-from .pointwise import all_frozen, conv1x1, fork_shortcut, fused_eval_block, stem_conv
+from .fused_bn import bn_relu, bn_relu_shift2d, bn_relu_skip, bn_relu_tshift_fork, bn_relu_tshift_skip
+from .pointwise import _gathered_kind, all_frozen, conv1x1, conv_on_gathered, fork_shortcut, fused_eval_block, stem_conv
 from .shiftlib import RubiksShift2D, RubiksShiftBase
 from .train_block import bn_relu_from_stats, fused_train_block
 
@@ -172,6 +172,22 @@ class RubiksShiftBlock(nn.Module):
             # relu(bn(.)) as one operator on GPU tensors (fused_bn.py); the shortcut's gradient joins inside its backward
             out, shortcut = bn_relu_skip(self.bn1, x)
         else:
+            if (self.training and isinstance(self.conv2, nn.Sequential) and len(self.conv2) == 2 and x.dim() == 4
+                    and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+                # downsampling -aq block: bn1 + ReLU inside the AttentionShift, the shortcut's operand gathered from x, the
+                # shortcut's gradient joined inside the filter's backward (fused_bn.bn_relu_tshift_fork)
+                kind = _gathered_kind(self.shortcut, x.shape[0], (x.shape[2] // 2) * (x.shape[3] // 2), x.dtype)
+                r = bn_relu_tshift_fork(self.bn1, self.conv2[0], x) if kind is not None else None
+                if r is not None:
+                    out, xs = r
+                    shortcut = conv_on_gathered(self.shortcut, xs, kind)
+                    z2 = conv1x1(self.conv2[1], out)
+                    out = bn_relu_shift2d(self.bn2, self.as3, z2)
+                    if out is None:
+                        out = self.as3(bn_relu(self.bn2, z2))
+                    if self.se:
+                        out = self.se(out)
+                    return conv1x1(self.conv3, out, residual=shortcut)
             out = bn_relu(self.bn1, x)
             # (stride-2 projecting shortcut on bf16 activations: one autograd node for the two consumers of `out`, their
             # gradients joined in one pass)

@@ -35,6 +35,7 @@ class Switches:
     pw16_stats: bool = False
     bn_shift2d: bool = True
     prepack: bool = True
+    bn_tshift_fork: bool = True
 
     @staticmethod
     def from_env(env=None):
@@ -48,7 +49,8 @@ class Switches:
                         wgrad_overlap=env.get("RK_WGRAD_OVERLAP", "1") != "0",
                         pw16_stats=env.get("RK_PW16_STATS", "0") == "1",
                         bn_shift2d=env.get("RK_BN_SHIFT2D", "1") != "0",
-                        prepack=env.get("RK_PREPACK", "1") != "0")
+                        prepack=env.get("RK_PREPACK", "1") != "0",
+                        bn_tshift_fork=env.get("RK_BN_TSHIFT_FORK", "1") != "0")
 
 
 _current = Switches.from_env()

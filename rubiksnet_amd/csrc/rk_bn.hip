@@ -802,6 +802,23 @@ int bn_bwd_dx_pre(const T* dz, const T* x, const float* gamma, const float* save
     return launch_status();
 }
 
+// xs[f][c][ho][wo] = relu(a[c] x[f][c][2 ho][2 wo] + b[c]) rounded to the storage type: the activation of a downsampling block
+// at the pixels its stride-2 projecting shortcut reads (fused_bn.bn_relu_tshift_fork: the full-size activation is never stored)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bn_relu_gather2(const T* __restrict__ x, const float* __restrict__ ab, T* __restrict__ xs,
+                                                            long long total, int C, int H, int W) {
+    const long long o = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= total) return;
+    const int Wo = W / 2, Ho = H / 2;
+    const int wo = (int)(o % Wo);
+    const long long r = o / Wo;
+    const int ho = (int)(r % Ho);
+    const long long p = r / Ho;                                      // (f, c) plane
+    const int c = (int)(p % C);
+    const float v = fmaf(ab[c], ld(x + (p * H + 2 * ho) * W + 2 * wo), ab[C + c]);
+    st(xs + o, fmaxf(v, 0.f));
+}
+
 }  // namespace bn
 }  // namespace rk
 
@@ -822,7 +839,27 @@ static int bn_apply_affine(const T* x, const float* a, const float* b, T* y, int
     return launch_status();
 }
 
+template <typename T>
+static int bn_relu_gather2(const void* x, const float* ab, void* xs, int F, int C, int H, int W, rk_stream_t stream) {
+    if (!x || !ab || !xs) return RK_ERR_NULL_POINTER;
+    if (F <= 0 || C <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return RK_ERR_BAD_DIMS;
+    const long long total = (long long)F * C * (H / 2) * (W / 2);
+    const long long blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL((k_bn_relu_gather2<T>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (const T*)x, ab, (T*)xs,
+                       total, C, H, W);
+    return launch_status();
+}
+
 extern "C" {
+
+// xs [F, C, H/2, W/2] = relu(a x + b) at the even pixels of x [F, C, H, W]; ab = [2][C] (rk_bn_stats_finish_*)
+int rk_bn_relu_gather2_f32(const float* x, const float* ab, float* xs, int F, int C, int H, int W, rk_stream_t stream) {
+    return bn_relu_gather2<float>(x, ab, xs, F, C, H, W, stream);
+}
+int rk_bn_relu_gather2_bf16(const void* x, const float* ab, void* xs, int F, int C, int H, int W, rk_stream_t stream) {
+    return bn_relu_gather2<__hip_bfloat16>(x, ab, xs, F, C, H, W, stream);
+}
 
 size_t rk_bn_workspace_bytes(int F, int C, int P) {
     BnDims d;

@@ -191,16 +191,21 @@ struct BnBwdT {
     float* k12;                 // [2][C] or nullptr: BatchNorm's backward constants (sum dz, sum dz xhat) / count ...
     float* dgamma; float* dbeta;    // ... and d(gamma), d(beta) [C], written by the finalizer waves (k_bn_bwd_finish_tiles' job)
     float inv_count;            // 1 / (NT H W)
+    const void* gsmall;         // FORK: [NT, C, H/2, W/2] -- a second gradient of the activation, given at its even pixels only
+    int W;                      //       (the projecting shortcut's, pointwise.fork_shortcut); plane width (W % VEC == 0, W even)
 };
-template <typename T, int VEC, bool FUSED, bool BN = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(T) * VEC >= 16 ? 3 : 4)))
+// FORK (with BN; downsampling blocks): the activation also feeds the stride-2 projecting shortcut, whose gradient -- a quarter-
+// size tensor, the even pixels -- joins d(activation) here, BEFORE the ReLU mask and BatchNorm's sums (unfused: zeros + scatter
+// + add + k_bn_bwd_reduce + k_bn_bwd_dx over the full-size tensor).
+template <typename T, int VEC, bool FUSED, bool BN = false, bool FORK = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(T) * VEC >= 16 || FORK ? 3 : 4)))
 void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                              const typename Compute<T>::type* __restrict__ taps,
                                                              T* __restrict__ gx,
                                                              typename Compute<T>::type* __restrict__ part, DimsT d,
                                                              dma::Fin fin, typename Compute<T>::type* __restrict__ gtaps,
                                                              BnBwdT bn = BnBwdT{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                                                nullptr, 0.f}) {
+                                                                                nullptr, 0.f, nullptr, 0}) {
     using CT = typename Compute<T>::type;
     __shared__ CT red[BN ? 5 : 3][kBlock / kWave];
     if constexpr (FUSED) {
@@ -267,6 +272,26 @@ void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
             T* op = gx + base + i;
             CT xprev[VEC], xcur[VEC], xnxt[VEC], gprev[VEC], gcur[VEC], gnxt[VEC], out[VEC];
             CT hcur[VEC], hnxt[VEC];                      // BN: xhat of the current / next time step
+            // FORK: this pack's even elements have a partner in the small gradient when its row is even
+            constexpr int HV = VEC >= 2 ? VEC / 2 : 1;
+            bool fork_row = false;
+            const T* gsp = nullptr;
+            if constexpr (FORK && VEC >= 2) {
+                const int h = i / bn.W, w = i - h * bn.W;
+                fork_row = (h & 1) == 0;
+                gsp = (const T*)bn.gsmall + ((size_t)n * d.S * d.C + c) * (size_t)(d.HW / 4) + (size_t)(h >> 1) * (bn.W >> 1) + (w >> 1);
+            }
+            const size_t sstride = (size_t)d.C * (d.HW / 4);
+            auto join = [&](CT (&o)[VEC], const Pack<T, HV>& sp) {
+                if constexpr (FORK && VEC >= 2) {
+                    if (fork_row) {
+                        CT sv[HV];
+                        unpack<T, HV>(sp, sv);
+#pragma unroll
+                        for (int k = 0; k < HV; ++k) o[2 * k] += sv[k];
+                    }
+                }
+            };
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { hcur[k] = 0; hnxt[k] = 0; }
 #pragma unroll
@@ -281,6 +306,13 @@ void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                 for (int t = 0; t < kSeg; ++t) {
                     gr[t] = load_stream<T, VEC, RK_TS_NT_BWD>(gp + (size_t)t * tstride);
                     xr[t] = load_stream<T, VEC, RK_TS_NT_BWD>(xp + (size_t)t * tstride);
+                }
+                // (FORK: the small gradient's packs are requested two steps ahead, not all up front: with 8 more packs live the
+                // 16-byte form spilled 650 bytes per lane)
+                Pack<T, HV> sr[3];
+                if constexpr (FORK && VEC >= 2) {
+                    sr[0] = load_raw<T, HV>(fork_row ? gsp : (const T*)bn.gsmall);
+                    sr[1] = load_raw<T, HV>(fork_row ? gsp + sstride : (const T*)bn.gsmall);
                 }
                 pin(gr[0]);
                 unpack<T, VEC>(gr[0], gcur);
@@ -310,6 +342,10 @@ void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                         a1 += gcur[k] * xcur[k];
                         a2 += gprev[k] * xcur[k];
                     }
+                    if constexpr (FORK && VEC >= 2) {
+                        if (t + 2 < kSeg) sr[(t + 2) % 3] = load_raw<T, HV>(fork_row ? gsp + (size_t)(t + 2) * sstride : (const T*)bn.gsmall);
+                        join(out, sr[t % 3]);
+                    }
                     mask(out, xcur, hcur);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) { gprev[k] = gcur[k]; gcur[k] = gnxt[k]; }
@@ -336,6 +372,9 @@ void k_tshift3_backward(const T* __restrict__ gy, const T* __restrict__ x,
                     a0 += gcur[k] * xprev[k];
                     a1 += gcur[k] * xcur[k];
                     a2 += gcur[k] * xnxt[k];
+                }
+                if constexpr (FORK && VEC >= 2) {
+                    if (fork_row) join(out, load_raw<T, HV>(gsp + (size_t)t * sstride));
                 }
                 mask(out, xcur, hcur);
 #pragma unroll
@@ -541,8 +580,15 @@ int bwd_bn_launch(const T* gy, const T* x, const float* taps, const BnBwdT& bn, 
     fin.gran = reinterpret_cast<unsigned long long*>(ws);
     fin.tag = dma::next_launch_tag();
     fin.producers = (int)gridT(d);
-    hipLaunchKernelGGL((k_tshift3_backward<T, VEC, true, true>), dim3(gridT(d) + C), dim3(kBlock), 0, stream, gy, x, taps, dz,
-                       (float*)ws, d, fin, gtaps, bn);
+    if (bn.gsmall) {
+        if constexpr (VEC >= 2)
+            hipLaunchKernelGGL((k_tshift3_backward<T, VEC, true, true, true>), dim3(gridT(d) + C), dim3(kBlock), 0, stream, gy, x,
+                               taps, dz, (float*)ws, d, fin, gtaps, bn);
+        else return RK_ERR_UNSUPPORTED;
+    } else {
+        hipLaunchKernelGGL((k_tshift3_backward<T, VEC, true, true>), dim3(gridT(d) + C), dim3(kBlock), 0, stream, gy, x, taps, dz,
+                           (float*)ws, d, fin, gtaps, bn);
+    }
     return launch_status();
 }
 template <typename T>
@@ -562,7 +608,8 @@ int forward_bnT(const void* x_, const float* taps, const float* ab, void* y_, in
 template <typename T>
 int backward_bnT(const void* gy_, const void* x_, const float* taps, const float* ab, const float* mean, const float* invstd,
                  void* dz_, float* gtaps, void* bred, int NT, int S, int C, int HW, void* ws, size_t ws_bytes,
-                 rk_stream_t stream_, float* k12 = nullptr, float* dgamma = nullptr, float* dbeta = nullptr) {
+                 rk_stream_t stream_, float* k12 = nullptr, float* dgamma = nullptr, float* dbeta = nullptr,
+                 const void* gsmall = nullptr, int W = 0) {
     const T* gy = (const T*)gy_; const T* x = (const T*)x_; T* dz = (T*)dz_;
     if (!gy || !x || !taps || !ab || !mean || !invstd || !dz || !gtaps) return RK_ERR_NULL_POINTER;
     if (k12 ? (!dgamma || !dbeta) : !bred) return RK_ERR_NULL_POINTER;
@@ -570,8 +617,17 @@ int backward_bnT(const void* gy_, const void* x_, const float* taps, const float
     const size_t need = rk_tshift3_backward_workspace_bytes(NT, S, C, HW);
     if (!ws || ws_bytes < (k12 ? need / 3 * 5 : need)) return RK_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    const BnBwdT bn{ab, mean, invstd, (float2*)bred, k12, dgamma, dbeta, (float)(1.0 / ((double)NT * HW))};
-    switch (pick_vec<T>(HW, gy, x, dz)) {
+    const BnBwdT bn{ab, mean, invstd, (float2*)bred, k12, dgamma, dbeta, (float)(1.0 / ((double)NT * HW)), gsmall, W};
+    int vec = pick_vec<T>(HW, gy, x, dz);
+    if (gsmall) {                                               // a pack inside one row, its even elements at even columns
+        if (W <= 0 || W % 2 || HW % W || (HW / W) % 2) return RK_ERR_BAD_DIMS;
+        // (16-bit storage: 4 elements per pack at most -- the 8-element FORK instance compiles to 570 bytes of scratch per lane
+        // whatever the register budget)
+        if (sizeof(T) == 2 && vec > 4) vec = 4;
+        while (vec > 1 && (W % vec != 0 || ((uintptr_t)gsmall % ((vec / 2) * sizeof(T))) != 0)) vec >>= 1;
+        if (vec < 2) return RK_ERR_UNSUPPORTED;
+    }
+    switch (vec) {
         case 8: if constexpr (max_vec<T>() >= 8) return bwd_bn_launch<T, 8>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
         case 4: return bwd_bn_launch<T, 4>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
         case 2: return bwd_bn_launch<T, 2>(gy, x, taps, bn, dz, gtaps, NT, S, C, HW, ws, stream);
@@ -645,6 +701,25 @@ int rk_tshift3_bn_backward_fin_bf16(const void* gy, const void* x, const float* 
     if (!k12) return RK_ERR_NULL_POINTER;
     return backward_bnT<__hip_bfloat16>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, nullptr, NT, S, C, HW, ws, ws_bytes,
                                         stream, k12, dgamma, dbeta);
+}
+
+// ... and with a second gradient of the activation joined before the ReLU mask: gsmall [NT, C, H/2, W/2] = the gradient of
+// the activation's even pixels (the stride-2 projecting shortcut of a downsampling block); W = the plane's width (even, H even)
+int rk_tshift3_bn_backward_fork_f32(const float* gy, const float* x, const float* taps, const float* ab, const float* save_mean,
+                                    const float* save_invstd, const float* gsmall, float* dz, float* gtaps, float* k12,
+                                    float* dgamma, float* dbeta, int NT, int S, int C, int H, int W, void* ws, size_t ws_bytes,
+                                    rk_stream_t stream) {
+    if (!k12 || !gsmall) return RK_ERR_NULL_POINTER;
+    return backward_bnT<float>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, nullptr, NT, S, C, H * W, ws, ws_bytes, stream,
+                               k12, dgamma, dbeta, gsmall, W);
+}
+int rk_tshift3_bn_backward_fork_bf16(const void* gy, const void* x, const float* taps, const float* ab, const float* save_mean,
+                                     const float* save_invstd, const void* gsmall, void* dz, float* gtaps, float* k12,
+                                     float* dgamma, float* dbeta, int NT, int S, int C, int H, int W, void* ws, size_t ws_bytes,
+                                     rk_stream_t stream) {
+    if (!k12 || !gsmall) return RK_ERR_NULL_POINTER;
+    return backward_bnT<__hip_bfloat16>(gy, x, taps, ab, save_mean, save_invstd, dz, gtaps, nullptr, NT, S, C, H * W, ws, ws_bytes,
+                                        stream, k12, dgamma, dbeta, gsmall, W);
 }
 
 int rk_soft_taps_forward_f32(const float* weight, const float* T, float* taps, int C, rk_stream_t stream) {

@@ -233,6 +233,109 @@ def bn_relu_tshift_skip(bn, shift, x):
                                     take_stats(x))
 
 
+class _BNReLUTShiftForkTrain(torch.autograd.Function):
+    """(tshift3(relu(batch_norm(x)), taps), relu(batch_norm(x))[:, :, ::2, ::2]): a DOWNSAMPLING -aq block's bn1 + ReLU, whose
+    activation feeds the AttentionShift in front of conv2 AND the stride-2 projecting shortcut (backbone.py:98-104, :129).  As
+    _BNReLUTShiftTrain, with the shortcut's operand gathered by rk_bn_relu_gather2_* (the full-size activation is never stored)
+    and its gradient -- quarter size -- joined to d(activation) INSIDE the filter's backward, before the ReLU mask and
+    BatchNorm's sums (rk_tshift3_bn_backward_fork_*).  Unfused this block ran normalise + reduce + d(x) passes, and zeros +
+    scatter + add for the shortcut's gradient, all over the full-size tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, taps, running_mean, running_var, momentum, eps, n_segment, counter_ptr, stats=None):
+        L = _native.lib()
+        Fr, C, H, W = x.shape
+        P = H * W
+        dev = x.device
+        sfx = _SFX[x.dtype]
+        taps32 = taps.detach().float().contiguous()
+        y = torch.empty_like(x)
+        xs = torch.empty(Fr, C, H // 2, W // 2, dtype=x.dtype, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if stats is not None:
+                fin = _finish_tiles(L, stats, Fr * P, weight, bias, running_mean, running_var, momentum, eps, counter_ptr, dev,
+                                    stream)
+                save_mean, save_invstd, ab = fin[0], fin[1], fin[2:4]
+            else:
+                save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+                save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+                ws, nbytes = _ws(L, Fr, C, P, dev)
+                _native.check(getattr(L, "rk_bn_stats_finish_" + sfx)(
+                    x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var), save_mean.data_ptr(),
+                    save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(),
+                    nbytes, stream), "rk_bn_stats_finish")
+            _native.check(getattr(L, "rk_tshift3_bn_forward_" + sfx)(
+                x.data_ptr(), taps32.data_ptr(), ab.data_ptr(), y.data_ptr(), Fr, n_segment, C, P, stream),
+                "rk_tshift3_bn_forward")
+            _native.check(getattr(L, "rk_bn_relu_gather2_" + sfx)(x.data_ptr(), ab.data_ptr(), xs.data_ptr(), Fr, C, H, W, stream),
+                          "rk_bn_relu_gather2")
+        ctx.save_for_backward(x, weight, bias, taps32, save_mean, save_invstd, ab)
+        ctx.n_segment = n_segment
+        ctx.taps_dtype = taps.dtype
+        return y, xs
+
+    @staticmethod
+    def backward(ctx, gy, gxs):
+        x, weight, bias, taps32, save_mean, save_invstd, ab = ctx.saved_tensors
+        L = _native.lib()
+        Fr, C, H, W = x.shape
+        P = H * W
+        S = ctx.n_segment
+        dev = x.device
+        sfx = _SFX[x.dtype]
+        if gy is None:
+            gy = torch.zeros_like(x)
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        if gxs is None:
+            gxs = torch.zeros(Fr, C, H // 2, W // 2, dtype=x.dtype, device=dev)
+        gxs = gxs.contiguous()
+        if gxs.dtype != x.dtype:
+            gxs = gxs.to(x.dtype)
+        dz = torch.empty_like(x)
+        gtaps = torch.empty_like(taps32)
+        k12 = torch.empty(2, C, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nb = int(L.rk_tshift3_bn_backward_fin_workspace_bytes(Fr, S, C, P))
+            ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+            _native.check(getattr(L, "rk_tshift3_bn_backward_fork_" + sfx)(
+                gy.data_ptr(), x.data_ptr(), taps32.data_ptr(), ab.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
+                gxs.data_ptr(), dz.data_ptr(), gtaps.data_ptr(), k12.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), Fr, S, C, H, W,
+                ws.data_ptr(), nb, stream), "rk_tshift3_bn_backward_fork")
+            _native.check(getattr(L, "rk_bn_bwd_dx_pre_" + sfx)(
+                dz.data_ptr(), x.data_ptr(), weight.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), k12.data_ptr(),
+                None, dz.data_ptr(), Fr, C, P, stream), "rk_bn_bwd_dx_pre")                       # in place: dz -> d(x)
+        return (dz, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gtaps.to(ctx.taps_dtype), None, None, None, None, None, None,
+                None)
+
+
+def bn_relu_tshift_fork(bn, shift, x):
+    """(`shift(relu(bn(x)))`, `relu(bn(x))[:, :, ::2, ::2]`) for a downsampling -aq block in training mode (`shift`: the block's
+    AttentionShift; the second element is what the stride-2 projecting shortcut reads).  None when it does not apply."""
+    sw = config.switches()
+    if not (sw.fused_train and sw.bn_tshift_fork and _fusable(bn, x) and bn.training and torch.is_grad_enabled()):
+        return None
+    w = getattr(shift, "weight", None)
+    S = getattr(shift, "n_segment", 0)
+    H, W = x.shape[2], x.shape[3]
+    if (w is None or not w.is_cuda or w.dim() != 2 or w.shape != (x.shape[1], 3) or S <= 0 or x.shape[0] % S
+            or bn.num_features != x.shape[1] or H % 2 or W % 2 or x.data_ptr() % 16):
+        return None
+    # the widest pack with W % pack == 0 must hold at least 2 elements (always, W is even) and stay inside the operand's limits
+    x = x.contiguous()
+    momentum, counter = _count_batch(bn)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNReLUTShiftForkTrain.apply(x, bn.weight, bn.bias, shift.soft_taps(), rm, rv, momentum, bn.eps, S, _ptr(counter),
+                                        take_stats(x))
+
+
 class _BNReLUShift2DTrain(torch.autograd.Function):
     """shift2d(relu(batch_norm(z))): the -aq block's training-mode bn2 + ReLU folded into the RubiksShift2D that consumes
     it (rk2d_*_bn_*): the activation is never stored.  Forward = statistics pass + ONE shift pass (instead of statistics,

@@ -543,26 +543,40 @@ class _ForkS2(torch.autograd.Function):
         return out
 
 
+def _gathered_kind(conv, Fr, P, dtype, device_ok=True):
+    """Which HIP kernels run the stride-2 projecting shortcut `conv` on its GATHERED operand [Fr, K, P]: "pw16" / "odd16" / None."""
+    if not (pointwise_mode() != "0" and dtype == torch.bfloat16
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.weight.is_cuda):
+        return None
+    K, M = conv.in_channels, conv.out_channels
+    L = _native.lib()
+    if P % 4 == 0 and P >= 8 and K % 2 == 0 and M % 2 == 0 and _pw16_fits(Fr, max(K, M), P):
+        return "pw16"
+    if P % 4 != 0 and L.rk_pw_odd16_supported(Fr, K, M, P) and L.rk_pw_odd16_supported(Fr, M, K, P):
+        return "odd16"
+    return None
+
+
+def conv_on_gathered(conv, xs, kind):
+    """The stride-2 shortcut `conv` applied to its already gathered operand xs = x[:, :, ::2, ::2] (kind: _gathered_kind)."""
+    if kind == "pw16":
+        return _Conv1x1Func.apply(xs, conv.weight, True, None, True)
+    return _Conv1x1Odd16Func.apply(xs, conv.weight, None, 1)
+
+
 def fork_shortcut(conv, x):
     """`(x', conv(x))` for the stride-2 projecting shortcut `conv` of a downsampling block whose activation x also feeds the
     main path: the caller continues with x' (an autograd alias of x).  bf16 activations on the HIP kernels; otherwise
     `(x, conv1x1(conv, x))`."""
-    ok = (pointwise_mode() != "0" and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.bfloat16
-          and x.dim() == 4 and x.is_contiguous() and x.numel() > 0 and x.data_ptr() % 16 == 0
-          and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-          and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (2, 2)
-          and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
-          and conv.weight.is_cuda)
+    ok = (torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+          and x.data_ptr() % 16 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
     if ok:
-        Fr, K, M = x.shape[0], conv.in_channels, conv.out_channels
-        P = (x.shape[2] // 2) * (x.shape[3] // 2)
-        L = _native.lib()
-        if P % 4 == 0 and P >= 8 and K % 2 == 0 and M % 2 == 0 and _pw16_fits(Fr, max(K, M), P):
+        kind = _gathered_kind(conv, x.shape[0], (x.shape[2] // 2) * (x.shape[3] // 2), x.dtype)
+        if kind is not None:
             x_main, xs = _ForkS2.apply(x)
-            return x_main, _Conv1x1Func.apply(xs, conv.weight, True, None, True)
-        if P % 4 != 0 and L.rk_pw_odd16_supported(Fr, K, M, P) and L.rk_pw_odd16_supported(Fr, M, K, P):
-            x_main, xs = _ForkS2.apply(x)
-            return x_main, _Conv1x1Odd16Func.apply(xs, conv.weight, None, 1)
+            return x_main, conv_on_gathered(conv, xs, kind)
     return x, conv1x1(conv, x)
 
 

@@ -309,3 +309,43 @@ def test_bf16_dx_pass_is_the_fp32_expression_rounded_once(shape, inplace, skip):
                                           torch.cuda.current_stream().cuda_stream), "dx_pre (unaligned)")
     torch.cuda.synchronize()
     assert torch.equal(out1, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(16, 24, 28, 28, 8), (8, 72, 56, 56, 8), (16, 40, 14, 14, 8), (8, 12, 6, 10, 4), (16, 6, 112, 112, 8)])
+def test_bn_relu_folded_into_the_temporal_filter_of_a_downsampling_block(dtype, shape):
+    """bn_relu_tshift_fork (a downsampling -aq block: the activation feeds the AttentionShift AND the stride-2 projecting shortcut;
+    rk_bn_relu_gather2_*, rk_tshift3_bn_backward_fork_*) against the unfused chain bn_relu -> (AttentionShift, [:, :, ::2, ::2]):
+    both outputs, every gradient, running statistics."""
+    from rubiksnet_amd.attention_shift import AttentionShift
+    from rubiksnet_amd.fused_bn import bn_relu, bn_relu_tshift_fork
+
+    NT, C, H, W, S = shape
+    torch.manual_seed(sum(shape))
+    x0 = (torch.randn(NT, C, H, W, device="cuda") * 1.5 + 0.3).to(dtype)
+    gy = torch.randn(NT, C, H, W, device="cuda").to(dtype)
+    gs = torch.randn(NT, C, H // 2, W // 2, device="cuda").to(dtype)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        bn = nn.BatchNorm2d(C).cuda().train()
+        shift = AttentionShift(S, C).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            r = bn_relu_tshift_fork(bn, shift, x)
+            assert r is not None
+            y, xs = r
+        else:
+            a = bn_relu(bn, x)
+            y, xs = shift(a), a[:, :, ::2, ::2]
+        torch.autograd.backward([y, xs], [gy, gs])
+        res.append((y.detach().float(), xs.detach().float(), x.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                    shift.weight.grad.clone(), bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    f, u = res
+    assert f[8] == u[8] == 1
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -6        # bf16: the unfused chain rounds the activation and its gradient once more
+    for name, a, b in zip(("y", "xs", "dx", "dgamma", "dbeta", "dtaps", "running_mean", "running_var"), f[:8], u[:8]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=tol * max(1e-3, float(b.abs().max())), err_msg=name)

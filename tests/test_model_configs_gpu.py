@@ -187,6 +187,39 @@ class _Taps:
         monkeypatch.setattr(BT, "forward", staticmethod(btfwd))
         monkeypatch.setattr(BT, "backward", staticmethod(btbwd))
 
+        # downsampling -aq blocks (bf16): the same with the projecting shortcut's operand gathered and its gradient joined inside the
+        # filter's backward (fused_bn._BNReLUTShiftForkTrain): fa_fork / ba_fork
+        from rubiksnet_amd.fused_bn import _BNReLUTShiftForkTrain as BF
+        bff, bfb = BF.forward, BF.backward
+        self.fa_fork, self.ba_fork = {}, {}
+
+        def bffwd(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter, stats=None):
+            out = bff(ctx, x, weight, bias, soft, rm, rv, momentum, eps, n_segment, counter, stats)
+            taps.calls["fa"] += 1
+            key = (tuple(x.shape), x.dtype)
+            if key not in taps.fa_fork:
+                taps.fa_fork[key] = dict(x=x.detach().cpu(), w=weight.detach().cpu(), b=bias.detach().cpu(), soft=soft.detach().cpu(),
+                                         S=int(n_segment), eps=float(eps), y=out[0].detach().cpu(), xs=out[1].detach().cpu())
+            return out
+
+        def bfbwd(ctx, gy, gxs):
+            key = (tuple(gy.shape), ctx.saved_tensors[0].dtype)
+            first = key not in taps.ba_fork
+            if first:
+                sx, sw, sb, ssoft = ctx.saved_tensors[:4]
+                rec = dict(gy=gy.detach().cpu(), gxs=gxs.detach().cpu(), x=sx.detach().cpu(), w=sw.detach().cpu(), b=sb.detach().cpu(),
+                           soft=ssoft.detach().cpu(), S=int(ctx.n_segment))
+            out = bfb(ctx, gy, gxs)
+            taps.calls["ba"] += 1
+            if first:
+                rec.update(dx=out[0].detach().cpu(), dgamma=out[1].detach().cpu(), dbeta=out[2].detach().cpu(),
+                           gsoft=out[3].detach().cpu())
+                taps.ba_fork[key] = rec
+            return out
+
+        monkeypatch.setattr(BF, "forward", staticmethod(bffwd))
+        monkeypatch.setattr(BF, "backward", staticmethod(bfbwd))
+
         # -aq blocks on 14 x 14 planes in training: bn2 + ReLU folded into the 2-D shift (fused_bn._BNReLUShift2DTrain): counted
         # with the plain 2-D calls, recorded separately (f2_bn / b2_bn) with the activation materialised by the stand-alone
         # normalise kernel -- so the checks read "normalise, then the oracle's shift", as for the 3-D fusion above
@@ -425,9 +458,12 @@ def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp)
 
     # AttentionShift sits in front of conv2: block inputs (C, H) = (w,112), (w,56), (2w,28), (4w,14), (8w,7); the blocks
     # with an identity shortcut take the bn1-folded form (fa_bn / ba_bn), the 4 projecting ones the plain filter
-    assert {(k[0][1], k[0][2]) for k in list(taps.fa) + list(taps.fa_bn)} == {(width, 112), (width, 56), (2 * width, 28),
-                                                                               (4 * width, 14), (8 * width, 7)}
+    assert {(k[0][1], k[0][2]) for k in list(taps.fa) + list(taps.fa_bn) + list(taps.fa_fork)} == {
+        (width, 112), (width, 56), (2 * width, 28), (4 * width, 14), (8 * width, 7)}
     assert set(taps.fa) == set(taps.ba) and set(taps.fa_bn) == set(taps.ba_bn) and len(taps.fa_bn) >= 4
+    assert set(taps.fa_fork) == set(taps.ba_fork)
+    if amp is not None:
+        assert not taps.fa and len(taps.fa_fork) == 4          # bf16: the 4 projecting blocks take the forked form
     def bn_taps_ref(r, eps):
         x = r["x"].double().requires_grad_(True)
         w, b, soft = (r[n].double().requires_grad_(True) for n in ("w", "b", "soft"))
@@ -461,6 +497,24 @@ def test_aq_train_step_shift_layers_match_oracle(oracle, monkeypatch, tier, amp)
             np.testing.assert_allclose(g[name].double().numpy(), ref.numpy(), rtol=0,
                                        atol=(5e-3 if st == torch.bfloat16 else 1e-4) * float(ref.abs().max()),
                                        err_msg="bn1 + taps %s %s" % (name, key))
+    for key, r in taps.fa_fork.items():                # ---- the forked form: + the gathered activation ...
+        _, _, _, _, a, y = bn_taps_ref(r, r["eps"])
+        np.testing.assert_allclose(r["y"].double().numpy(), y.detach().numpy(), rtol=0, atol=bar * float(y.abs().max()),
+                                   err_msg="forked bn1 + taps forward %s" % (key,))
+        xs = a.detach()[:, :, ::2, ::2]
+        np.testing.assert_allclose(r["xs"].double().numpy(), xs.numpy(), rtol=0, atol=bar * float(xs.abs().max()),
+                                   err_msg="forked bn1: gathered activation %s" % (key,))
+    for key, g in taps.ba_fork.items():                # ---- ... and the shortcut's gradient joined before the ReLU mask
+        x, w, b, soft, a, y = bn_taps_ref(g, eps)
+        torch.autograd.backward([y, a[:, :, ::2, ::2]], [g["gy"].double(), g["gxs"].double()])
+        dx = x.grad
+        scale = max(float(dx.abs().max()), float(w.abs().max()) * float(a.grad.abs().max()) / float(x.detach().std()))
+        off = (g["dx"].double() - dx).abs() > bar * scale
+        assert float(off.double().mean()) < 1e-5, "forked bn1 + taps d(x) %s: %d elements off" % (key, int(off.sum()))
+        for name, ref in (("dgamma", w.grad), ("dbeta", b.grad), ("gsoft", soft.grad)):
+            np.testing.assert_allclose(g[name].double().numpy(), ref.numpy(), rtol=0,
+                                       atol=(5e-3 if st == torch.bfloat16 else 1e-4) * float(ref.abs().max()),
+                                       err_msg="forked bn1 + taps %s %s" % (name, key))
     for key, r in taps.fa.items():                     # ---- AttentionShift taps, forward
         assert r["x"].dtype == st and r["soft"].dtype == torch.float32
         y_ref = ao.taps_forward(r["x"].float().numpy(), r["soft"].numpy(), r["S"])
