@@ -53,6 +53,12 @@ template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
 #ifndef RK_C2_NT
 #define RK_C2_NT 1
 #endif
+#ifndef RK_C2_BWD_WAVES
+#define RK_C2_BWD_WAVES 3
+#endif
+#ifndef RK_C2_WIDE_BWD
+#define RK_C2_WIDE_BWD 0
+#endif
 template <typename T> __device__ __forceinline__ void store_quad(T* p, const Quad<T>& q) {
     if constexpr (RK_C2_NT && sizeof(T) == 2) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -65,6 +71,11 @@ template <typename T> __device__ __forceinline__ void store_quad(T* p, const Qua
 
 // training fusion (bn2 + ReLU inside the shift, fused_bn.bn_relu_shift2d): the value the unfused path would have stored
 // -- rounded to the storage type -- so that both paths see the same activation
+// a 16-bit storage value given as bits
+template <typename T> __device__ __forceinline__ float from_bits16(unsigned b) {
+    if constexpr (std::is_same<T, __hip_bfloat16>::value) return __uint_as_float(b << 16);
+    else return __half2float(__builtin_bit_cast(__half, (unsigned short)b));
+}
 template <typename T> __device__ __forceinline__ float as_stored(float v) { T t; st(&t, v); return ld(&t); }
 template <typename T> __device__ __forceinline__ float bn_relu_of(float z, float a, float b) {
     return as_stored<T>(fmaxf(fmaf(a, z, b), 0.f));
@@ -108,6 +119,62 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
         o00[m] = h0 * d.W + w0;
         mask[m] = (i < HWo) ? ((mh0 && mw0 ? 1u : 0u) | (mh0 && mw1 ? 2u : 0u) | (mh1 && mw0 ? 4u : 0u) |
                                (mh1 && mw1 ? 8u : 0u)) : 0u;
+    }
+    // WIDE (16-bit storage, stride (2,2) / pad 0, even planes, Wo % 4 == 0, shift floors in {-1, 0}: every downsampling layer of
+    // the -aq networks): the 8 taps of a thread's 4 consecutive outputs are 8 CONSECUTIVE input elements in each of two rows, so
+    // they arrive as two 16-byte loads (2-byte aligned: the hardware takes them) instead of 16 two-byte gathers; a window that
+    // would start at column -1 starts at 0 and is moved up one element in registers (its first tap is masked anyway).
+    constexpr bool S2W = VEC && kM == 4 && sizeof(T) == 2;
+    const bool wide = S2W && d.sH == 2 && d.sW == 2 && d.pH == 0 && d.pW == 0 && (d.Wo & 3) == 0 && !(d.H & 1) && !(d.W & 1) &&
+                      d.W >= 8 && (iH == 0 || iH == -1) && (iW == 0 || iW == -1);      // (uniform per thread group)
+    if (wide) {
+        const int i0 = id.chunk * cd.E * kM + e * kM;
+        const int ii0 = i0 < HWo ? i0 : 0;
+        const int ho = ii0 / d.Wo, wo0 = ii0 - ho * d.Wo;
+        const int h0 = 2 * ho + iH, c0 = 2 * wo0 + iW;
+        const bool up1 = c0 < 0;
+        const int colL = up1 ? 0 : c0;
+        const int wa = (h0 < 0 ? 0 : h0) * d.W + colL, wb = (h0 + 1) * d.W + colL;
+        struct Win { unsigned a[4], b[4]; };
+        auto load_win = [&](int k, Win& f) {
+            const T* p = xc + (size_t)k * fsi;
+            __builtin_memcpy(f.a, p + wa, 16);
+            __builtin_memcpy(f.b, p + wb, 16);
+        };
+        auto use_win = [&](int k, const Win& f) {
+            T* out = yc + (size_t)k * fso;
+            Quad<T> oq;
+#pragma unroll
+            for (int m = 0; m < kM; ++m) {
+                const unsigned ra = up1 ? ((f.a[m] << 16) | (m > 0 ? f.a[m > 0 ? m - 1 : 0] >> 16 : 0u)) : f.a[m];
+                const unsigned rb = up1 ? ((f.b[m] << 16) | (m > 0 ? f.b[m > 0 ? m - 1 : 0] >> 16 : 0u)) : f.b[m];
+                const unsigned mk = mask[m];
+                CT t0 = (CT)from_bits16<T>(ra & 0xffffu), t1 = (CT)from_bits16<T>(ra >> 16);
+                CT t2 = (CT)from_bits16<T>(rb & 0xffffu), t3 = (CT)from_bits16<T>(rb >> 16);
+                if constexpr (BN) {
+                    t0 = bn_relu_of<T>(t0, bnA, bnB); t1 = bn_relu_of<T>(t1, bnA, bnB);
+                    t2 = bn_relu_of<T>(t2, bnA, bnB); t3 = bn_relu_of<T>(t3, bnA, bnB);
+                }
+                const CT p00 = (mk & 1u) ? t0 : (CT)0, p01 = (mk & 2u) ? t1 : (CT)0;
+                const CT p10 = (mk & 4u) ? t2 : (CT)0, p11 = (mk & 8u) ? t3 : (CT)0;
+                st(&oq.v[m & 3], interp2d(p00, p01, p10, p11, rH, rW));
+            }
+            if (oidx[0] >= 0) store_quad<T>(out + oidx[0], oq);
+        };
+        int k = 0;
+        for (; k + 3 < nf; k += 4) {
+            Win fr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_win(k + j, fr[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) use_win(k + j, fr[j]);
+        }
+        for (; k < nf; ++k) {
+            Win f;
+            load_win(k, f);
+            use_win(k, f);
+        }
+        return;
     }
     struct Frame { CT q[kM][4]; };
     auto load_frame = [&](int k, Frame& f) {                              // addresses clamped into the plane, masked at use
@@ -171,7 +238,10 @@ __global__ __launch_bounds__(kBlock) void k2d_forward_column(const T* __restrict
 // d(bn2's output) = d(activation) masked by the ReLU (rounded to the storage type first, as the unfused path stores it), and
 // BatchNorm's two reduction sums over it (sum dz, sum dz (z - mean) invstd) leave as partials 2 and 3: part[c][4][P].
 template <typename T, typename S, int kM, bool SINGLE, bool VEC = false, bool BN = false>
-__global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restrict__ gy, const T* __restrict__ x,
+// (16-bit storage: 3 waves per SIMD -- left to itself the fused stride-2 instance takes 180 VGPRs, 2 waves: 420 -> 365 us at
+// [256,72,112,112]; fp32 is faster left alone)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? RK_C2_BWD_WAVES : 2)))
+void k2d_backward_column(const T* __restrict__ gy, const T* __restrict__ x,
                                                               const S* __restrict__ shift, T* gx,
                                                               typename Compute<T>::type* __restrict__ part,
                                                               C2Dims cd, const float4* __restrict__ abmi = nullptr) {
@@ -244,7 +314,30 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
             }
             CT sH = 0, sW = 0, sB1 = 0, sB2 = 0;
             constexpr int NTAP = SINGLE ? 1 : 4;
-            struct Frame { CT xv[kM]; CT q[kM][NTAP]; };
+            // WIDE (16-bit storage, both strides >= 2, a thread's 4 consecutive inputs in one row): the 4 taps are 2-3 CONSECUTIVE
+            // gy elements of one row, so they arrive as ONE 8-byte load (2-byte aligned: the hardware takes it) at `gbase` and are
+            // picked out by shifts -- 3 memory instructions per thread and frame instead of 6 (the kernel ran at 0.30-0.36 of 8 TB/s
+            // with four two-byte gathers per thread)
+            constexpr bool WIDE = SINGLE && VEC && kM == 4 && sizeof(T) == 2;
+            // (measured: 420 -> 436 us at [256,72,112,112] -- the kernel is bound by its ~40 VALU operations per element, not by the
+            // gathers; the path stays compiled for RK_C2_WIDE_BWD=1 builds)
+            const bool wide = WIDE && RK_C2_WIDE_BWD && (d.W & 3) == 0 && HWo >= 4;     // (uniform; W % 4 != 0: a thread's inputs straddle rows)
+            int gbase = 0;
+            unsigned gsh[kM];
+            if (wide) {
+                int vmin = 0x7fffffff;
+#pragma unroll
+                for (int m = 0; m < kM; ++m) if (tap[m][0] >= 0 && tap[m][0] < vmin) vmin = tap[m][0];
+                gbase = vmin == 0x7fffffff ? 0 : vmin;
+                gbase = gbase < HWo - 4 ? gbase : HWo - 4;            // (the load stays inside the plane; host: HWo >= 4)
+#pragma unroll
+                for (int m = 0; m < kM; ++m) {
+                    int ix = tap[m][0] >= 0 ? tap[m][0] - gbase : 0;
+                    if (ix > 3) { ix = 0; tap[m][0] = -1; }           // (cannot happen with both strides 2: the taps span <= 3 elements)
+                    gsh[m] = 16u * (unsigned)ix;
+                }
+            }
+            struct Frame { CT xv[kM]; CT q[kM][WIDE ? 1 : NTAP]; unsigned long long gq; };
             auto load_frame = [&](int k, Frame& f) {                          // addresses clamped into the plane, values masked at use
                 const T* p = gc + (size_t)k * fso;
                 const T* xp = xc + (size_t)k * fsi;
@@ -256,10 +349,14 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
 #pragma unroll
                     for (int m = 0; m < kM; ++m) f.xv[m] = ld(xp + (iidx[m] >= 0 ? iidx[m] : 0));
                 }
+                if (wide) {
+                    __builtin_memcpy(&f.gq, p + gbase, 8);
+                } else {
 #pragma unroll
-                for (int m = 0; m < kM; ++m)
+                    for (int m = 0; m < kM; ++m)
 #pragma unroll
-                    for (int j = 0; j < NTAP; ++j) f.q[m][j] = ld(p + (tap[m][j] >= 0 ? tap[m][j] : 0));
+                        for (int j = 0; j < NTAP; ++j) f.q[m][j] = ld(p + (tap[m][j] >= 0 ? tap[m][j] : 0));
+                }
             };
             auto use_frame = [&](int k, const Frame& f) {
                 T* out = oc + (size_t)k * fsi;
@@ -270,7 +367,9 @@ __global__ __launch_bounds__(kBlock) void k2d_backward_column(const T* __restric
                     if constexpr (BN) xv = iidx[m] >= 0 ? (CT)bn_relu_of<T>((float)f.xv[m], bnp.x, bnp.y) : (CT)0;
                     CT Q, QH, QW;
                     if (SINGLE) {
-                        const CT v = tap[m][0] >= 0 ? f.q[m][0] : (CT)0;
+                        CT v;
+                        if (wide) v = tap[m][0] >= 0 ? (CT)from_bits16<T>((unsigned)(f.gq >> gsh[m]) & 0xffffu) : (CT)0;
+                        else v = tap[m][0] >= 0 ? f.q[m][0] : (CT)0;
                         const CT vj = v * wj[m];
                         Q = vj * wk[m];                                      // = K8's interp2d with three zero taps
                         QH = sj[m] * (v * wk[m]);
