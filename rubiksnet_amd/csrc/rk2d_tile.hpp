@@ -284,8 +284,14 @@ __global__ __launch_bounds__(kBlock) void k2d_tile_interp(const T* __restrict__ 
 // shifted) is recomputed where the d(shift) sums use it -- a lane needs x only at its OWN pair --, d(x) leaves masked by the
 // ReLU (= d(bn2's output), what k_bn_bwd_dx_pre expects), and bn2's two reduction sums (sum dz, sum dz zhat) ride along as
 // partials 2 and 3: [C][4][P]; the finalizer also writes k12 / d(gamma) / d(beta).
+// (the bn2-fused bf16 instance takes 161 VGPRs = 3 waves per SIMD; forced to 4 waves it spills 100 bytes per lane: 34.5 -> 43.9 us
+// at [256,288,14,14])
+#ifndef RK_T2_BN_WAVES
+#define RK_T2_BN_WAVES 2
+#endif
 template <typename T, typename S, int H, int W, int R, bool BN = false>
-__global__ __launch_bounds__(kBlock) void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BN && sizeof(T) == 2 ? RK_T2_BN_WAVES : 2)))
+void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
                                                             const S* __restrict__ shift, T* __restrict__ gx, TDims2 d,
                                                             Fin2<S> fin, BnFuse2 bn = BnFuse2{}) {
     using G = Geo<T, H, W>;
