@@ -197,13 +197,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     }
     const int half = n & 1;                          // this lane's 4 pixels within the unit
     const int rowb = 16 * (rb0 + rh * RB) + 4 * g;
-    // The residual: added in the EPILOGUE from 16-byte loads issued one row block ahead (RES_EPI).  The first form made it the
-    // accumulators' initial value -- 4 RB eight-byte loads per lane up front whose wait at the first step also drained the
-    // wave's DMAs: + 14 us on a 16.6 us GEMM at [256, 288 -> 288, 14, 14]; kept only where the statistics epilogue needs the
-    // sum in the accumulators (RES_INIT: rk_pw_gemm_packed_stats_bf16 with a residual, which no caller in the tree passes).
-    constexpr bool RES_INIT = RES && STATS, RES_EPI = RES && !STATS;
-    uint2 rr[RES_INIT ? RB : 1][4];
-    if (RES_INIT) {
+    uint2 rr[RES ? RB : 1][4];
+    if (RES) {
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
@@ -241,7 +236,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (RES_INIT) {
+                    if (RES) {
                         acc[r][0][i] = __uint_as_float(rr[r][i].x << 16);
                         acc[r][1][i] = __uint_as_float(rr[r][i].x & 0xffff0000u);
                         acc[r][2][i] = __uint_as_float(rr[r][i].y << 16);
@@ -316,44 +311,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         ncols += dpp_or_zero<0x114, 0xf>(ncols); ncols += dpp_or_zero<0x118, 0xf>(ncols);     // lane n = 15: the wave's columns
     }
     const int J = 2 * (int)gridDim.x;
-    if constexpr (RES_EPI) {
-        // fp32 exchange inside the lane pair (each lane ends up with 2 rows x the unit's 8 columns), + residual, one rounding
-        auto rload = [&](int r, int e) -> u32x4 {
-            const int row = rowb + 16 * r + 2 * half + e;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (out_ok && row < d.M) v = *reinterpret_cast<const u32x4*>(R + at0 + (size_t)row * d.P);
-            return v;
-        };
-        u32x4 rv[2] = {rload(0, 0), rload(0, 1)};
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            u32x4 rn[2] = {rv[0], rv[1]};
-            if (r + 1 < RB) { rn[0] = rload(r + 1, 0); rn[1] = rload(r + 1, 1); }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float mine[4], recv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    mine[q] = half ? acc[r][q][2 + e] : acc[r][q][e];                   // my rows (2 half + e), my 4 columns
-                    const float send = half ? acc[r][q][e] : acc[r][q][2 + e];         // the partner's rows, my 4 columns
-                    recv[q] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
-                }
-                const int row = rowb + 16 * r + 2 * half + e;
-                if (!out_ok || row >= d.M) continue;
-                u32x4 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {                                            // dword k = columns 2 k, 2 k + 1 of the unit
-                    const float lo = k < 2 ? (half ? recv[2 * k] : mine[2 * k]) : (half ? mine[2 * k - 4] : recv[2 * k - 4]);
-                    const float hi = k < 2 ? (half ? recv[2 * k + 1] : mine[2 * k + 1]) : (half ? mine[2 * k - 3] : recv[2 * k - 3]);
-                    const float v0 = lo + __uint_as_float(rv[e][k] << 16), v1 = hi + __uint_as_float(rv[e][k] & 0xffff0000u);
-                    o[k] = bf16_bits(v0) | (bf16_bits(v1) << 16);
-                }
-                *reinterpret_cast<u32x4*>(Y + at0 + (size_t)row * d.P) = o;
-            }
-            rv[0] = rn[0]; rv[1] = rn[1];
-        }
-        return;
-    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         unsigned w[4][2];
