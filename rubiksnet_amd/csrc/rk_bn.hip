@@ -819,6 +819,35 @@ __global__ __launch_bounds__(kBlock) void k_bn_relu_gather2(const T* __restrict_
     st(xs + o, fmaxf(v, 0.f));
 }
 
+// the same for 16-bit storage and W % 8 == 0: a thread reads 8 consecutive elements of an even row (16 bytes) and writes the 4
+// even ones (8 bytes) -- the element-at-a-time form above read 2 bytes per lane: 58 us per call on the four layers that use it
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bn_relu_gather2_x4(const T* __restrict__ x, const float* __restrict__ ab, T* __restrict__ xs,
+                                                               long long cells, int C, int H, int W) {
+    const long long o = (long long)blockIdx.x * kBlock + threadIdx.x;       // cell = 4 consecutive outputs of one output row
+    if (o >= cells) return;
+    const int cpr = W / 8, Ho = H / 2;
+    const int j = (int)(o % cpr);
+    const long long r = o / cpr;
+    const int ho = (int)(r % Ho);
+    const long long p = r / Ho;
+    const int c = (int)(p % C);
+    const float a = ab[c], b = ab[C + c];
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (p * H + 2 * ho) * W + 8 * j);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    T out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T e;
+        const unsigned short bits = (unsigned short)(w[k] & 0xffffu);       // the even element of the pair
+        __builtin_memcpy(&e, &bits, 2);
+        st(&out[k], fmaxf(fmaf(a, ld(&e), b), 0.f));
+    }
+    uint2 q;
+    __builtin_memcpy(&q, out, 8);
+    *reinterpret_cast<uint2*>(xs + (p * Ho + ho) * (W / 2) + 4 * j) = q;
+}
+
 }  // namespace bn
 }  // namespace rk
 
@@ -844,6 +873,15 @@ static int bn_relu_gather2(const void* x, const float* ab, void* xs, int F, int 
     if (!x || !ab || !xs) return RK_ERR_NULL_POINTER;
     if (F <= 0 || C <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return RK_ERR_BAD_DIMS;
     const long long total = (long long)F * C * (H / 2) * (W / 2);
+    if constexpr (sizeof(T) == 2) {
+        if (W % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)xs & 7)) {
+            const long long cells = total / 4, cblocks = (cells + kBlock - 1) / kBlock;
+            if (cblocks > 0x7fffffffLL) return RK_ERR_BAD_DIMS;
+            hipLaunchKernelGGL((k_bn_relu_gather2_x4<T>), dim3((unsigned)cblocks), dim3(kBlock), 0, (hipStream_t)stream, (const T*)x, ab,
+                               (T*)xs, cells, C, H, W);
+            return launch_status();
+        }
+    }
     const long long blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return RK_ERR_BAD_DIMS;
     hipLaunchKernelGGL((k_bn_relu_gather2<T>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (const T*)x, ab, (T*)xs,
