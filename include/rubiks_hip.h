@@ -526,6 +526,13 @@ int rk_bn_stats_finish_f32(const float* x, const float* gamma, const float* beta
 int rk_bn_stats_finish_bf16(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                             float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
                             long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream);
+/* ... also leaving abmi [C][4] = (a, b, mean, invstd), the packed record rk2d_backward_bn_* reads (16-byte aligned) */
+int rk_bn_stats_finish_abmi_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float* save_mean, float* save_invstd, float* ab, float* abmi, int F, int C, int P, float eps,
+                                float momentum, long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream);
+int rk_bn_stats_finish_abmi_bf16(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float* save_mean, float* save_invstd, float* ab, float* abmi, int F, int C, int P, float eps,
+                                 float momentum, long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream);
 
 /* ---- input side of the network on the device -- widening row f4 of SURVEY 8(f) ----------------------
  * Replaces, per batch instead of per sample on CPU workers, the reference's transform tail

@@ -120,6 +120,8 @@ SIGNATURES = {
     "rk_bn_bwd_dx_pre_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rk_bn_stats_finish_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _p, _p, _sz, _p]),
     "rk_bn_stats_finish_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _p, _p, _sz, _p]),
+    "rk_bn_stats_finish_abmi_f32": (_i, [_p] * 9 + [_i, _i, _i, ctypes.c_float, ctypes.c_float, _p, _p, _sz, _p]),
+    "rk_bn_stats_finish_abmi_bf16": (_i, [_p] * 9 + [_i, _i, _i, ctypes.c_float, ctypes.c_float, _p, _p, _sz, _p]),
 }
 SIGNATURES["rk_se_mlp_forward_f32"] = (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p])
 SIGNATURES["rk_se_mlp_backward_f32"] = (_i, [_p] * 11 + [_i, _i, _i, _p])

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_stats_fused(const T* __restrict__
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                            float* __restrict__ ab, float eps, float momentum,
-                                                           long long* __restrict__ num_batches_tracked) {
+                                                           long long* __restrict__ num_batches_tracked,
+                                                           float4* __restrict__ abmi = nullptr) {
     if ((int)blockIdx.x >= fin.producers) {
         if (threadIdx.x >= kWave) return;
         const int c = (int)blockIdx.x - fin.producers;
@@ -153,8 +154,10 @@ __global__ __launch_bounds__(kBlock) void k_bn_stats_fused(const T* __restrict__
         save_mean[c] = mean;
         save_invstd[c] = invstd;
         const float a = gamma[c] * invstd;                              // (affine() below, declared after this kernel)
+        const float bb = fmaf(-mean, a, beta[c]);
         ab[c] = a;
-        ab[d.C + c] = fmaf(-mean, a, beta[c]);
+        ab[d.C + c] = bb;
+        if (abmi) abmi[c] = make_float4(a, bb, mean, invstd);           // (the packed record the fused shift backwards read)
         if (running_mean) {
             const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -312,7 +315,8 @@ __global__ __launch_bounds__(kWave) void k_bn_finish_parts(const T* __restrict__
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                            float* __restrict__ ab, BnDims d, float eps, float momentum,
-                                                           long long* __restrict__ num_batches_tracked) {
+                                                           long long* __restrict__ num_batches_tracked,
+                                                           float4* __restrict__ abmi = nullptr) {
     __shared__ double sm[1][2];
     const int c = blockIdx.x;
     if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(kWave) void k_bn_finish_parts(const T* __restrict__
     affine(gamma[c], beta[c], mean, invstd, a, b);
     ab[c] = a;
     ab[d.C + c] = b;
+    if (abmi) abmi[c] = make_float4(a, b, mean, invstd);
     if (running_mean) {
         const float unbiased = (float)(var * (M / (M > 1 ? M - 1 : 1)));
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -595,8 +600,9 @@ inline bool stats_fused_on() {                              // RK_BN_STATS_FUSED
 template <typename T>
 int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float* save_mean, float* save_invstd, float* ab, int F, int C, int P, float eps, float momentum,
-                    long long* nbt, void* ws, size_t ws_bytes, rk_stream_t stream_) {
+                    long long* nbt, void* ws, size_t ws_bytes, rk_stream_t stream_, float4* abmi = nullptr) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !ab) return RK_ERR_NULL_POINTER;
+    if ((uintptr_t)abmi & 15) return RK_ERR_BAD_DIMS;
     if ((running_mean == nullptr) != (running_var == nullptr)) return RK_ERR_NULL_POINTER;
     BnDims d;
     if (int rc = make_bn(d, F, C, P)) return rc;
@@ -609,7 +615,7 @@ int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* ru
         fin.producers = (int)grid_bn(d);
         const dim3 grid(grid_bn(d) + C), block(kBlock);
 #define RK_BN_SF(VEC) hipLaunchKernelGGL((k_bn_stats_fused<T, VEC>), grid, block, 0, stream, x, d, fin, gamma, beta, running_mean, \
-                                         running_var, save_mean, save_invstd, ab, eps, momentum, nbt)
+                                         running_var, save_mean, save_invstd, ab, eps, momentum, nbt, abmi)
         if constexpr (std::is_same<T, __hip_bfloat16>::value) {
             if (P % 8 == 0 && !((uintptr_t)x & 15)) { RK_BN_SF(8); return launch_status(); }
         }
@@ -622,7 +628,7 @@ int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* ru
     if (vec4_ok<T>(d, x, x)) hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid_bn(d)), dim3(kBlock), 0, stream, x, part, d);
     else hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid_bn(d)), dim3(kBlock), 0, stream, x, part, d);
     hipLaunchKernelGGL((k_bn_finish_parts<T>), dim3(C), dim3(kWave), 0, stream, x, (const float*)part, gamma, beta, running_mean,
-                       running_var, save_mean, save_invstd, ab, d, eps, momentum, nbt);
+                       running_var, save_mean, save_invstd, ab, d, eps, momentum, nbt, abmi);
     return launch_status();
 }
 // The same map as a FLAT sweep of memory.  The per-channel form above gives a workgroup 8 192 elements of ONE channel, i.e.
@@ -978,6 +984,22 @@ int rk_bn_stats_finish_bf16(const void* x, const float* gamma, const float* beta
                             long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream) {
     return bn_stats_finish<__hip_bfloat16>((const __hip_bfloat16*)x, gamma, beta, running_mean, running_var, save_mean,
                                            save_invstd, ab, F, C, P, eps, momentum, num_batches_tracked, ws, ws_bytes, stream);
+}
+// ... also leaving the packed record abmi [C][4] = (a, b, mean, invstd) that rk2d_backward_bn_* reads (16-byte aligned)
+int rk_bn_stats_finish_abmi_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float* save_mean, float* save_invstd, float* ab, float* abmi, int F, int C, int P, float eps,
+                                float momentum, long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!abmi) return RK_ERR_NULL_POINTER;
+    return bn_stats_finish<float>(x, gamma, beta, running_mean, running_var, save_mean, save_invstd, ab, F, C, P, eps, momentum,
+                                  num_batches_tracked, ws, ws_bytes, stream, (float4*)abmi);
+}
+int rk_bn_stats_finish_abmi_bf16(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float* save_mean, float* save_invstd, float* ab, float* abmi, int F, int C, int P, float eps,
+                                 float momentum, long long* num_batches_tracked, void* ws, size_t ws_bytes, rk_stream_t stream) {
+    if (!abmi) return RK_ERR_NULL_POINTER;
+    return bn_stats_finish<__hip_bfloat16>((const __hip_bfloat16*)x, gamma, beta, running_mean, running_var, save_mean,
+                                           save_invstd, ab, F, C, P, eps, momentum, num_batches_tracked, ws, ws_bytes, stream,
+                                           (float4*)abmi);
 }
 
 #define RK_DEF_BN(SFX, TYPE, CTYPE)                                                                               \

@@ -357,6 +357,7 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
         y = torch.empty((Fr, C, (H + 2 * pH - 1) // sH + 1, (W + 2 * pW - 1) // sW + 1), dtype=z.dtype, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
+            abmi = None
             if stats is not None:
                 fin = _finish_tiles(L, stats, Fr * P, weight, bias, running_mean, running_var, momentum, eps, counter_ptr, dev,
                                     stream)
@@ -365,22 +366,25 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
                 save_mean = torch.empty(C, dtype=torch.float32, device=dev)
                 save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
                 ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+                abmi = torch.empty(C, 4, dtype=torch.float32, device=dev)      # (a, b, mean, invstd): what the backward reads
                 ws, nbytes = _ws(L, Fr, C, P, dev)
-                _native.check(getattr(L, "rk_bn_stats_finish_" + sfx)(
+                _native.check(getattr(L, "rk_bn_stats_finish_abmi_" + sfx)(
                     z.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var), save_mean.data_ptr(),
-                    save_invstd.data_ptr(), ab.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr, ws.data_ptr(),
-                    nbytes, stream), "rk_bn_stats_finish")
+                    save_invstd.data_ptr(), ab.data_ptr(), abmi.data_ptr(), Fr, C, P, float(eps), float(momentum), counter_ptr,
+                    ws.data_ptr(), nbytes, stream), "rk_bn_stats_finish_abmi")
+            if abmi is None:
+                abmi = torch.stack((ab[0], ab[1], save_mean, save_invstd), dim=1).contiguous()
             rc = getattr(L, "rk2d_forward_bn_" + _BNReLUShift2DTrain._SHIFT_SFX[z.dtype])(
                 z.data_ptr(), ab.data_ptr(), shift.data_ptr(), y.data_ptr(), Fr, C, H, W, sH, sW, pH, pW, 0, stream)
         _native.check(rc, "rk2d_forward_bn")
-        ctx.save_for_backward(z, weight, bias, shift, save_mean, save_invstd, ab)
+        ctx.save_for_backward(z, weight, bias, shift, save_mean, save_invstd, ab, abmi)
         ctx.normalize_grad = bool(normalize_grad)
         ctx.geometry = (sH, sW, pH, pW)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        z, weight, bias, shift, save_mean, save_invstd, ab = ctx.saved_tensors
+        z, weight, bias, shift, save_mean, save_invstd, ab, abmi = ctx.saved_tensors
         L = _native.lib()
         Fr, C, H, W = z.shape
         P = H * W
@@ -394,7 +398,6 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
         k12 = torch.empty(2, C, dtype=torch.float32, device=dev)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        abmi = torch.stack((ab[0], ab[1], save_mean, save_invstd), dim=1).contiguous()       # [C][4]
         sH, sW, pH, pW = ctx.geometry
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream

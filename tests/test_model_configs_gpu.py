@@ -248,7 +248,7 @@ class _Taps:
             return y
 
         def b2bwd(ctx, gy):
-            z, weight, bias, shift, save_mean, save_invstd, ab = ctx.saved_tensors
+            z, weight, bias, shift, save_mean, save_invstd, ab = ctx.saved_tensors[:7]
             key = (tuple(z.shape), tuple(ctx.geometry), z.dtype)
             first = key not in taps.b2_bn
             rec = None
