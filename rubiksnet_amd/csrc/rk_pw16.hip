@@ -142,7 +142,33 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     }
     const int xstep = kCh * d.P * 2;                                // bytes per 32 channel rows
     const bool k_ragged = (d.K & (kCh - 1)) != 0;
+    // RES: the residual rides through the SAME ring as nchR more chunks after X's -- R [F, M, P] has X's layout, and
+    // Y = [A | I] [X ; R]: chunk nch + j holds R's rows 16 rb0 + 32 j .. + 31, and its A stage is two identity blocks among
+    // zeros, written to LDS by the A waves from registers instead of from the packed operand -- the step below does not
+    // know the difference (its MFMAs on zero blocks are free: the pipe is idle 80 % of the time).  1.0 x r and the fp32 add
+    // are exact, so this is "accumulate, add the residual in fp32, round once".  (Before: 4 RB 8-byte loads per lane ahead of the K loop as the
+    // accumulators' initial values -- a 72 KB round trip per workgroup that nothing overlapped: 30.8 us against 17.9 plain
+    // at [256, 288 -> 288, 14, 14]; adding them in the epilogue from loads one row block ahead measured the same.)
+    const int nchR = RES ? ((d.nrb - rb0 < 2 * RB ? d.nrb - rb0 : 2 * RB) + 1) / 2 : 0;
+    const char* rbase = RES ? uniform_bytes(reinterpret_cast<const char*>(R)) : xbase;
+    long long roff0 = 0;
+    if (RES) {
+        const long long q = dma_ok ? ug_dma : 0;
+        const int f = (int)(q / d.U), j = (int)(q - (long long)f * d.U);
+        const int px = (odd_tail && j == d.U - 1) ? d.P - 8 : 8 * j;
+        roff0 = (((long long)f * d.M) * d.P + px) * 2;
+    }
+    auto issue_r = [&](int j, int stage) {                          // chunk j of the residual's rows of this workgroup
+        const unsigned dst = xs0 + (unsigned)(stage * kXStage + 4 * wave * kXGroup);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int k = 16 * rb0 + kCh * j + 16 * wave + 4 * i + (lane >> 4);
+            k = k < d.M ? k : d.M - 1;                              // rows past M: a valid row, added to rows that are not stored
+            if (dma_ok) dma::dma16s<false>(rbase, (int)(roff0 + (long long)k * d.P * 2), dst + (unsigned)(i * kXGroup));
+        }
+    };
     auto issue_x = [&](int c, int stage) {                          // (called with c = 0, 1, 2, ... in order)
+        if (RES && c >= d.nch) { issue_r(c - d.nch, stage); return; }
         const unsigned dst = xs0 + (unsigned)(stage * kXStage + 4 * wave * kXGroup);
         const bool clamp = k_ragged && c == d.nch - 1;
 #pragma unroll
@@ -170,7 +196,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     }
     const u32x4* asrc = reinterpret_cast<const u32x4*>(Apk);
     const int astep = d.nrb * 64;                                   // 16-byte pieces per chunk of the packed operand
+    // identity fragments for the residual's chunks (see issue_r below), made in registers: lane (m = lane & 15, kg = lane >> 4)
+    // of the block with parity h holds a 1.0 at k = 16 h + m, i.e. in element m & 7 of k-group kg = 2 h + (m >> 3)
+    const int id_kg = (lane >> 4) - ((lane & 15) >> 3);             // = 2 h where this lane holds the 1.0
+    const int id_dw = (lane & 7) >> 1;
+    const unsigned id_one = (lane & 1) ? 0x3f800000u : 0x00003f80u; // bf16 1.0 in the element's half of its dword
     auto fetch_a = [&](int c) {
+        if (RES && c >= d.nch) {
+            const int j = c - d.nch;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int blk = (wave & 1) + 2 * b;                 // (workgroup-local block: the chunk holds blocks 2 j, 2 j + 1)
+                const unsigned v = ((blk >> 1) == j && id_kg == 2 * (blk & 1)) ? id_one : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) areg[b][e] = id_dw == e ? v : 0u;
+            }
+            return;
+        }
         const u32x4* src0 = asrc + (size_t)c * astep;
 #pragma unroll
         for (int b = 0; b < RB; ++b) areg[b] = src0[ablk[b]];
@@ -184,8 +226,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
         }
     };
 
-    // output geometry of this lane, and its residual values: loaded up front (they land under the K loop; being older
-    // than every DMA of the wave they do not disturb the counted waits below)
+    // output geometry of this lane
     const long long ug = (long long)blockIdx.x * 16 + 8 * cgp + (n >> 1);
     const bool out_ok = ug < d.nunits;
     size_t at0 = 0;                                  // element offset of this lane's UNIT in row 0 of its frame's output
@@ -197,24 +238,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
     }
     const int half = n & 1;                          // this lane's 4 pixels within the unit
     const int rowb = 16 * (rb0 + rh * RB) + 4 * g;
-    uint2 rr[RES ? RB : 1][4];
-    if (RES) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rowb + 16 * r + i;
-                rr[r][i] = (out_ok && row < d.M) ? *reinterpret_cast<const uint2*>(R + at0 + 4 * half + (size_t)row * d.P) : make_uint2(0u, 0u);
-            }
-    }
+    f32x4 acc[RB][4];                                // zeroed in the first iteration
 
-    f32x4 acc[RB][4];                                // initialised in the first iteration (zeros, or the residual)
-
-    const int nch = d.nch;
+    const int nch = d.nch, nchT = nch + nchR;        // X's chunks, then the residual's
     if (x_wave) {
 #pragma unroll
         for (int j = 0; j < DX - 1; ++j)
-            if (j < nch) issue_x(j, j);
+            if (j < nchT) issue_x(j, j);
     } else {
         fetch_a(0);
         deposit_a(0);
@@ -226,30 +256,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
 
     auto step = [&](int c, auto first) {
         // chunk c has landed when only the younger chunks of this wave's stream (up to D - 2 of them) are outstanding
-        const int left = nch - 1 - c;
+        const int left = nchT - 1 - c;
         if (x_wave) dma::wait_vmcnt(4 * (left < DX - 2 ? left : DX - 2));
         __syncthreads();
         if (decltype(first)::value) {
-            // the accumulators start from the residual: no register is spent on it past this point (the compiler's wait
-            // for these loads also drains the DMAs issued so far -- once per workgroup)
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (RES) {
-                        acc[r][0][i] = __uint_as_float(rr[r][i].x << 16);
-                        acc[r][1][i] = __uint_as_float(rr[r][i].x & 0xffff0000u);
-                        acc[r][2][i] = __uint_as_float(rr[r][i].y << 16);
-                        acc[r][3][i] = __uint_as_float(rr[r][i].y & 0xffff0000u);
-                    } else {
-                        acc[r][0][i] = acc[r][1][i] = acc[r][2][i] = acc[r][3][i] = 0.f;
-                    }
-                }
+                for (int i = 0; i < 4; ++i) acc[r][0][i] = acc[r][1][i] = acc[r][2][i] = acc[r][3][i] = 0.f;
         }
         if (x_wave) {
-            if (c + DX - 1 < nch) issue_x(c + DX - 1, sx == 0 ? DX - 1 : sx - 1);      // into the stage of chunk c - 1
+            if (c + DX - 1 < nchT) issue_x(c + DX - 1, sx == 0 ? DX - 1 : sx - 1);     // into the stage of chunk c - 1
         } else {
-            if (c + 1 < nch) fetch_a(c + 1);                                           // lands under this chunk's MFMAs
+            if (c + 1 < nchT) fetch_a(c + 1);                                          // lands under this chunk's MFMAs
         }
 
         const char* xs = xrd + sx * kXStage;
@@ -287,11 +306,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_gemm(const char* __restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q], acc[r][q], 0, 0, 0);
         }
-        if (!x_wave && c + 1 < nch) deposit_a(sa);           // sa is already the stage of chunk c + 1 (last read in step c - 1)
+        if (!x_wave && c + 1 < nchT) deposit_a(sa);          // sa is already the stage of chunk c + 1 (last read in step c - 1)
     };
     step(0, std::true_type{});
 #pragma nounroll
-    for (int c = 1; c < nch; ++c) step(c, std::false_type{});
+    for (int c = 1; c < nchT; ++c) step(c, std::false_type{});
 
     // results: lane (n, g) holds rows 16 rb + 4 g + i, columns 4 n + q of its column group = half a unit.  Lane pairs
     // swap two rows each (DPP) so that every lane stores 2 rows x 16 bytes instead of 4 rows x 8: the epilogue is
@@ -542,6 +561,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_pw16_wgrad(const __hip_bfloat16* 
         }
 }
 
+// A second form was measured in round 5 and not kept (profiles/r05_pw16_wgrad_{pmc,sweep}.txt): 3 x 3 waves of
+// 3 x 3 blocks, one workgroup per CU, half the splits, 4 / 6 / 8 register stages of loads in flight, transposed blocks
+// for 16-byte stores -- 35.3 -> 33.5 us stand-alone at 288 x 288, level at any prefetch depth, and level in the train step.
+// The counters say why: L2 serves the second reader of every operand row (TCC misses x 128 B = operands once + partials),
+// and the L1s sit in TCP_PENDING_STALL for more than half of the kernel -- 2.7 M 64-byte requests for 118 MB of loads (rows
+// are 392 B apart at 14 x 14: a row's 64-byte piece straddles sectors), ~196 MB of sectors in all between L2 and the CUs
+// at the ~6.5 TB/s every streaming kernel here tops out at.  The bound is the formulation's traffic (operands x tiles per
+// side + 2 x splits x M K x 4), not latency.
 // out[i] = sum over the S partial matrices, fixed order: 4 slices of the split range per output (one per wave, 64
 // outputs per workgroup), each summed front to back, then the 4 slice sums added in slice order
 __global__ __launch_bounds__(kBlock) void k_pw16_reduce(const float* __restrict__ in, float* __restrict__ out, int MK, int S) {
@@ -641,6 +668,7 @@ int rk_pw_gemm_packed_bf16(const void* Apk, const void* X_, const void* R_, void
     if (F <= 0 || K <= 0 || M <= 0 || P < 8 || P % 4 != 0) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)Apk & 15) || ((uintptr_t)X & 7) || ((uintptr_t)Y & 7) || (R && ((uintptr_t)R & 7))) return RK_ERR_BAD_DIMS;
     if ((long long)F * K * P * 2 >= (1ll << 31)) return RK_ERR_BAD_DIMS;             // 32-bit byte offsets in the DMA
+    if (R && (long long)F * M * P * 2 >= (1ll << 31)) return RK_ERR_BAD_DIMS;        // (the residual goes through the same DMA)
     Dims d;
     d.F = F; d.K = K; d.M = M; d.P = P;
     d.nrb = (M + 15) / 16; d.nch = (K + kCh - 1) / kCh;
@@ -671,7 +699,7 @@ int rk_pw_gemm_packed_stats_bf16(const void* Apk, const void* X_, const void* R_
     if (F <= 0 || K <= 0 || M <= 0 || P < 8 || P % 4 != 0) return RK_ERR_BAD_DIMS;
     if (((uintptr_t)Apk & 15) || ((uintptr_t)X & 7) || ((uintptr_t)Y & 7) || (R && ((uintptr_t)R & 7)) || ((uintptr_t)stats & 15))
         return RK_ERR_BAD_DIMS;
-    if ((long long)F * K * P * 2 >= (1ll << 31)) return RK_ERR_BAD_DIMS;
+    if ((long long)F * K * P * 2 >= (1ll << 31) || (R && (long long)F * M * P * 2 >= (1ll << 31))) return RK_ERR_BAD_DIMS;
     if (tiles != rk_pw16_stat_tiles(F, P)) return RK_ERR_BAD_DIMS;
     Dims d;
     d.F = F; d.K = K; d.M = M; d.P = P;
