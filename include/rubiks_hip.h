@@ -272,6 +272,12 @@ int rk_tshift3_bn_backward_fork_bf16(const void* gy, const void* x, const float*
 int rk_soft_taps_forward_f32(const float* weight, const float* T, float* taps, int C, rk_stream_t stream);
 int rk_soft_taps_backward_f32(const float* weight, const float* T, const float* taps, const float* gtaps, float* gweight,
                               int C, rk_stream_t stream);
+/* Every AttentionShift layer of a network in one launch each way.  jobs: device array of n records {const float* weight;
+ * const float* T; int64 off; int32 C; int32 pad} (32 bytes); layer i's taps / gtaps / gweight are rows off .. off + C of
+ * concatenated [sum C][3] fp32 buffers; max_c = the largest C.  Same arithmetic as the one-layer calls (bit-identical). */
+int rk_soft_taps_many_forward_f32(const void* jobs, int n, float* taps, int max_c, rk_stream_t stream);
+int rk_soft_taps_many_backward_f32(const void* jobs, int n, const float* taps, const float* gtaps, float* gweight, int max_c,
+                                   rk_stream_t stream);
 
 /* ---- BatchNorm2d (+ ReLU) of the backbone blocks -- widening row f3 of SURVEY 8(f) ----------------
  * Replaces the reference's nn.BatchNorm2d followed by nn.ReLU(inplace=True)
@@ -327,7 +333,9 @@ int rk_pw_gemm_bf16(const float* A, const void* X, const void* R, void* Y, int F
  *   rk_pw_packed_bytes(rows, depth): bytes of a packed operand;
  *   rk_pw_pack_bf16: W [Cout][Cin] fp32 -> `fwd` (rows Cout, depth Cin: forward) and / or `bwd` (rows Cin, depth
  *                   Cout: W^T for d(input)); either may be NULL;
- *   rk_pw_gemm_packed_bf16: Y[f] = A X[f] (+ R[f]) with A packed (M rows, depth K); R may be NULL or Y itself. */
+ *   rk_pw_gemm_packed_bf16: Y[f] = A X[f] (+ R[f]) with A packed (M rows, depth K); R may be NULL or Y itself.  R [F,M,P]
+ *                   is streamed through the same LDS-DMA ring as X (identity-weighted chunks after X's: exact), so both
+ *                   F*K*P*2 and F*M*P*2 must stay below 2^31 bytes (RK_ERR_BAD_DIMS otherwise). */
 size_t rk_pw_packed_bytes(int rows, int depth);
 int rk_pw_pack_bf16(const float* W, int Cout, int Cin, void* fwd, void* bwd, rk_stream_t stream);
 /* The same for n weights in one launch (once per train step, pointwise.prepacked): `jobs` = device array of n 40-byte

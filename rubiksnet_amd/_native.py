@@ -56,6 +56,8 @@ SIGNATURES = {
     "rk_tshift3_bn_backward_fin_bf16": (_i, [_p] * 11 + [_i, _i, _i, _i, _p, _sz, _p]),
     "rk_soft_taps_forward_f32": (_i, [_p, _p, _p, _i, _p]),
     "rk_soft_taps_backward_f32": (_i, [_p, _p, _p, _p, _p, _i, _p]),
+    "rk_soft_taps_many_forward_f32": (_i, [_p, _i, _p, _i, _p]),
+    "rk_soft_taps_many_backward_f32": (_i, [_p, _i, _p, _p, _p, _i, _p]),
     "rk_bn_workspace_bytes": (_sz, [_i, _i, _i]),
     "rk_pw_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_gemm_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -7,13 +7,16 @@ inflates the [C,3] weights to [C*H*W,1,3] and calls a grouped conv1d (>= 3 full 
 Here the tiny [C,3] normalise+softmax stays in PyTorch (so autograd owns it) and the
 activation goes once through the HIP 3-tap kernel (rk_tshift3_*, include/rubiks_hip.h).
 """
+import contextlib
+import struct
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _native
+from . import _native, config
 
-__all__ = ["AttentionShift", "temporal_shift3"]
+__all__ = ["AttentionShift", "temporal_shift3", "presoftened"]
 
 
 def _run(name, dev, *args):
@@ -83,6 +86,74 @@ class _SoftTapsFunc(torch.autograd.Function):
         return gw, None
 
 
+class _SoftTapsManyFunc(torch.autograd.Function):
+    """The taps of EVERY AttentionShift layer of a network in one launch (rk_soft_taps_many_*), and their backward in one
+    launch once the last layer's d(taps) has arrived (+ one torch.cat of the 51 small gradients): 2 + 2 launches per train
+    step instead of 51 + 51 of ~4 us each between dependent kernels.  Outputs are views of one fresh [sum C, 3] buffer; the
+    gradients returned are views of one buffer too (AccumulateGrad takes them as they are)."""
+
+    @staticmethod
+    def forward(ctx, plan, *weights):
+        jobs, offs, total, max_c = plan
+        dev = weights[0].device
+        taps = torch.empty(total, 3, dtype=torch.float32, device=dev)
+        _run("rk_soft_taps_many_forward_f32", dev, jobs.data_ptr(), len(weights), taps.data_ptr(), max_c)
+        ctx.plan = plan
+        ctx.dev = dev
+        ctx.set_materialize_grads(False)                    # a layer that took no part in the graph: None, not zeros
+        ctx.save_for_backward(taps)
+        return tuple(taps[o:o + int(w.shape[0])] for w, o in zip(weights, offs))
+
+    @staticmethod
+    def backward(ctx, *gtaps):
+        jobs, offs, total, max_c = ctx.plan
+        taps, = ctx.saved_tensors
+        parts = []
+        for g, o, o1 in zip(gtaps, offs, list(offs[1:]) + [total]):
+            parts.append(torch.zeros(o1 - o, 3, dtype=torch.float32, device=ctx.dev) if g is None else g.float())
+        gcat = torch.cat(parts, dim=0).contiguous()
+        gw = torch.empty_like(gcat)
+        _run("rk_soft_taps_many_backward_f32", ctx.dev, jobs.data_ptr(), len(gtaps), taps.data_ptr(), gcat.data_ptr(),
+             gw.data_ptr(), max_c)
+        return (None,) + tuple(gw[o:o1] if g is not None else None
+                               for g, o, o1 in zip(gtaps, offs, list(offs[1:]) + [total]))
+
+
+_PRESOFT = None
+
+
+@contextlib.contextmanager
+def presoftened(module):
+    """Inside the block, `AttentionShift.soft_taps()` of every layer of `module` returns its slice of ONE batched evaluation
+    (see _SoftTapsManyFunc); dp.train_step wraps the forward of a step in it.  The job table (weight / temperature pointers,
+    offsets) is cached on the module and rebuilt when a parameter moves.  Outside a block nothing is shared."""
+    global _PRESOFT
+    layers = [m for m in module.modules() if isinstance(m, AttentionShift) and m.weight is not None and m.weight.is_cuda
+              and m.weight.dtype == torch.float32 and m.weight.dim() == 2 and m.weight.shape[1] == 3
+              and m.weight.is_contiguous() and m.T.is_cuda and m.T.dtype == torch.float32]
+    if not config.switches().presoft or _PRESOFT is not None or len(layers) < 2 or len(layers) > 65535 or len({m.weight.device for m in layers}) != 1:
+        yield
+        return
+    key = tuple((m.weight.data_ptr(), m.T.data_ptr(), int(m.weight.shape[0])) for m in layers)
+    plan = getattr(module, "_rk_presoft_plan", None)
+    if plan is None or plan[0] != key:
+        recs, offs, off, max_c = [], [], 0, 0
+        for wp, tp, c in key:
+            recs.append(struct.pack("<QQqii", wp, tp, off, c, 0))
+            offs.append(off)
+            off += c
+            max_c = max(max_c, c)
+        jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(layers[0].weight.device)
+        plan = (key, (jobs, tuple(offs), off, max_c))
+        module._rk_presoft_plan = plan
+    outs = _SoftTapsManyFunc.apply(plan[1], *[m.weight for m in layers])
+    _PRESOFT = {id(m): t for m, t in zip(layers, outs)}
+    try:
+        yield
+    finally:
+        _PRESOFT = None
+
+
 def temporal_shift3(x, taps, n_segment):
     """Functional form: x [N*T, C, H, W], taps [C, 3] (already normalised)."""
     return _TemporalShift3Func.apply(x, taps, n_segment)
@@ -104,6 +175,10 @@ class AttentionShift(nn.Module):
     def soft_taps(self):
         """softmax((w / (std(w) + 1e-6)) / T) over the 3 taps (attention_shift.py:29-30)."""
         w = self.weight
+        if _PRESOFT is not None:
+            hit = _PRESOFT.get(id(self))
+            if hit is not None:
+                return hit
         if w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == 3:
             return _SoftTapsFunc.apply(w, self.T)
         weight = w / (torch.std(w, dim=1, keepdim=True) + 1e-6)      # host-side tensors: the same expression in PyTorch

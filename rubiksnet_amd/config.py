@@ -14,6 +14,9 @@
                                   of its output for bn2 (rk_pw_gemm_packed_stats_bf16).  Off by default: measured on the
                                   Large-AQ step the epilogue costs what the pass it replaces cost (33.1 vs 32.8 ms), DESIGN 3.5b
 
+    RK_PRESOFT     1 | 0          train step: the [C, 3] tap softmax of every AttentionShift layer in one launch each way
+                                  (attention_shift.presoftened) / one launch per layer and direction
+
 Everything else that used to be tunable from the environment (tile shapes, channel limits, prefetch depths)
 is a constant next to the code it tunes.  The native library has one switch of its own, RK_SHIFT_KERNELS
 (include/rubiks_hip.h), and RK_PW2 = 1 | 0 | 2 (second-generation fp32 1x1 kernels where they are ahead /
@@ -36,6 +39,7 @@ class Switches:
     bn_shift2d: bool = True
     prepack: bool = True
     bn_tshift_fork: bool = True
+    presoft: bool = True
 
     @staticmethod
     def from_env(env=None):
@@ -50,7 +54,8 @@ class Switches:
                         pw16_stats=env.get("RK_PW16_STATS", "0") == "1",
                         bn_shift2d=env.get("RK_BN_SHIFT2D", "1") != "0",
                         prepack=env.get("RK_PREPACK", "1") != "0",
-                        bn_tshift_fork=env.get("RK_BN_TSHIFT_FORK", "1") != "0")
+                        bn_tshift_fork=env.get("RK_BN_TSHIFT_FORK", "1") != "0",
+                        presoft=env.get("RK_PRESOFT", "1") != "0")
 
 
 _current = Switches.from_env()

@@ -431,11 +431,30 @@ __global__ __launch_bounds__(kBlock) void k_tshift3_finalize(const CT* __restric
 // ---- the [C,3] half of AttentionShift (attention_shift.py:29-30): taps = softmax((w / (std(w) + 1e-6)) / T) over the
 // three taps of a channel, std unbiased (torch.std default).  One thread per channel; in PyTorch this is ~15 tiny
 // kernels forward and ~25 backward per layer (2 000 launches per Large-AQ train step).
+__device__ __forceinline__ void soft_taps_one(const float* __restrict__ w, float T, float* __restrict__ taps, int c);
+__device__ __forceinline__ void soft_taps_grad_one(const float* __restrict__ w, float T, const float* __restrict__ taps,
+                                                   const float* __restrict__ gtaps, float* __restrict__ gw, int c);
 __global__ __launch_bounds__(kBlock) void k_soft_taps_forward(const float* __restrict__ w, const float* __restrict__ Tp,
                                                               float* __restrict__ taps, int C) {
     const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= C) return;
-    const float T = Tp[0];
+    if (c < C) soft_taps_one(w, Tp[0], taps, c);
+}
+
+// d(w) from d(taps): softmax backward, then z_i = w_i a(w) with a = 1 / (T (std + eps)), d std / d w_k = (w_k - m) / (2 std)
+// (0 / 0 = NaN when the three weights are equal, as torch.std's backward)
+__global__ __launch_bounds__(kBlock) void k_soft_taps_backward(const float* __restrict__ w, const float* __restrict__ Tp,
+                                                               const float* __restrict__ taps,
+                                                               const float* __restrict__ gtaps, float* __restrict__ gw,
+                                                               int C) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c < C) soft_taps_grad_one(w, Tp[0], taps, gtaps, gw, c);
+}
+
+// Every AttentionShift layer of a network in ONE launch each way (attention_shift.presoftened: 51 layers in Large-AQ, 102
+// launches of ~4 us between dependent kernels of a train step): blockIdx.y = the layer; a layer's taps / gradients live at
+// channel offset `off` of concatenated [sum C][3] buffers, its weight and temperature stay where the module keeps them.
+struct SoftJob { const float* w; const float* T; long long off; int C; int pad; };
+__device__ __forceinline__ void soft_taps_one(const float* __restrict__ w, float T, float* __restrict__ taps, int c) {
     const float w0 = w[3 * c], w1 = w[3 * c + 1], w2 = w[3 * c + 2];
     const float m = (w0 + w1 + w2) / 3.0f;
     const float d0 = w0 - m, d1 = w1 - m, d2 = w2 - m;
@@ -449,17 +468,9 @@ __global__ __launch_bounds__(kBlock) void k_soft_taps_forward(const float* __res
     taps[3 * c + 1] = e1 / es;
     taps[3 * c + 2] = e2 / es;
 }
-
-// d(w) from d(taps): softmax backward, then z_i = w_i a(w) with a = 1 / (T (std + eps)), d std / d w_k = (w_k - m) / (2 std)
-// (0 / 0 = NaN when the three weights are equal, as torch.std's backward)
-__global__ __launch_bounds__(kBlock) void k_soft_taps_backward(const float* __restrict__ w, const float* __restrict__ Tp,
-                                                               const float* __restrict__ taps,
-                                                               const float* __restrict__ gtaps, float* __restrict__ gw,
-                                                               int C) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= C) return;
+__device__ __forceinline__ void soft_taps_grad_one(const float* __restrict__ w, float T, const float* __restrict__ taps,
+                                                   const float* __restrict__ gtaps, float* __restrict__ gw, int c) {
     const float w0 = w[3 * c], w1 = w[3 * c + 1], w2 = w[3 * c + 2];
-    const float T = Tp[0];
     const float p0 = taps[3 * c], p1 = taps[3 * c + 1], p2 = taps[3 * c + 2];
     const float g0 = gtaps[3 * c], g1 = gtaps[3 * c + 1], g2 = gtaps[3 * c + 2];
     const float dot = g0 * p0 + g1 * p1 + g2 * p2;
@@ -470,10 +481,21 @@ __global__ __launch_bounds__(kBlock) void k_soft_taps_backward(const float* __re
     const float den = sd + 1e-6f;
     const float a = 1.0f / (T * den);
     const float zw = z0 * w0 + z1 * w1 + z2 * w2;
-    const float k = -zw / (T * den * den) / (2.0f * sd);          // (sum_i dz_i w_i) * da/dstd / (2 std)
+    const float k = -zw / (T * den * den) / (2.0f * sd);
     gw[3 * c] = a * z0 + k * d0;
     gw[3 * c + 1] = a * z1 + k * d1;
     gw[3 * c + 2] = a * z2 + k * d2;
+}
+__global__ __launch_bounds__(kBlock) void k_soft_taps_many_forward(const SoftJob* __restrict__ jobs, float* __restrict__ taps) {
+    const SoftJob j = jobs[blockIdx.y];
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c < j.C) soft_taps_one(j.w, j.T[0], taps + 3 * j.off, c);
+}
+__global__ __launch_bounds__(kBlock) void k_soft_taps_many_backward(const SoftJob* __restrict__ jobs, const float* __restrict__ taps,
+                                                                    const float* __restrict__ gtaps, float* __restrict__ gw) {
+    const SoftJob j = jobs[blockIdx.y];
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c < j.C) soft_taps_grad_one(j.w, j.T[0], taps + 3 * j.off, gtaps + 3 * j.off, gw + 3 * j.off, c);
 }
 
 int make_dimsT(DimsT& d, int NT, int S, int C, int HW, int vec) {
@@ -735,6 +757,24 @@ int rk_soft_taps_backward_f32(const float* weight, const float* T, const float* 
     if (C <= 0) return RK_ERR_BAD_DIMS;
     hipLaunchKernelGGL(k_soft_taps_backward, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, weight, T,
                        taps, gtaps, gweight, C);
+    return launch_status();
+}
+// jobs: device array of n records {const float* weight; const float* T; int64 off; int C; int pad} (32 bytes): layer i's taps /
+// d(taps) / d(weight) are rows off .. off + C of the concatenated [sum C][3] buffers; max_c = the largest C
+int rk_soft_taps_many_forward_f32(const void* jobs, int n, float* taps, int max_c, rk_stream_t stream) {
+    if (!jobs || !taps) return RK_ERR_NULL_POINTER;
+    if (n <= 0 || n > 65535 || max_c <= 0 || ((uintptr_t)jobs & 7)) return RK_ERR_BAD_DIMS;
+    static_assert(sizeof(SoftJob) == 32, "the record layout attention_shift.py writes");
+    hipLaunchKernelGGL(k_soft_taps_many_forward, dim3((max_c + kBlock - 1) / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const SoftJob*)jobs, taps);
+    return launch_status();
+}
+int rk_soft_taps_many_backward_f32(const void* jobs, int n, const float* taps, const float* gtaps, float* gweight, int max_c,
+                                   rk_stream_t stream) {
+    if (!jobs || !taps || !gtaps || !gweight) return RK_ERR_NULL_POINTER;
+    if (n <= 0 || n > 65535 || max_c <= 0 || ((uintptr_t)jobs & 7)) return RK_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(k_soft_taps_many_backward, dim3((max_c + kBlock - 1) / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const SoftJob*)jobs, taps, gtaps, gweight);
     return launch_status();
 }
 

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import pointwise
+from . import attention_shift, pointwise
 
 __all__ = [
     "DistEnv", "init_distributed", "shard_range", "wrap_ddp", "make_optimizer", "train_step",
@@ -129,8 +129,11 @@ def train_step(model, optimizer, clips, labels, criterion=None):
     optimizer.zero_grad(set_to_none=True)
     bf16_step = (clips.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
     # (bf16 autocast: the 1x1 weights packed for the bf16 GEMMs once for the whole step, pointwise.prepacked)
+    # (and the [C, 3] tap softmax of every AttentionShift layer evaluated in one launch, attention_shift.presoftened)
     with (pointwise.prepacked(model) if bf16_step else contextlib.nullcontext()):
-        loss = criterion(model(clips), labels)
+        with (attention_shift.presoftened(model) if clips.is_cuda else contextlib.nullcontext()):
+            out = model(clips)
+        loss = criterion(out, labels)
         loss.backward()
     optimizer.step()
     return loss

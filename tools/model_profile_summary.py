@@ -13,7 +13,8 @@ import sys
 
 def short(name):
     name = name.strip('"')
-    if name.startswith("void (anonymous namespace)::"):
+    if name.startswith("void (anonymous namespace)::") or name.startswith("(anonymous namespace)::"):
+        # (a non-template kernel demangles without its return type: these rows used to collapse into an empty name)
         name = name.replace("(anonymous namespace)::", "rk::", 1)
     if "rk::" in name:
         return name.split("(")[0].replace("void ", "")
