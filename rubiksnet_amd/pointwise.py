@@ -208,12 +208,15 @@ class _Conv1x1Func(torch.autograd.Function):
             if stats is None:
                 stats = torch.empty(0, device=x.device)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)                # (no zero-filled `_dstats` per backward)
             return y, stats
         return y
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 6
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
@@ -841,12 +844,15 @@ class _StemFunc(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         if with_stats:
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)
             return y, stats
         return y
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None
         dy = dy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:                       # (never in the networks: the stem's input is the clip)

@@ -263,6 +263,9 @@ class _FusedTrainBlock(torch.autograd.Function):
         ctx.save_for_backward(x, z, a2 if a2 is not None else z, s, bn1, bn2, g1, g2, b2, w2, w3,
                               wsc if wsc is not None else w3, shift_c, *se_saved)
         ctx.mark_non_differentiable(stats_out)
+        # (or autograd hands backward() a freshly zero-filled tensor of stats_out's shape for `_dstats`: one fill kernel per block
+        # and step -- 51 launches of ~6 us in RubiksNet-Large's kernel table)
+        ctx.set_materialize_grads(False)
         return out, stats_out
 
     @staticmethod
@@ -278,6 +281,8 @@ class _FusedTrainBlock(torch.autograd.Function):
         Fr, Cin, H, W, Cmid, Cout, Ho, Wo = plan.Fr, plan.Cin, plan.H, plan.W, plan.Cmid, plan.Cout, plan.Ho, plan.Wo
         P, Po = H * W, Ho * Wo
         s3, pd = [1, plan.stride, plan.stride], [0, 0, 0]
+        if dout is None:                                    # (the block's output took no part in the loss)
+            return (None,) * 13
         dout = dout.contiguous()
         need = ctx.needs_input_grad
         with torch.cuda.device(dev):
