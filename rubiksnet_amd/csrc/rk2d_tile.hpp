@@ -460,19 +460,30 @@ void k2d_tile_backward(const T* __restrict__ gy, const T* __restrict__ x,
 // Host side.  false / 0 = shape not handled here.
 // frames per wave, [256,288,14,14] fwd / bwd us (steady state): bf16 1: 22 / 44, 2: 19 / 31, 4: 17 / 26, 8: 17 / 26,
 // 16: 19 / 28, 32: 26 / 40, 64: 45 / 62; fp32 1: 22 / 50, 2: 21 / 40, 4: 22.5 / 35, 8: 24 / 36, 16: 27 / 42, 32: 30 / 46
+// The backward of the 16-bit types (3 waves per SIMD) in ONE round of resident waves: with 4 frames per wave [256,288,14,14] is
+// 9 216 waves = 3 rounds, each wave paying its address plan, DMA ramp and finalizer hand-off for 4 frames; frames per wave
+// so that the waves just fit the machine (12 at 256 CUs) measured 25.8 -> 24.3 us plain, 34.4 -> 30.5 us bn2-fused (sweep,
+// us plain / fused: 4: 25.8 / 34.4, 6: 25.1 / 33.7, 8: 26.2 / 34.0, 10: 25.0 / 35.1, 12: 24.3 / 30.5, 13: 24.9 / 31.8, 14: 26.0 /
+// 33.6, 16: 28.2 / 36.9 -- the optimum is the round boundary; the forward is best at 4: 14.4 / 15.7 us against 15.5 / 17.6 at 12).
 constexpr int kTileFrames = 4;
-template <typename T, int H, int W> inline bool make_tdims(TDims2& t, const Dims2& d) {
+template <typename T, int H, int W> inline bool make_tdims(TDims2& t, const Dims2& d, bool backward = false) {
     using G = Geo<T, H, W>;
     const bool s1p0 = d.sH == 1 && d.sW == 1 && d.pH == 0 && d.pW == 0;
     if (!s1p0 || d.H != H || d.W != W || d.C % G::GC != 0 || !streaming_kernels_on()) return false;
     t.F = d.N; t.C = d.C; t.NG = d.C / G::GC;
-    t.FG = kTileFrames < d.N ? kTileFrames : d.N;
+    int fg = kTileFrames;
+    if (backward && sizeof(T) == 2) {
+        const long long slots = (long long)device_cus() * 12;       // 3 waves per SIMD
+        const long long want = ((long long)d.N * t.NG + slots - 1) / slots;
+        fg = (int)(want < kTileFrames ? kTileFrames : (want > 16 ? 16 : want));
+    }
+    t.FG = fg < d.N ? fg : d.N;
     t.ngroups = (d.N + t.FG - 1) / t.FG;
     return true;
 }
 template <typename T> inline int backward2_partials(const Dims2& d) {
     TDims2 t;
-    return make_tdims<T, 14, 14>(t, d) ? t.ngroups : 0;
+    return make_tdims<T, 14, 14>(t, d, true) ? t.ngroups : 0;
 }
 
 template <typename T, bool NEGATE, typename S>
@@ -494,7 +505,7 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
     constexpr int R = 3;       // (the forward's static full-group schedule was tried here too: 245 VGPRs, 26 -> 31 us)
     using G = Geo<T, 14, 14>;
     TDims2 t;
-    if (!make_tdims<T, 14, 14>(t, d) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
+    if (!make_tdims<T, 14, 14>(t, d, true) || !aligned16(gy) || !aligned16(x) || !aligned16(gx)) return false;
     const long long waves = (long long)t.NG * t.ngroups;
     const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
     Fin2<S> fin;
@@ -527,7 +538,7 @@ inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, 
     constexpr int R = 3;
     using G = Geo<T, 14, 14>;
     TDims2 t;
-    if (!make_tdims<T, 14, 14>(t, d) || !aligned16(gy) || !aligned16(z) || !aligned16(dz) || !aligned16(bn.abmi)) return false;
+    if (!make_tdims<T, 14, 14>(t, d, true) || !aligned16(gy) || !aligned16(z) || !aligned16(dz) || !aligned16(bn.abmi)) return false;
     const long long waves = (long long)t.NG * t.ngroups;
     const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
     Fin2<S> fin;
