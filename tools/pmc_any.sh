@@ -14,7 +14,7 @@ CMD=("$@")
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 pass sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 pass sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM
-pass m1 FETCH_SIZE WRITE_SIZE
+[ -n "${SKIP_M1:-}" ] || pass m1 FETCH_SIZE WRITE_SIZE      # (this pass hung on two boxes of round 5: SKIP_M1=1 leaves it out; TCC_MISS x 128 B gives the same traffic)
 pass m2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 pass m3 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
 pass grbm GRBM_GUI_ACTIVE
