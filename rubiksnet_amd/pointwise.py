@@ -112,8 +112,9 @@ def _pw16_fits(Fr, C, P):
 def _packed_ok(a, x, K, M, P, a_is_mk):
     # (tensors of 2 GiB and more -- ~150 clips of 8 x 72 x 112 x 112 in bf16 -- keep the first-generation kernel, which
     # indexes with size_t)
+    # (max(K, M): the residual [F, M, P] goes through the same 32-bit-offset DMA as X since round 5)
     return (x.dtype == torch.bfloat16 and P >= 8 and a.dim() >= 2 and a.shape[0] == (M if a_is_mk else K)
-            and _pw16_fits(x.shape[0], K, P))
+            and _pw16_fits(x.shape[0], max(K, M), P))
 
 
 def _gemm(a, x, out, Fr, K, M, P, a_is_mk, residual=None, packed=None):
