@@ -385,6 +385,9 @@ int rk_pw_wgrad16_bf16(const void* dY, const void* X, float* dW, int F, int K, i
  * running_mean a): the (ka, kb) / (ma, mb) arrays of the fused entry points below, in one launch. */
 int rk_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                    float* a, float* b, int C, rk_stream_t stream);
+/* the same fold for n BatchNorm layers in one launch: jobs = device array of {gamma*, beta*, running_mean*, running_var*,
+ * int64 off, int32 C, float eps} (48 bytes); ab = [2][total] fp32, layer i's a / b at [off, off + C) of each half */
+int rk_bn_fold_many_f32(const void* jobs, int n, float* ab, long long total, int max_c, rk_stream_t stream);
 int rk_pw_gemm_fused_f32(const float* A, const float* X, const float* R, float* Y, int F, int K, int M, int P,
                          int a_is_mk, const float* ka, const float* kb, int relu_in, const float* ma,
                          const float* mb, int relu_out, rk_stream_t stream);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "rk_pw_s2_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rk_pw_s2_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "rk_bn_fold_f32": (_i, [_p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _p]),
+    "rk_bn_fold_many_f32": (_i, [_p, _i, _p, ctypes.c_longlong, _i, _p]),
     "rk_pw_gemm_fused_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "rk_pw_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     # second-generation fp32 kernels (rk_pw2.hip): tuning / test hooks with an explicit kernel configuration

@@ -80,6 +80,18 @@ __global__ __launch_bounds__(kBlock) void k_bn_fold(const float* __restrict__ ga
     b[c] = fmaf(-mean[c], s, beta[c]);
 }
 
+// every eval-mode BatchNorm of a network in ONE launch (pointwise.prefolded: 28 folds of ~5 us per RubiksNet-Tiny forward):
+// blockIdx.y = the layer; a[off .. off + C) / b[off .. off + C) of one [2][total] buffer
+struct FoldJob { const float* gamma; const float* beta; const float* mean; const float* var; long long off; int C; float eps; };
+__global__ __launch_bounds__(kBlock) void k_bn_fold_many(const FoldJob* __restrict__ jobs, float* __restrict__ ab, long long total) {
+    const FoldJob j = jobs[blockIdx.y];
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= j.C) return;
+    const float s = j.gamma[c] * (1.0f / sqrtf(j.var[c] + j.eps));  // (k_bn_fold's expression: bit-identical)
+    ab[j.off + c] = s;
+    ab[total + j.off + c] = fmaf(-j.mean[c], s, j.beta[c]);
+}
+
 struct PwFuse {
     const float* ka; const float* kb; const float* ma; const float* mb;
     int relu_in, relu_out;
@@ -1697,6 +1709,16 @@ int rk_bn_fold_f32(const float* gamma, const float* beta, const float* running_m
     if (C <= 0) return RK_ERR_BAD_DIMS;
     hipLaunchKernelGGL(k_bn_fold, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, gamma, beta,
                        running_mean, running_var, eps, a, b, C);
+    return launch_status();
+}
+// jobs: device array of n records {gamma*, beta*, running_mean*, running_var*, int64 off, int32 C, float eps} (48 bytes);
+// ab = [2][total]: layer i's a / b at [off, off + C) of each half; max_c = the largest C
+int rk_bn_fold_many_f32(const void* jobs, int n, float* ab, long long total, int max_c, rk_stream_t stream) {
+    if (!jobs || !ab) return RK_ERR_NULL_POINTER;
+    if (n <= 0 || n > 65535 || total <= 0 || max_c <= 0 || ((uintptr_t)jobs & 7)) return RK_ERR_BAD_DIMS;
+    static_assert(sizeof(FoldJob) == 48, "the record layout pointwise.py writes");
+    hipLaunchKernelGGL(k_bn_fold_many, dim3((max_c + kBlock - 1) / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const FoldJob*)jobs, ab, total);
     return launch_status();
 }
 // Inference: Y[f] = epi(A pro(X[f])) (+ R[f]) with the per-channel affine (+ReLU) stages of PwFuse above; ka / kb

@@ -8,6 +8,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import pointwise
 from .attention_shift import AttentionShift
 from .backbone import RubiksNetBackbone
 from .shiftlib import RubiksShift2D, RubiksShift3D
@@ -78,7 +79,13 @@ class RubiksNet(nn.Module):
 
     def forward(self, input):
         frames = input.view((-1, 3) + input.size()[-2:])
-        logits = self.new_fc(self.backbone(frames))
+        if not self.training and frames.is_cuda:
+            # (inference: every BatchNorm of the backbone folded to its affine map in one launch, pointwise.prefolded)
+            with pointwise.prefolded(self.backbone):
+                feats = self.backbone(frames)
+        else:
+            feats = self.backbone(frames)
+        logits = self.new_fc(feats)
         logits = logits.view((-1, self.num_frames) + logits.size()[1:])
         return logits.mean(dim=1, keepdim=True).squeeze(1)
 
