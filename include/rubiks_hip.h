@@ -29,7 +29,12 @@
  *   - return value: RK_OK (0) or a negative RK_ERR_* code; never exit()s
  *     (the reference's gpuAssert does, rubiks3d_kernels.cu:963-971).  The reference's
  *     Python asserts `ret == 0` (rubiks3d/primitive.py:79,139).
- *   - re-entrant, no global mutable state; safe from autograd worker threads.
+ *   - re-entrant and thread-safe: any thread may call any entry point on any device (autograd worker threads,
+ *     nn.DataParallel's one-thread-per-device backward).  The only process-wide mutable state is atomic and
+ *     order-independent: the launch-tag counter and poll budget of the in-launch finalizers (rk_dma.hpp), and, PER
+ *     DEVICE, the cached CU count and the "dynamic-LDS ceiling already raised" bit of each kernel instantiation
+ *     (rk_common.hpp: raise_dynamic_lds -- hipFuncSetAttribute is per device).  Calls act on the CURRENT device of the
+ *     calling thread (hipGetDevice); the Python layer sets it from the tensors' device.
  *   - ONE environment switch, read once per process: RK_SHIFT_KERNELS = auto | column | generic selects which
  *     kernel families the shift operators may use (rk_common.hpp; every family is bit-identical for y and d(x),
  *     tests/test_fallback_paths_gpu.py).  RK_FORCE_GENERIC=1 is the older spelling of `generic`.
@@ -64,6 +69,12 @@ int rk_device_count(void);            /* hipGetDeviceCount, 0 when none */
 /* test hook (no reference counterpart): the tag the next backward launch with an in-launch row-sum will stamp its
  * workspace granules with; lets the parity tests pre-fill a workspace with adversarial near-miss patterns */
 unsigned rk_debug_peek_launch_tag(void);
+/* test hooks for the in-launch finalizers' give-up path (tests/test_finalizer_gpu.py): the poll budget after which a
+ * finalizer wave stops waiting for partials and writes NaN (default ~2 s; spins <= 0 restores it; returns the previous
+ * value), and a launch of ONLY the 3-D finalizer waves over a workspace nothing publishes to. */
+int rk_debug_set_finalize_spins(int spins);
+int rk3d_debug_finalize_only_f32(void* ws, size_t ws_bytes, int C, int partials, float* gshift, int normalize_grad,
+                                 float t_factor, rk_stream_t stream);
 
 /* ------------------------------------------------------------------------- 3D
  * Replaces rubiks_shift_3d_forward<T>  (cuda_src/rubiks.cpp:181-253) + functor

@@ -28,6 +28,8 @@ SIGNATURES = {
     "rk_out_len": (_i, [_i, _i, _i]),
     "rk_device_count": (_i, []),
     "rk_debug_peek_launch_tag": (ctypes.c_uint, []),
+    "rk_debug_set_finalize_spins": (_i, [_i]),
+    "rk3d_debug_finalize_only_f32": (_i, [_p, _sz, _i, _i, _p, _i, ctypes.c_float, _p]),
     "rk3d_forward_f32": (_i, [_p, _p, _p] + _DIMS3 + [_i, _p]),
     "rk3d_forward_f64": (_i, [_p, _p, _p] + _DIMS3 + [_i, _p]),
     "rk3d_backward_workspace_bytes": (_sz, _DIMS3 + [_i]),

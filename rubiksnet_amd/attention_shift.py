@@ -9,6 +9,7 @@ activation goes once through the HIP 3-tap kernel (rk_tshift3_*, include/rubiks_
 """
 import contextlib
 import struct
+import threading
 
 import torch
 import torch.nn as nn
@@ -119,39 +120,64 @@ class _SoftTapsManyFunc(torch.autograd.Function):
                                for g, o, o1 in zip(gtaps, offs, list(offs[1:]) + [total]))
 
 
-_PRESOFT = None
+_TABLES = threading.local()        # .presoft: {id(layer): taps} inside a `presoftened` block, per THREAD (cf. pointwise._TABLES)
+PRESOFT_GROUP = 16                 # layers per batched node
+
+
+def _presoft_table():
+    return getattr(_TABLES, "presoft", None)
 
 
 @contextlib.contextmanager
 def presoftened(module):
-    """Inside the block, `AttentionShift.soft_taps()` of every layer of `module` returns its slice of ONE batched evaluation
-    (see _SoftTapsManyFunc); dp.train_step wraps the forward of a step in it.  The job table (weight / temperature pointers,
-    offsets) is cached on the module and rebuilt when a parameter moves.  Outside a block nothing is shared."""
-    global _PRESOFT
+    """Inside the block, `AttentionShift.soft_taps()` of every layer of `module` returns its slice of a batched evaluation
+    (see _SoftTapsManyFunc); dp.train_step wraps the forward of a step in it.  The layers are batched in groups of
+    PRESOFT_GROUP consecutive layers, one autograd node per group, and a group is evaluated when its FIRST layer asks for
+    its taps -- NOT one node for the whole network made up front: a node's backward can run once the d(taps) of all its
+    layers have arrived, i.e. after the backward of the earliest block of its group, and the engine takes ready nodes in
+    order of creation, latest first -- a node made before the forward would be taken after every block's backward however
+    early it became ready.  The gradient of every weight in a node is ready only when the node has run, and
+    DistributedDataParallel launches a bucket's all-reduce only when every gradient in it is ready (buckets in order): with
+    one up-front node every bucket holding a tap weight -- all of them in an -aq model -- would be exchanged after the
+    backward instead of under it.  Made where its first layer runs, a group's node sits in the engine's order right behind
+    that layer's own backward, so the last stages' buckets go out while the first stages are still computing
+    (RubiksNet-Large-AQ: 51 layers, 4 nodes each way; tests/test_attention_gpu.py checks the order).
+    The job tables (weight / temperature pointers, offsets) are cached on the module and rebuilt when a parameter moves.
+    Outside a block nothing is shared."""
     layers = [m for m in module.modules() if isinstance(m, AttentionShift) and m.weight is not None and m.weight.is_cuda
               and m.weight.dtype == torch.float32 and m.weight.dim() == 2 and m.weight.shape[1] == 3
               and m.weight.is_contiguous() and m.T.is_cuda and m.T.dtype == torch.float32]
-    if not config.switches().presoft or _PRESOFT is not None or len(layers) < 2 or len(layers) > 65535 or len({m.weight.device for m in layers}) != 1:
+    if (not config.switches().presoft or _presoft_table() is not None or getattr(module, "_is_replica", False) or len(layers) < 2
+            or len({m.weight.device for m in layers}) != 1):
         yield
         return
     key = tuple((m.weight.data_ptr(), m.T.data_ptr(), int(m.weight.shape[0])) for m in layers)
     plan = getattr(module, "_rk_presoft_plan", None)
-    if plan is None or plan[0] != key:
-        recs, offs, off, max_c = [], [], 0, 0
-        for wp, tp, c in key:
-            recs.append(struct.pack("<QQqii", wp, tp, off, c, 0))
-            offs.append(off)
-            off += c
-            max_c = max(max_c, c)
-        jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(layers[0].weight.device)
-        plan = (key, (jobs, tuple(offs), off, max_c))
+    if plan is None or plan[0] != key or plan[1] != PRESOFT_GROUP:
+        groups = []
+        for g0 in range(0, len(key), PRESOFT_GROUP):
+            recs, offs, off, max_c = [], [], 0, 0
+            for wp, tp, c in key[g0:g0 + PRESOFT_GROUP]:
+                recs.append(struct.pack("<QQqii", wp, tp, off, c, 0))
+                offs.append(off)
+                off += c
+                max_c = max(max_c, c)
+            jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(layers[0].weight.device)
+            groups.append((jobs, tuple(offs), off, max_c))
+        plan = (key, PRESOFT_GROUP, tuple(groups))
         module._rk_presoft_plan = plan
-    outs = _SoftTapsManyFunc.apply(plan[1], *[m.weight for m in layers])
-    _PRESOFT = {id(m): t for m, t in zip(layers, outs)}
+    table = {}
+    for gi, group in enumerate(plan[2]):
+        members = layers[gi * PRESOFT_GROUP:(gi + 1) * PRESOFT_GROUP]
+        if len(members) == 1:
+            continue                                            # (a lone last layer: its own _SoftTapsFunc node)
+        pending = {"plan": group, "members": members, "outs": None}
+        table.update((id(m), (pending, i)) for i, m in enumerate(members))
+    _TABLES.presoft = table
     try:
         yield
     finally:
-        _PRESOFT = None
+        _TABLES.presoft = None
 
 
 def temporal_shift3(x, taps, n_segment):
@@ -175,10 +201,14 @@ class AttentionShift(nn.Module):
     def soft_taps(self):
         """softmax((w / (std(w) + 1e-6)) / T) over the 3 taps (attention_shift.py:29-30)."""
         w = self.weight
-        if _PRESOFT is not None:
-            hit = _PRESOFT.get(id(self))
+        table = _presoft_table()
+        if table is not None:
+            hit = table.get(id(self))
             if hit is not None:
-                return hit
+                group, i = hit
+                if group["outs"] is None:                       # the group's first layer to run makes the group's node
+                    group["outs"] = _SoftTapsManyFunc.apply(group["plan"], *[m.weight for m in group["members"]])
+                return group["outs"][i]
         if w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == 3:
             return _SoftTapsFunc.apply(w, self.T)
         weight = w / (torch.std(w, dim=1, keepdim=True) + 1e-6)      # host-side tensors: the same expression in PyTorch

@@ -442,7 +442,7 @@ inline bool launch_backward2(const float* gy, const float* x, const float* shift
     if (lds > 64 * 1024) return false;
     Fin2<float> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;

@@ -455,7 +455,7 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
     if (lds > 64 * 1024) return false;
     Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -495,7 +495,7 @@ inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, 
     if (lds > 64 * 1024) return false;
     Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;

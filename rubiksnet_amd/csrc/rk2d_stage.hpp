@@ -404,7 +404,7 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
     const size_t lds = ring_bytes(f.b);
     dma2d::Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -441,7 +441,7 @@ inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, 
     const size_t lds = ring_bytes(f.b);
     dma2d::Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = f.ngroups * f.b.C * f.b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;

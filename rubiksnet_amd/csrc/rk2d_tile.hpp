@@ -510,7 +510,7 @@ inline bool launch_backward2(const T* gy, const T* x, const S* shift, T* gx, S* 
     const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
     Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = (int)((waves + 3) / 4);
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -543,7 +543,7 @@ inline bool launch_backward2_bn(const T* gy, const T* z, const S* shift, T* dz, 
     const size_t lds = (size_t)4 * 2 * R * G::STRIDE;
     Fin2<S> fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = (int)((waves + 3) / 4);
     fin.gshift = gshift;
     fin.normalize = normalize;

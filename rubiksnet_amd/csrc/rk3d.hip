@@ -16,6 +16,10 @@ using namespace rk;
 
 namespace {
 
+__global__ __launch_bounds__(kWave) void k3d_debug_finalize_only(dma3d::Fin3 fin, int C, int P) {
+    dma3d::finalizer_wave<3>(fin, (int)blockIdx.x, C, P);
+}
+
 int make_dims(Dims3& d, int N, int T, int C, int H, int W, int sT, int sH, int sW, int pT, int pH, int pW) {
     if (N <= 0 || T <= 0 || C <= 0 || H <= 0 || W <= 0) return RK_ERR_BAD_DIMS;
     if (sT <= 0 || sH <= 0 || sW <= 0 || pT < 0 || pH < 0 || pW < 0) return RK_ERR_BAD_STRIDE;
@@ -278,6 +282,25 @@ int rk3d_backward_finalize_f32(const void* ws, int C, int partials, float* gshif
     if (C <= 0 || partials <= 0) return RK_ERR_BAD_DIMS;
     hipLaunchKernelGGL((k3d_finalize<float>), dim3(C), dim3(finalize_block(partials)), 0, (hipStream_t)stream,
                        (const float*)ws, gshift, C, partials, normalize_grad, t_factor);
+    return launch_status();
+}
+
+// Test hook: ONLY the finalizer waves of a fused 3-D backward (rk3d_dma.hpp, finalizer_wave<3>) on a workspace no producer
+// will ever publish to -- the give-up path: every channel must come back NaN once the poll budget
+// (rk_debug_set_finalize_spins) is spent, and the launch must end.  No product code calls it.
+int rk3d_debug_finalize_only_f32(void* ws, size_t ws_bytes, int C, int partials, float* gshift, int normalize_grad,
+                                 float t_factor, rk_stream_t stream) {
+    if (!ws || !gshift) return RK_ERR_NULL_POINTER;
+    if (C <= 0 || partials <= 0) return RK_ERR_BAD_DIMS;
+    if (ws_bytes < (size_t)C * 3 * partials * 16) return RK_ERR_WORKSPACE;
+    dma3d::Fin3 fin{};
+    fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
+    dma::fin_arm(fin.f);
+    fin.f.producers = 0;
+    fin.gshift = gshift;
+    fin.normalize = normalize_grad;
+    fin.t_factor = t_factor;
+    hipLaunchKernelGGL(k3d_debug_finalize_only, dim3((unsigned)C), dim3(kWave), 0, (hipStream_t)stream, fin, C, partials);
     return launch_status();
 }
 

@@ -412,7 +412,7 @@ inline int launch_backward(const T* x, const T* shift, const T* gy, T* gx, T* ws
         if (gshift && streaming_kernels_on()) {
             fused = true;
             fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-            fin.f.tag = dma::next_launch_tag();
+            dma::fin_arm(fin.f);
             fin.f.producers = (int)grid_of(cd);
             fin.gshift = gshift;
             fin.normalize = normalize;

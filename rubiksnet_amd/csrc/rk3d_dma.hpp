@@ -598,7 +598,7 @@ inline int launch_bwd(const float* x, const float* shift, const float* gy, float
     if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return 0;
     Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = b.N * b.C * b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -625,7 +625,7 @@ inline bool launch_bwd_bn(const float* z, const float* shift, const float* gy, f
     if (bwd_ring_bytes(b, 1, 1) > 64 * 1024) return false;
     Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = b.N * b.C * b.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;

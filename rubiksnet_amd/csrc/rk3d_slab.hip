@@ -1055,7 +1055,7 @@ int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, f
     const unsigned producers = (unsigned)((long long)s.N * s.nchunks);
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = (int)producers;
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -1108,7 +1108,7 @@ int launch_bwd_s2(const float* x, const float* shift, const float* gy, float* gx
     const unsigned producers = (unsigned)((long long)s.N * s.nchunks);
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = (int)producers;
     fin.gshift = gshift;
     fin.normalize = normalize;

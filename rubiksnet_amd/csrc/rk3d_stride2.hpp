@@ -546,7 +546,7 @@ inline bool launch_backward_bn(const float* z, const float* shift, const float* 
     if (lds > 64 * 1024) return false;
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = s.N * s.C * s.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -567,7 +567,7 @@ inline int launch_backward(const float* x, const float* shift, const float* gy, 
     if (lds > 64 * 1024) return 0;
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = s.N * s.C * s.nbands;
     fin.gshift = gshift;
     fin.normalize = normalize;

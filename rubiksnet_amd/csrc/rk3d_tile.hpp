@@ -376,7 +376,7 @@ inline bool launch_bwd_bn(const float* z, const float* shift, const float* gy, f
     const size_t lds = 4 * 6 * t14::kStride;
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = (int)producers;
     fin.gshift = gshift;
     fin.normalize = normalize;
@@ -397,7 +397,7 @@ inline int launch_bwd(const float* x, const float* shift, const float* gy, float
     const size_t lds = 4 * 6 * t14::kStride;
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.f.tag = next_launch_tag();
+    fin_arm(fin.f);
     fin.f.producers = (int)producers;
     fin.gshift = gshift;
     fin.normalize = normalize;

@@ -611,7 +611,7 @@ int bn_stats_finish(const T* x, const float* gamma, const float* beta, float* ru
     if (stats_fused_on() && !((uintptr_t)ws & 15)) {
         dma::Fin fin;
         fin.gran = reinterpret_cast<unsigned long long*>(ws);
-        fin.tag = dma::next_launch_tag();
+        dma::fin_arm(fin);
         fin.producers = (int)grid_bn(d);
         const dim3 grid(grid_bn(d) + C), block(kBlock);
 #define RK_BN_SF(VEC) hipLaunchKernelGGL((k_bn_stats_fused<T, VEC>), grid, block, 0, stream, x, d, fin, gamma, beta, running_mean, \

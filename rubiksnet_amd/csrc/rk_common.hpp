@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -130,16 +131,43 @@ __device__ __forceinline__ float4 lds_b128(const float4* p) {
     return v;
 }
 
-// compute units of the current device, cached per device (256 on a full MI355X; fewer in partitioned modes)
+constexpr int kMaxDevices = 64;           // devices whose per-device host state is cached (beyond: queried every call)
+
+// compute units of the current device, cached per device (256 on a full MI355X; fewer in partitioned modes).  The cache is
+// a table of relaxed atomics: any thread of any device may call this (nn.DataParallel: one autograd thread per device).
 inline int device_cus() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    static int cached[16] = {0};
-    if (!cached[dev]) {
-        int v = 0;
-        cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    static std::atomic<int> cached[kMaxDevices];
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    int v = tracked ? cached[dev].load(std::memory_order_relaxed) : 0;
+    if (!v) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        if (tracked) cached[dev].store(v, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return v;
+}
+
+// Kernels that take more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised -- per DEVICE
+// (every device has its own copy of the function), so the "already raised" record of a kernel instantiation is one bit
+// per device, atomic, and the attribute is always raised to the hardware's 160 KB: every call that races sets the same
+// value, so the order in which two threads get there cannot leave a lower ceiling behind.  One DynLdsRaised lives as a
+// function-local static of each launcher template instantiation.
+struct DynLdsRaised {
+    std::atomic<unsigned long long> devices{0};
+};
+constexpr size_t kMaxDynLds = 160 * 1024;
+inline int raise_dynamic_lds(const void* kernel, size_t lds, DynLdsRaised& st) {
+    if (lds > kMaxDynLds) return RK_ERR_UNSUPPORTED;
+    if (lds <= 65536) return RK_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RK_ERR_LAUNCH;
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    const unsigned long long bit = tracked ? 1ull << dev : 0;
+    if (tracked && (st.devices.load(std::memory_order_acquire) & bit)) return RK_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess) return RK_ERR_LAUNCH;
+    if (tracked) st.devices.fetch_or(bit, std::memory_order_release);
+    return RK_OK;
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RK_OK : RK_ERR_LAUNCH; }

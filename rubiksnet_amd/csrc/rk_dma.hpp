@@ -238,15 +238,28 @@ struct Fin {
     unsigned long long* gran;     // [C][D][P] granule PAIRS (16 bytes per partial)
     unsigned tag;                 // != 0, unique per launch
     int producers;                // producer blocks; blocks beyond are finalizers
+    int spins;                    // polls of one lane before its finalizer gives up (~0.25 us each)
 };
+// The library's only process-wide mutable state, both std::atomic (any thread, any device): the launch-tag counter and
+// the finalizers' poll budget (a test hook: rk_debug_set_finalize_spins, rk_misc.hip).
 inline std::atomic<unsigned>& launch_tag_counter() {
     static std::atomic<unsigned> tag{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
     return tag;
+}
+constexpr int kFinSpins = 8000000;                                   // ~2 s
+inline std::atomic<int>& fin_spin_budget() {
+    static std::atomic<int> spins{kFinSpins};
+    return spins;
 }
 inline unsigned next_launch_tag() {
     std::atomic<unsigned>& tag = launch_tag_counter();
     unsigned t = tag.fetch_add(1, std::memory_order_relaxed);
     return t ? t : tag.fetch_add(1, std::memory_order_relaxed);
+}
+// every launch that hands partials to in-launch finalizers arms its Fin here: a fresh tag + the current poll budget
+inline void fin_arm(Fin& f) {
+    f.tag = next_launch_tag();
+    f.spins = fin_spin_budget().load(std::memory_order_relaxed);
 }
 // A partial is handed over as a PAIR of 8-byte granules at gran[2*at], gran[2*at + 1]:
 //   value granule {fp32 value, tag}   and   check granule {~value bits, tag2},  tag2 = a second word derived from tag.
@@ -332,7 +345,7 @@ __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double
 #pragma unroll
         for (int k = 0; k < D; ++k) { v[k] = done; w[k] = done2; want[k] = act; }
         fin_load<D>(fin, g, P, i, v, w, want);
-        for (int spin = 0; spin < 8000000; ++spin) {                 // ~0.25 us per poll: gives up after ~2 s
+        for (int spin = 0; spin < fin.spins; ++spin) {               // ~0.25 us per poll: gives up after ~2 s (kFinSpins)
             bool ready = true;
 #pragma unroll
             for (int k = 0; k < D; ++k) ready = ready && fin_ready(fin, v[k], w[k]);

@@ -100,4 +100,11 @@ unsigned rk_debug_peek_launch_tag(void) {
     return t ? t : 1u;
 }
 
+// Test hook: the number of polls after which an in-launch d(shift) finalizer gives up and its outputs become NaN
+// (rk_dma.hpp, kFinSpins ~ 2 s).  spins <= 0 restores the default.  Returns the previous value.  Takes effect for launches
+// armed afterwards; no product code calls it.
+int rk_debug_set_finalize_spins(int spins) {
+    return rk::dma::fin_spin_budget().exchange(spins > 0 ? spins : rk::dma::kFinSpins, std::memory_order_relaxed);
+}
+
 }  // extern "C"

@@ -384,12 +384,8 @@ template <int RB, bool RES, int DX, bool STATS = false>
 int launch_gemm(const char* Apk, const __hip_bfloat16* X, const __hip_bfloat16* R, __hip_bfloat16* Y, const Dims& d,
                 hipStream_t stream, float4* stats = nullptr) {
     constexpr size_t lds = (size_t)DX * kXStage + (size_t)2 * 2 * RB * 1024;
-    static bool raised = false;                      // > 64 KB of dynamic LDS needs the attribute, once per instance
-    if (lds > 65536 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_gemm<RB, RES, DX, STATS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RK_ERR_LAUNCH;
-        raised = true;
-    }
+    static DynLdsRaised raised;                      // > 64 KB of dynamic LDS needs the attribute: once per instance and device
+    if (const int rc = raise_dynamic_lds(reinterpret_cast<const void*>(&k_pw16_gemm<RB, RES, DX, STATS>), lds, raised)) return rc;
     const dim3 grid((unsigned)((d.nunits + 15) / 16), (unsigned)((d.nrb + 2 * RB - 1) / (2 * RB)));
     hipLaunchKernelGGL((k_pw16_gemm<RB, RES, DX, STATS>), grid, dim3(kBlock), lds, stream, Apk, X, R, Y, d, stats);
     return launch_status();

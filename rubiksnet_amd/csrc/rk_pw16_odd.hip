@@ -171,12 +171,8 @@ int launch_gemm(const char* Apk, const __hip_bfloat16* X, const __hip_bfloat16* 
                 hipStream_t stream) {
     const size_t lds = gemm_lds(d.rbw, d.P);
     if (lds > 160 * 1024) return RK_ERR_UNSUPPORTED;
-    static size_t raised = 0;                        // > 64 KB of dynamic LDS needs the attribute
-    if (lds > 65536 && lds > raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_odd_gemm<RB, RES, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RK_ERR_LAUNCH;
-        raised = lds;
-    }
+    static DynLdsRaised raised;                      // > 64 KB of dynamic LDS needs the attribute: per instance and device
+    if (const int rc = raise_dynamic_lds(reinterpret_cast<const void*>(&k_pw16_odd_gemm<RB, RES, NW>), lds, raised)) return rc;
     const dim3 grid((unsigned)d.F, (unsigned)((d.nrb + d.rbw - 1) / d.rbw));
     hipLaunchKernelGGL((k_pw16_odd_gemm<RB, RES, NW>), grid, dim3(64 * NW), lds, stream, Apk, X, R, Y, d);
     return launch_status();
@@ -342,12 +338,8 @@ template <int BM, int BK, int NL>
 int launch_wgrad_nl(const __hip_bfloat16* dY, const __hip_bfloat16* X, float* ws, const OWDims& d, hipStream_t stream) {
     const size_t lds = wgrad_lds(d);
     if (lds > 80 * 1024) return RK_ERR_UNSUPPORTED;
-    static size_t raised = 0;
-    if (lds > 65536 && lds > raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw16_odd_wgrad<BM, BK, NL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RK_ERR_LAUNCH;
-        raised = lds;
-    }
+    static DynLdsRaised raised;
+    if (const int rc = raise_dynamic_lds(reinterpret_cast<const void*>(&k_pw16_odd_wgrad<BM, BK, NL>), lds, raised)) return rc;
     hipLaunchKernelGGL((k_pw16_odd_wgrad<BM, BK, NL>), dim3((unsigned)(d.tilesM * d.tilesK * d.S)), dim3(kBlock), lds, stream, dY,
                        X, ws, d);
     return launch_status();

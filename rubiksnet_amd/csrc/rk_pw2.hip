@@ -758,12 +758,9 @@ int launch_wgrad_i(const float* dY, const float* X, float* ws, const WDims& d, h
     constexpr size_t ring = (size_t)NS * ROWS * 128;
     constexpr size_t fold = PH == 2 ? (size_t)WR * WC * RA * RX * 4 * 64 * sizeof(float) : 0;
     constexpr size_t lds = ring > fold ? ring : fold;
-    static bool raised = false;
-    if (lds > 65536 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw2_wgrad<RA, RX, WR, WC, PH, NS, PRO>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RK_ERR_LAUNCH;
-        raised = true;
-    }
+    static DynLdsRaised raised;                      // per instance and device (rk_common.hpp)
+    if (const int rc = raise_dynamic_lds(reinterpret_cast<const void*>(&k_pw2_wgrad<RA, RX, WR, WC, PH, NS, PRO>), lds, raised))
+        return rc;
     const int T = d.tilesM * d.tilesK;
     const unsigned grid = (unsigned)(((d.S + 7) / 8) * 8 * T);
     hipLaunchKernelGGL((k_pw2_wgrad<RA, RX, WR, WC, PH, NS, PRO>), dim3(grid), dim3(64 * WR * WC * PH), lds, stream, dY, X, ws, d);

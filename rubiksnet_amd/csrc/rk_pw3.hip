@@ -329,18 +329,7 @@ bool plan(Plan& pl, int F, int K, int M, int P) {
     static const int mode = [] { const char* e = getenv("RK_PW3"); return e ? atoi(e) : 1; }();
     if (!mode || P % 4 || K % 16 || M % 4 || M <= 256 || M > 288 || K > 1024) return false;
     const long long ntot = (long long)F * P;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        static int cached[16] = {0};
-        if (dev >= 0 && dev < 16) {
-            if (!cached[dev]) {
-                int v = 0;
-                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cached[dev] = v;
-                else cached[dev] = 256;
-            }
-            cus = cached[dev];
-        }
-    }
+    const int cus = device_cus();                    // cached per device, thread-safe (rk_common.hpp)
     const long long rounds = (ntot + (long long)cus * 224 - 1) / ((long long)cus * 224);
     long long cw = (ntot + cus * rounds - 1) / (cus * rounds);
     cw = (cw + 3) / 4 * 4;
@@ -364,13 +353,9 @@ int launch(const float* A, const float* X, const float* R, float* Y, const Dims&
     const int abytes = 16 * RB * NRG * kKC * 4;
     const int npx = (kKC * pl.G * 16 + 1023) / 1024;
     const size_t lds = (size_t)kNS * (abytes + npx * 1024) + (PRO ? 2 * d.K * sizeof(float) : 0);
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw3_gemm<RB, NRG, CB, A_MK, PRO, EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RK_ERR_LAUNCH;
-        raised = true;
-    }
-    if (lds > 160 * 1024) return RK_ERR_UNSUPPORTED;
+    static DynLdsRaised raised;                      // per instance and device (rk_common.hpp)
+    if (const int rc = raise_dynamic_lds(reinterpret_cast<const void*>(&k_pw3_gemm<RB, NRG, CB, A_MK, PRO, EPI>), lds, raised))
+        return rc;
     hipLaunchKernelGGL((k_pw3_gemm<RB, NRG, CB, A_MK, PRO, EPI>), dim3((unsigned)pl.nwg), dim3(64 * NRG * 2), lds, stream, A, X, R,
                        Y, d, fz, tr);
     return launch_status();

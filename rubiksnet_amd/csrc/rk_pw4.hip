@@ -402,16 +402,7 @@ inline int mode() {
     static const int m = [] { const char* e = getenv("RK_PW4"); return e ? atoi(e) : 1; }();    // 0: off, 2: any size
     return m;
 }
-inline int num_cus() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    static int cached[16] = {0};
-    if (!cached[dev]) {
-        int v = 0;
-        cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return cached[dev];
-}
+inline int num_cus() { return device_cus(); }        // cached per device, thread-safe (rk_common.hpp)
 constexpr long long kMinTiles = 4096;                // below: rk_pw2.hip (more, shorter-lived waves)
 
 template <int RB, int NST, bool PRO, int EPI, bool RES>
@@ -426,12 +417,9 @@ int launch(const float* A, const float* X, const float* R, float* Y, const Dims&
     const size_t lds = (size_t)kWaves * NREC * 1024 + 8 * NST * sizeof(float) + 16 * RB * sizeof(float4) +
                        (ALDS ? (size_t)RB * NST * 256 : 0);
     if (lds > 160 * 1024) return RK_ERR_UNSUPPORTED;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw4_gemm<RB, NST, PRO, EPI, RES, ALDS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RK_ERR_LAUNCH;
-        raised = true;
-    }
+    static DynLdsRaised raised;                      // per instance and device (rk_common.hpp)
+    if (const int rc = raise_dynamic_lds(reinterpret_cast<const void*>(&k_pw4_gemm<RB, NST, PRO, EPI, RES, ALDS>), lds, raised))
+        return rc;
     long long wgs = (long long)num_cus() * wgs_per_cu;
     const long long need = (d.ntiles + kWaves - 1) / kWaves;
     wgs = wgs < need ? wgs : need;

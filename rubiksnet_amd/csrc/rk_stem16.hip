@@ -254,20 +254,14 @@ inline int make_sdims(SDims& d, int F, int Cin, int C, int H, int W, int rows_pe
 constexpr int kWgradGroups = 512;
 inline int wgrad_groups(const SDims& d) { return d.units < kWgradGroups ? d.units : kWgradGroups; }
 
-template <typename K> int raise_lds(K kernel, size_t lds, size_t& raised) {
-    if (lds > 160 * 1024) return RK_ERR_UNSUPPORTED;
-    if (lds > 65536 && lds > raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RK_ERR_LAUNCH;
-        raised = lds;
-    }
-    return RK_OK;
+template <typename K> int raise_lds(K kernel, size_t lds, DynLdsRaised& raised) {      // per instance and device (rk_common.hpp)
+    return raise_dynamic_lds(reinterpret_cast<const void*>(kernel), lds, raised);
 }
 
 template <int RBN>
 int launch_forward(const float* Wt, const float* X, __hip_bfloat16* Y, const SDims& d, hipStream_t stream) {
     const size_t lds = ((size_t)(3 * 9 * d.pitch * 2 + 15) & ~(size_t)15) + (size_t)4 * d.C * d.Wo * 2;
-    static size_t raised = 0;
+    static DynLdsRaised raised;
     if (int rc = raise_lds(&k_stem16_forward<RBN>, lds, raised)) return rc;
     const int groups = d.units < 1024 ? d.units : 1024;              // two resident workgroups per CU, two rounds
     hipLaunchKernelGGL((k_stem16_forward<RBN>), dim3((unsigned)groups), dim3(kBlock), lds, stream, Wt, X, Y, d);
@@ -278,7 +272,7 @@ int launch_wgrad(const __hip_bfloat16* dY, const float* X, float* ws, const SDim
     size_t lds = (size_t)3 * 17 * d.pitch * 2;
     const size_t red = (size_t)4 * 16 * RBN * 32 * 4;
     lds = lds > red ? lds : red;
-    static size_t raised = 0;
+    static DynLdsRaised raised;
     if (int rc = raise_lds(&k_stem16_wgrad<RBN>, lds, raised)) return rc;
     hipLaunchKernelGGL((k_stem16_wgrad<RBN>), dim3((unsigned)wgrad_groups(d)), dim3(kBlock), lds, stream, dY, X, ws, d);
     return launch_status();

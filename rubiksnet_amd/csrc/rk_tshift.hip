@@ -541,12 +541,12 @@ int bwd_launch(const T* gy, const T* x, const typename Compute<T>::type* taps, T
     if constexpr (std::is_same<CT, float>::value) {
         dma::Fin fin;
         fin.gran = reinterpret_cast<unsigned long long*>(ws);
-        fin.tag = dma::next_launch_tag();
+        dma::fin_arm(fin);
         fin.producers = (int)gridT(d);
         hipLaunchKernelGGL((k_tshift3_backward<T, VEC, true>), dim3(gridT(d) + C), dim3(kBlock), 0, stream, gy, x, taps, gx,
                            (CT*)ws, d, fin, gtaps);
     } else {
-        dma::Fin fin{nullptr, 0u, 0};
+        dma::Fin fin{nullptr, 0u, 0, 0};
         hipLaunchKernelGGL((k_tshift3_backward<T, VEC, false>), dim3(gridT(d)), dim3(kBlock), 0, stream, gy, x, taps, gx,
                            (CT*)ws, d, fin, gtaps);
         hipLaunchKernelGGL((k_tshift3_finalize<CT>), dim3(C), dim3(kBlock), 0, stream, (const CT*)ws, gtaps, d.NB);
@@ -600,7 +600,7 @@ int bwd_bn_launch(const T* gy, const T* x, const float* taps, const BnBwdT& bn, 
     if (int rc = make_dimsT(d, NT, S, C, HW, VEC)) return rc;
     dma::Fin fin;
     fin.gran = reinterpret_cast<unsigned long long*>(ws);
-    fin.tag = dma::next_launch_tag();
+    dma::fin_arm(fin);
     fin.producers = (int)gridT(d);
     if (bn.gsmall) {
         if constexpr (VEC >= 2)

@@ -33,7 +33,14 @@ def pointwise_mode():
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}      # storage of the activations; weights are fp32
 
 
-_PREPACKED = None            # inside `prepacked(module)`: {weight.data_ptr(): (weight shape, fwd image, bwd image)}
+# Per-THREAD tables of the `prepacked` / `prefolded` blocks (nn.DataParallel runs one forward thread per replica: a table
+# shared between them would be torn down by the first thread to leave its block while another is between its `is not None`
+# test and its lookup).  .prepacked: {weight.data_ptr(): (weight shape, fwd image, bwd image)}; .prefolded: {id(bn): (a, b)}.
+_TABLES = threading.local()
+
+
+def _table(name):
+    return getattr(_TABLES, name, None)
 
 
 @contextlib.contextmanager
@@ -43,8 +50,7 @@ def prepacked(module):
     -- runs after the block), so `_pack` finds its operands instead of launching k_pw16_pack per layer and forward (x 100 in
     Large-AQ: 0.5 ms of the step).  Outside a block nothing is cached: no key would see an edit made through `.data`.
     The images live in one fresh buffer per block; the d(input) operands saved for backward are views of it."""
-    global _PREPACKED
-    if _PREPACKED is not None or not config.switches().prepack or pointwise_mode() == "0":
+    if _table("prepacked") is not None or not config.switches().prepack or pointwise_mode() == "0":
         yield
         return
     weights = [m.weight for m in module.modules()
@@ -74,12 +80,12 @@ def prepacked(module):
         buf = torch.empty(total, dtype=torch.uint8, device=dev)
         _native.check(L.rk_pw_pack_many_bf16(jobs.data_ptr(), len(weights), buf.data_ptr(), max_units,
                                              torch.cuda.current_stream(dev).cuda_stream), "rk_pw_pack_many_bf16")
-    _PREPACKED = {w.data_ptr(): (tuple(w.shape[:2]), buf[o:o + bf], buf[o + bf:o + bf + bb])
-                  for w, (o, bf, bb) in zip(weights, views)}
+    _TABLES.prepacked = {w.data_ptr(): (tuple(w.shape[:2]), buf[o:o + bf], buf[o + bf:o + bf + bb])
+                         for w, (o, bf, bb) in zip(weights, views)}
     try:
         yield
     finally:
-        _PREPACKED = None
+        _TABLES.prepacked = None
 
 
 def _pack(weight):
@@ -87,8 +93,9 @@ def _pack(weight):
     W^T for d(input) -- in ONE small launch.  Redone on every forward (the d(input) operand rides to the backward in the
     autograd context): no cache key sees in-place edits made through `.data` (cf. _bn_affine) -- except inside
     `prepacked(module)`, whose images of this step's weights are used when present."""
-    if _PREPACKED is not None:
-        hit = _PREPACKED.get(weight.data_ptr())
+    table = _table("prepacked")
+    if table is not None:
+        hit = table.get(weight.data_ptr())
         if hit is not None and hit[0] == tuple(weight.shape[:2]):
             return hit[1], hit[2]
     L = _native.lib()
@@ -648,22 +655,20 @@ def conv1x1(conv, x, residual=None):
 # BN+ReLU pairs ride on the conv2 GEMM -- relu(bn1(x)) on its operand load, relu(bn2(.)) on its epilogue -- and the
 # residual add on the conv3 GEMM: per block two GEMMs and the shift touch memory, nothing else.
 
-_PREFOLDED = None
-
-
 @contextlib.contextmanager
 def prefolded(module):
     """Inside the block `_bn_affine(bn)` of every eval-mode BatchNorm2d of `module` returns its slice of ONE batched fold
     (rk_bn_fold_many_f32: one launch per forward instead of one per BatchNorm -- 28 x 5 us in a RubiksNet-Tiny forward).
     Entered by RubiksNet.forward in eval mode; recomputed on every entry (an edit made through `.data` between two forwards
-    is seen), the job table cached on the module and rebuilt when a parameter or buffer moves."""
-    global _PREFOLDED
+    is seen), the job table cached on the module and rebuilt when a parameter or buffer moves.  A replica made by
+    nn.DataParallel (a fresh object on every forward: its job table would be rebuilt -- one synchronous host-to-device copy
+    -- each time) folds layer by layer instead."""
     bns = [m for m in module.modules()
            if isinstance(m, torch.nn.BatchNorm2d) and not m.training and m.running_mean is not None and m.weight is not None
            and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                    for t in (m.weight, m.bias, m.running_mean, m.running_var))]
-    if (_PREFOLDED is not None or len(bns) < 2 or len(bns) > 65535 or len({m.weight.device for m in bns}) != 1
-            or not config.switches().fused_eval):
+    if (_table("prefolded") is not None or getattr(module, "_is_replica", False) or len(bns) < 2 or len(bns) > 65535
+            or len({m.weight.device for m in bns}) != 1 or not config.switches().fused_eval):
         yield
         return
     dev = bns[0].weight.device
@@ -685,11 +690,11 @@ def prefolded(module):
     with torch.cuda.device(dev):
         _native.check(_native.lib().rk_bn_fold_many_f32(jobs.data_ptr(), len(bns), ab.data_ptr(), total, max_c,
                                                         torch.cuda.current_stream(dev).cuda_stream), "rk_bn_fold_many_f32")
-    _PREFOLDED = {id(m): (ab[0, o:o + int(m.weight.shape[0])], ab[1, o:o + int(m.weight.shape[0])]) for m, o in zip(bns, offs)}
+    _TABLES.prefolded = {id(m): (ab[0, o:o + int(m.weight.shape[0])], ab[1, o:o + int(m.weight.shape[0])]) for m, o in zip(bns, offs)}
     try:
         yield
     finally:
-        _PREFOLDED = None
+        _TABLES.prefolded = None
 
 
 def _bn_affine(bn):
@@ -697,8 +702,9 @@ def _bn_affine(bn):
     (rk_bn_fold_f32) -- because no cache key sees in-place edits made through `.data` (EMA updates, checkpoint
     surgery; the reference itself initialises with `fc.weight.data.normal_`)."""
     w, bias, mean, var = bn.weight, bn.bias, bn.running_mean, bn.running_var
-    if _PREFOLDED is not None:
-        hit = _PREFOLDED.get(id(bn))
+    table = _table("prefolded")
+    if table is not None:
+        hit = table.get(id(bn))
         if hit is not None:
             return hit
     if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (w, bias, mean, var)):

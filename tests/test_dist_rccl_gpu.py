@@ -19,8 +19,8 @@ def _run(model, opt, clips, labels, steps):
     return losses
 
 
-@pytest.mark.parametrize("tier", ["tiny"])
-def test_ddp_world_size_one_matches_plain_model(tier):
+@pytest.mark.parametrize("tier,variant", [("tiny", "rubiks3d"), ("tiny", "rubiks3d-aq")])
+def test_ddp_world_size_one_matches_plain_model(tier, variant):
     import torch.distributed as dist
 
     from rubiksnet_amd import RubiksNet, dp
@@ -31,7 +31,9 @@ def test_ddp_world_size_one_matches_plain_model(tier):
     try:
         assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
         torch.manual_seed(0)
-        net = RubiksNet(tier, num_classes=17, num_frames=8, verbose=False).to(env.device)
+        # (-aq: the AttentionShift tap weights ride in DDP's buckets; their batched softmax nodes -- attention_shift.presoftened --
+        #  are made per group of layers where the group's first layer runs, so that a bucket is not held back to the end of backward)
+        net = RubiksNet(tier, num_classes=17, num_frames=8, variant=variant, verbose=False).to(env.device)
         ref = copy.deepcopy(net)
         model = dp.wrap_ddp(net, env, force=True)
         assert isinstance(model, torch.nn.parallel.DistributedDataParallel)

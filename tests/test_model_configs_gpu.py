@@ -364,6 +364,34 @@ def test_tiny_train_step_at_the_bench_batch_matches_oracle(oracle, monkeypatch):
     _check_3d_backward(oracle, taps.b3, "tiny b32")
 
 
+def test_large_train_step_at_the_bench_batch_matches_oracle(oracle, monkeypatch):
+    """configs[3] at the per-GPU batch the bench times (32 clips = one rank's share of the global 256): RubiksNet-Large
+    forward + backward + Adam, every distinct RubiksShift3D call shape -- 9 over 51 layers, at N = 32 the
+    launches take the paths the `large-train` bench leg runs (full rounds of resident workgroups, 14x14 planes of 288
+    channels, in-launch finalizers over 32+ partials per channel) -- compared with the oracle, forward AND backward, over the
+    whole batch (d(shift) is a sum over all 32 clips, so nothing can be sub-sampled there)."""
+    from rubiksnet_amd import RubiksNet, dp
+
+    torch.manual_seed(11)
+    B = 32
+    net = RubiksNet("large", 174, verbose=False).to(DEV)
+    opt = dp.make_optimizer(net, lr=1e-3, lr_shift_mult=0.1, kind="adam")
+    taps = _Taps(monkeypatch)
+    clips = torch.randn(B, 8, 3, 224, 224, device=DEV)
+    labels = torch.randint(0, 174, (B,), device=DEV)
+    loss = dp.train_step(net, opt, clips, labels)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    del clips
+    assert taps.calls["f3"] == 51 and taps.calls["b3"] == 51 and taps.calls["f2"] == 0
+    want = {((B, 8, c, h, h), (1, s, s)) for c, h, s in _expected_shapes(72)}
+    assert set(taps.f3) == want and set(taps.b3) == want
+    _check_3d_forward(oracle, taps.f3, "large b32")
+    _check_3d_backward(oracle, taps.b3, "large b32")
+    shifts = [p for n, p in net.named_parameters() if n.endswith("shift")]
+    assert len(shifts) == 51 and all(p.grad is not None and torch.isfinite(p.grad).all() for p in shifts)
+
+
 def test_tiny_forward_batch64_shift_layers_match_oracle(oracle, monkeypatch):
     """configs[2]: RubiksNet-Tiny full forward at batch 64 (eval, no grad -> the fused inference blocks);
     the first two clips of every distinct shift call are compared with the oracle (the operator is per clip)."""

@@ -25,12 +25,12 @@ def test_images_equal_the_per_layer_pack():
     assert len(convs) > 30
     ref = {c.weight.data_ptr(): pointwise._pack(c.weight) for c in convs}          # outside a block: one launch each
     with pointwise.prepacked(net):
-        assert pointwise._PREPACKED is not None and len(pointwise._PREPACKED) == len(convs)
+        assert pointwise._table("prepacked") is not None and len(pointwise._table("prepacked")) == len(convs)
         for c in convs:
             f, b = pointwise._pack(c.weight)
             rf, rb = ref[c.weight.data_ptr()]
             assert f.data_ptr() != rf.data_ptr() and torch.equal(f, rf) and torch.equal(b, rb), c
-    assert pointwise._PREPACKED is None
+    assert pointwise._table("prepacked") is None
     # the next block sees an edit made through .data
     with torch.no_grad():
         convs[3].weight.data.mul_(2.0)
