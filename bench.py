@@ -540,11 +540,56 @@ def cpu_baseline(budget_s=12.0):
     bytes_total = 20 * n * T * C * H * W
     return {
         "value": bytes_total / dt / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
+        "note": "the oracle: an order-preserving CHECKER (scalar loop nests in the reference's expression order, "
+                "-ffp-contract=off), not a tuned CPU implementation -- a stated baseline, not a target; "
+                "the roofline fraction is what measures the kernels",
+        "when": "before the GPU legs of this run, rank 0, N = 1",
         "sample": "%d clips of [8,64,56,56] fp32 fwd+bwd (same shift/stride/pad as the GPU run), oracle C restatement "
                   "(-O3 %s, OpenMP over (n,t) planes forward / (c,row) backward), %d threads, %.2f s"
                   % (n, "-march=native" if native else "-march=x86-64-v3", threads, dt),
         "threads_effective": threads,
         "clips_per_s": n / dt,
+    }
+
+
+def cpu_model_baseline(budget_s=12.0, batch=8):
+    """The model-level CPU column (north_star: RubiksNet-Tiny forward + backward "next to the reference run on the host CPU
+    cores"): the same RubiksNet-Tiny module on host tensors -- PyTorch's CPU convolution / BatchNorm
+    kernels around the oracle's RubiksShift3D plugged in as every layer's `shift_function` (oracle/torch_shift.py; the
+    reference itself has no CPU path) -- one train step (forward + CE + backward + Adam) at a reduced batch,
+    repeated for ~budget_s seconds."""
+    from oracle import oracle as orc
+    from oracle import torch_shift
+    from rubiksnet_amd import RubiksNet
+
+    orc.build()
+    threads = os.cpu_count() or 1
+    orc.set_threads(threads)
+    torch.manual_seed(0)
+    net = RubiksNet("tiny", num_classes=174, num_frames=8, verbose=False)
+    layers = torch_shift.plug_into(net)
+    opt = dp.make_optimizer(net, lr=1e-3, kind="adam")
+    net.train()
+    clips = torch.randn(batch, 8, 3, 224, 224)
+    labels = torch.randint(0, 174, (batch,))
+
+    def step():
+        t0 = time.perf_counter()
+        dp.train_step(net, opt, clips, labels)
+        return time.perf_counter() - t0
+
+    step()                                        # warm-up (thread pools, allocator, oneDNN primitive caches)
+    reps, dt = 0, 0.0
+    while dt < budget_s and reps < 50:
+        dt += step()
+        reps += 1
+    return {
+        "value": batch * reps / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+        "sample": "%d train steps (fwd + CE + bwd + Adam) of RubiksNet-Tiny on %d clips [8,3,224,224] fp32 on the host: "
+                  "PyTorch CPU conv / BatchNorm kernels (%d intra-op threads) + the oracle's RubiksShift3D in all %d shift "
+                  "layers (OpenMP, %d threads), %.2f s" % (reps, batch, torch.get_num_threads(), layers, threads, dt),
+        "per_step_batch": batch, "ms_per_step": 1e3 * dt / reps,
+        "note": "reduced batch (the GPU leg runs 32 clips per step); the shift layers run the order-preserving checker",
     }
 
 
@@ -779,6 +824,19 @@ def main():
         return
     assert env.device.type == "cuda", "bench.py needs a GPU (no CPU fallback for the product path)"
 
+    # The CPU column first (the host legs run BEFORE the GPU legs of the same process, on rank 0 of a
+    # one-GPU job only -- at N > 1 the other ranks would sit in a barrier while rank 0 computes on the host).
+    cpu = cpu_model = None
+    if env.is_main and env.world_size == 1 and not args.no_cpu:
+        try:
+            cpu = cpu_baseline()
+        except Exception as exc:
+            cpu = {"error": repr(exc)}
+        try:
+            cpu_model = cpu_model_baseline()
+        except Exception as exc:
+            cpu_model = {"error": repr(exc)}
+
     r = op_bench(env, args.steps, args.warmup, settle_s=args.settle)
     t_step = r["elapsed_s"] / args.steps
     bytes_step = r["bytes_fwd"] + r["bytes_bwd"]
@@ -795,6 +853,8 @@ def main():
             except Exception as exc:  # the op number must still be reported
                 models[leg] = {"error": repr(exc)}
             torch.cuda.empty_cache()
+    if cpu_model is not None and isinstance(models.get("tiny-train"), dict):
+        models["tiny-train"]["cpu_baseline"] = cpu_model
     probe = allreduce_probe(env)
     try:
         feeder = feeder_bench(env)
@@ -805,11 +865,8 @@ def main():
     # ran the 2-D / secondary legs on rank 0 after the last barrier while ranks 1..N-1 were already tearing the RCCL
     # communicator down -- untested on RCCL, flagged by the round-2 review.)  The other ranks idle at the barrier.
     traffic, traffic_src = pmc_traffic("backward")
-    rk2d = secondary = tshift = pw16 = pw32 = bnleg = cpu = None
-    if env.is_main and args.no_legs:
-        if not args.no_cpu:
-            cpu = cpu_baseline()
-    elif env.is_main:
+    rk2d = secondary = tshift = pw16 = pw32 = bnleg = None
+    if env.is_main and not args.no_legs:
         rk2d = op2d_bench(env)
         secondary = secondary_points(env)
         try:
@@ -828,8 +885,6 @@ def main():
             bnleg = bn_bench(env)
         except Exception as exc:
             bnleg = {"error": repr(exc)}
-        if not args.no_cpu:                  # after every timed GPU leg
-            cpu = cpu_baseline()
     dp.barrier(env)
 
     if env.is_main:
@@ -897,6 +952,7 @@ def main():
                 "others": others,
             },
             "cpu_baseline": cpu,
+            "cpu_baseline_model": cpu_model,          # the same record as models["tiny-train"]["cpu_baseline"]
             "rk2d": rk2d,
             "tshift": tshift, "pw_bf16": pw16, "pw_f32": pw32, "bn_bwd_dx": bnleg,
             "secondary": secondary,

@@ -38,6 +38,7 @@ struct TDims { int N, T, C; };
 
 namespace t14 {
 constexpr int kHW = 196, kTileB = 784, kStride = 800, kZ = 784, kRC = 4, kPieces = 49;
+constexpr int kSlotsBwd = 7;          // LDS slots of a backward wave: 3 gy + 3 x + the staging plane of d(x)
 template <int I> struct IC { static constexpr int value = I; };
 
 __device__ __forceinline__ float uni(float v) {
@@ -164,11 +165,17 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restr
 
 // Backward of the same shape: d(x) (WRITE_GX) + the d(shift) partial of (n, c), adjoint form (rk3d_dma.hpp) -- gy taps
 // with the negated shift from a ring of 3, my own x elements from a second ring of 3 (x[k-1] stays in registers).
-// VMEM order of a step j: [gy plane j+2][x plane j+2][4 stores, j >= 1 with WRITE_GX].
+// VMEM order of a step j: [gy plane j+2][x plane j+2][1 float4 store, j >= 1 with WRITE_GX].
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // BN (training fusion): x holds z; the activation is recomputed where the d(shift) sums use it, d(x) leaves masked by
 // the ReLU and bn2's reduction sums ride along (rk3d_dma.hpp, dma_backward_loop).
+// d(x) leaves as 49 float4 stores per plane: a lane computes elements l, l + 64, l + 128, l + 192 (consecutive LDS words per
+// tap read), so the plane is turned through a wave-private LDS staging plane (4 ds_write_b32 + 1 ds_read_b128 per step,
+// same wave, in-order LDS: no barrier) and lane l < 49 stores elements 4 l .. 4 l + 3 -- one VMEM store instruction per
+// step instead of four 256-byte ones that each straddle three 128-byte lines (planes start at multiples of 784 bytes).
+// Round 6, [32,8,288,14,14]: 36.8 -> 36.1 us; [32,8,216,14,14]: 29.0 -> 28.3 us (profiles/r06_tile14_variants.txt, with
+// the variants that did NOT pay: an XCD-contiguous workgroup map, 4 waves per SIMD, the next fetch ahead of the wait).
 template <bool WRITE_GX, bool FUSED, bool BN = false>
 __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __restrict__ x, const float* __restrict__ shift,
                                                               const float* __restrict__ gy, float* __restrict__ gx,
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
         publish(wave_sum(aT), wave_sum(aH), wave_sum(aW), wave_sum(aB1), wave_sum(aB2));
         return;
     }
-    char* ring = lds_raw + wave * (6 * kStride);                      // slots 0..2: gy, 3..5: x
+    char* ring = lds_raw + wave * (kSlotsBwd * kStride);              // slots 0..2: gy, 3..5: x, 6: the staging plane of d(x)
     if (lane < 6) *reinterpret_cast<float4*>(ring + lane * kStride + kZ) = make_float4(0.f, 0.f, 0.f, 0.f);
     const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r' of the negated shift
     const float rT = uni(fT.r), rH = uni(fH.r), rW = uni(fW.r), uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
@@ -229,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
     const unsigned gaddr = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring)), xaddr = gaddr + 3 * kStride;
     const long long tstride = (long long)d.C * kHW;
     const size_t col0 = ((size_t)n * d.T * d.C + c) * kHW;
-    float* optr = WRITE_GX ? gx + col0 + lane : nullptr;
+    float* optr = WRITE_GX ? gx + col0 + 4 * lane : nullptr;           // my float4 of the next output plane
+    float* stage = reinterpret_cast<float*>(ring + 6 * kStride);
 
     unsigned rel[kRC][4], xoff[kRC];
 #pragma unroll
@@ -260,9 +268,9 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
     const float bn_a = uni(bnp.x), bn_b = uni(bnp.y), bn_m = uni(bnp.z), bn_i = uni(bnp.w);
     auto step = [&](auto SC, auto LATE, bool store) {
         constexpr int S = decltype(SC)::value;
-        constexpr int W0 = (decltype(LATE)::value && WRITE_GX) ? 8 : 0;
+        constexpr int W0 = (decltype(LATE)::value && WRITE_GX) ? 2 : 0;
         // outstanding behind "gy plane k and x plane k have landed": the fetches of step k-1 that were VMEM ops
-        // (planes tg - 1, tx - 1 now) and the stores of steps k-2, k-1 (LATE: k >= 3)
+        // (planes tg - 1, tx - 1 now) and the stores of steps k-2, k-1 (LATE: k >= 3; one store instruction per step)
         const int more = ((unsigned)(tg - 1) < (unsigned)d.T ? 1 : 0) + ((unsigned)(tx - 1) < (unsigned)d.T ? 1 : 0);
         if (more == 2) wait_vmcnt(W0 + 2); else if (more == 1) wait_vmcnt(W0 + 1); else wait_vmcnt(W0);
         const bool xb_real = (unsigned)(tx - 2) < (unsigned)d.T;     // BN: the x plane of this step exists
@@ -312,10 +320,13 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
                     aB2 = fmaf(o1.x, (zold[1].x - bn_m) * bn_i, aB2);
                     aB2 = fmaf(o1.y, (zold[1].y - bn_m) * bn_i, aB2);
                 }
-                __builtin_nontemporal_store(o0.x, optr);
-                __builtin_nontemporal_store(o0.y, optr + 64);
-                __builtin_nontemporal_store(o1.x, optr + 128);
-                if (lane < kHW - 192) __builtin_nontemporal_store(o1.y, optr + 192);
+                stage[lane] = o0.x; stage[lane + 64] = o0.y; stage[lane + 128] = o1.x;
+                if (lane < kHW - 192) stage[lane + 192] = o1.y;
+                if (lane < kPieces) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * lane);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(optr));
+                }
                 optr += tstride;
             }
             Qprev[0] = Qnew[0]; Qprev[1] = Qnew[1];
@@ -373,7 +384,7 @@ inline bool launch_bwd_bn(const float* z, const float* shift, const float* gy, f
     if (d.H != 14 || d.W != 14) return false;
     TDims t{d.N, d.T, d.C};
     const unsigned producers = (unsigned)(((long long)d.N * d.C + 3) / 4);
-    const size_t lds = 4 * 6 * t14::kStride;
+    const size_t lds = 4 * t14::kSlotsBwd * t14::kStride;
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
     fin_arm(fin.f);
@@ -394,7 +405,7 @@ inline int launch_bwd(const float* x, const float* shift, const float* gy, float
     if (d.H != 14 || d.W != 14) return 0;
     TDims t{d.N, d.T, d.C};
     const unsigned producers = (unsigned)(((long long)d.N * d.C + 3) / 4);
-    const size_t lds = 4 * 6 * t14::kStride;
+    const size_t lds = 4 * t14::kSlotsBwd * t14::kStride;
     dma3d::Fin3 fin;
     fin.f.gran = reinterpret_cast<unsigned long long*>(ws);
     fin_arm(fin.f);

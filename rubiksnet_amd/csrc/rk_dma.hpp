@@ -293,23 +293,44 @@ __device__ __forceinline__ bool fin_ready(const Fin& fin, unsigned long long v, 
     return (unsigned)(v >> 32) == fin.tag && (unsigned)(w >> 32) == fin_tag2(fin.tag) && (unsigned)v == ~(unsigned)w;
 }
 // one wave (lanes 0..63 of the block): s[k] = sum_i granule[c][k][i] over this launch's P partials; false = timed out.
-// The D loads of a lane go out together (one round trip, not D dependent ones: the finalizers' sweep is the tail of
-// the launch), then each lane re-polls only what is still missing.
-// D pairs of one lane (row stride P pairs, lane index i), all requested before the first is used
+// The D pairs of a lane (row stride P pairs, lane index i) are fetched in ONE asm statement -- D 16-byte device-scope
+// loads and the s_waitcnt that covers them: one round trip per poll, not D dependent ones (the finalizers' sweep is the
+// tail of the launch).  The wait sits INSIDE the statement on purpose: to the compiler an asm load is an ordinary
+// instruction whose result is there when the statement ends, so it may copy the destination registers right behind it.
+// Round 5 issued the loads and the wait as separate statements ("+v" ties in between); that held only as long as the
+// register allocator happened to insert no copy between them -- a loop bound that became a kernel argument (the poll
+// budget, round 6) moved the allocation, the copies appeared (v_mov of the destination one instruction after the load) and
+// every finalizer read stale registers, timed out and wrote NaN.  A lane that is not `act` keeps what v / w hold.
 template <int D>
 __device__ __forceinline__ void fin_load(const Fin& fin, unsigned long long* g, int P, int i, unsigned long long (&v)[D],
-                                         unsigned long long (&w)[D], const bool (&want)[D]) {
+                                         unsigned long long (&w)[D], bool act) {
+    if (!act) return;
     if (fin_wide(fin)) {
         u32x4 q[D];
+        const unsigned long long* a[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            q[k] = u32x4{(unsigned)v[k], (unsigned)(v[k] >> 32), (unsigned)w[k], (unsigned)(w[k] >> 32)};
-            if (want[k]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(q[k]) : "v"(g + 2 * ((size_t)k * P + i)) : "memory");
-        }
-        if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) : : "memory");
+        for (int k = 0; k < D; ++k) a[k] = g + 2 * ((size_t)k * P + i);
+        if constexpr (D == 2)
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]) : "v"(a[0]), "v"(a[1]) : "memory");
+        else if constexpr (D == 3)
+            asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                         "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
+        else if constexpr (D == 4)
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+        else if constexpr (D == 5)
+            asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
+                         "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
+                         "global_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4])
+                         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]) : "memory");
         else {
 #pragma unroll
-            for (int k = 0; k < D; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[k]) : : "memory");
+            for (int k = 0; k < D; ++k)
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q[k]) : "v"(a[k]) : "memory");
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -319,12 +340,11 @@ __device__ __forceinline__ void fin_load(const Fin& fin, unsigned long long* g, 
         return;
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k)
-        if (want[k]) {
-            const size_t at = 2 * ((size_t)k * P + i);
-            v[k] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w[k] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    for (int k = 0; k < D; ++k) {
+        const size_t at = 2 * ((size_t)k * P + i);
+        v[k] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[k] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // `count` <= P: the partials that exist for this channel (rows keep the stride P)
 template <int D>
@@ -341,19 +361,16 @@ __device__ __forceinline__ bool fin_collect(const Fin& fin, int c, int P, double
         const int i = i0 + lane;
         const bool act = i < count;
         unsigned long long v[D], w[D];
-        bool want[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { v[k] = done; w[k] = done2; want[k] = act; }
-        fin_load<D>(fin, g, P, i, v, w, want);
+        for (int k = 0; k < D; ++k) { v[k] = done; w[k] = done2; }
+        fin_load<D>(fin, g, P, i, v, w, act);
         for (int spin = 0; spin < fin.spins; ++spin) {               // ~0.25 us per poll: gives up after ~2 s (kFinSpins)
             bool ready = true;
 #pragma unroll
             for (int k = 0; k < D; ++k) ready = ready && fin_ready(fin, v[k], w[k]);
             if (ready) break;
             __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-            for (int k = 0; k < D; ++k) want[k] = !fin_ready(fin, v[k], w[k]);
-            fin_load<D>(fin, g, P, i, v, w, want);
+            fin_load<D>(fin, g, P, i, v, w, act);        // (all D pairs again: a pair that was ready reads back the same)
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
