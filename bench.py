@@ -135,6 +135,12 @@ def op_bench(env, steps, warmup, nsets=4, settle_s=0.4):
     }
 
 
+# how every secondary leg (rk2d, secondary, tshift, pw_*, bn_bwd_dx) is timed -- stated in the JSON so that nobody compares
+# these numbers with a mean over launch-by-launch calls (rounds 1-4 reported that; the headline leg still does, per contract)
+SECONDARY_TIMING = ("untimed run-in, then a captured hipGraph of `iters` back-to-back launches of ONE kernel, replayed 4 times "
+                    "between one pair of HIP events; the figure is the BEST (minimum) of 3 such measurements, per launch")
+
+
 def _steady(fn, iters, settle_s):
     """Seconds per launch of `fn` on the GPU: an untimed run-in (clock / power transient), then a captured hipGraph of
     `iters` back-to-back launches replayed between ONE pair of HIP events.  The replay keeps Python and the launch path out
@@ -414,7 +420,7 @@ def op2d_bench(env, iters=60, settle_s=0.3):
                      "bwd_GBps": 3 * es * n / tb / 1e9,
                      "fwd_plus_bwd_frac_of_hbm_peak": 5 * es * n / (tf + tb) / 1e9 / HBM_PEAK_GBS}
     out["shape"] = [SHAPE[0] * SHAPE[1]] + list(SHAPE[2:])
-    out["timing"] = "untimed run-in, then a captured hipGraph of back-to-back launches of one kernel replayed between one pair of HIP events"
+    out["timing"] = SECONDARY_TIMING
     # SURVEY 8 a12's own example: the 35 layer-3 blocks of Large-AQ at 32 clips per GPU, [256, 288, 14, 14] in bf16
     shape = (256, 288, 14, 14)
     sets = [(torch.empty(shape, device=dev, dtype=torch.bfloat16).uniform_(-1, 1),
@@ -452,7 +458,9 @@ def secondary_points(env, iters=40, settle_s=0.2):
     dev = env.device
     out = {}
     points = (("stride_1_2_2", (32, 8, 54, 112, 112), [1, 2, 2], False),
-              ("planes_14x14", (32, 8, 216, 14, 14), [1, 1, 1], False),
+              ("planes_14x14", (32, 8, 216, 14, 14), [1, 1, 1], False),             # layer3 of Tiny (5 layers)
+              ("planes_14x14_288ch", (32, 8, 288, 14, 14), [1, 1, 1], False),       # layer3 of Large (35 of its 51 layers)
+              ("planes_14x14_72ch", (32, 8, 72, 14, 14), [1, 1, 1], False),         # (third point of the launch-cost line below)
               ("planes_7x7", (32, 8, 576, 7, 7), [1, 1, 1], False),                 # layer4 of Large
               ("stride_1_2_2_28to14", (32, 8, 288, 28, 28), [1, 2, 2], False),      # the third downsampling layer of Large
               ("quantize", SHAPE, [1, 1, 1], True))
@@ -490,6 +498,26 @@ def secondary_points(env, iters=40, settle_s=0.2):
                      "fwd_plus_bwd_frac_of_hbm_peak": (bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS}
         del sets
         torch.cuda.empty_cache()
+    # What a small-plane launch costs before it streams a byte, and how fast it streams once it does: the least-squares line
+    # t(C) = a + b C through the three 14x14 points (tools/fixed_cost_probe.py does the same over six; profiles/
+    # r06_small_plane_fixed_cost.txt).  A 14x14 tensor of 32 clips is 43-58 MB: at ~6 TB/s it streams in 7-10 us, so the
+    # ~4 us (forward) / ~6 us (backward: + the in-launch row-sum's hand-off) a launch costs up front is what the
+    # fraction-of-peak of these legs measures, not the kernels' streaming rate.
+    try:
+        pts = [out[k] for k in ("planes_14x14_72ch", "planes_14x14", "planes_14x14_288ch")]
+        cs = [p["x"][2] for p in pts]
+        n = len(cs)
+        mc = sum(cs) / n
+        fit = {}
+        for key, per_c in (("fwd", 8 * 32 * 8 * 196), ("bwd", 12 * 32 * 8 * 196)):
+            ts = [p[key + "_us"] for p in pts]
+            mt = sum(ts) / n
+            b = sum((c - mc) * (t - mt) for c, t in zip(cs, ts)) / sum((c - mc) ** 2 for c in cs)
+            fit[key] = {"launch_cost_us": mt - b * mc, "marginal_GBps": per_c / b / 1e3,
+                        "marginal_frac_of_hbm_peak": per_c / b / 1e3 / HBM_PEAK_GBS}
+        out["planes_14x14_launch_cost_fit"] = fit
+    except Exception as exc:      # a diagnostic, never the reason a bench line is lost
+        out["planes_14x14_launch_cost_fit"] = {"error": repr(exc)}
     return out
 
 
@@ -898,6 +926,9 @@ def main():
             "shift3d_stride_1_2_2_112to56": frac(secondary, "stride_1_2_2", "fwd_plus_bwd_frac_of_hbm_peak"),
             "shift3d_stride_1_2_2_28to14": frac(secondary, "stride_1_2_2_28to14", "fwd_plus_bwd_frac_of_hbm_peak"),
             "shift3d_planes_14x14": frac(secondary, "planes_14x14", "fwd_plus_bwd_frac_of_hbm_peak"),
+            "shift3d_planes_14x14_288ch": frac(secondary, "planes_14x14_288ch", "fwd_plus_bwd_frac_of_hbm_peak"),
+            "shift3d_planes_14x14_marginal_fwd": frac(secondary, "planes_14x14_launch_cost_fit", "fwd", "marginal_frac_of_hbm_peak"),
+            "shift3d_planes_14x14_marginal_bwd": frac(secondary, "planes_14x14_launch_cost_fit", "bwd", "marginal_frac_of_hbm_peak"),
             "shift3d_planes_7x7": frac(secondary, "planes_7x7", "fwd_plus_bwd_frac_of_hbm_peak"),
             "shift3d_quantize": frac(secondary, "quantize", "fwd_plus_bwd_frac_of_hbm_peak"),
             "shift2d_f32_56x56": frac(rk2d, "f32", "fwd_plus_bwd_frac_of_hbm_peak"),
@@ -950,6 +981,7 @@ def main():
                 "fwd_plus_bwd": {"achieved": both_gbs, "frac": both_gbs / HBM_PEAK_GBS,
                                  "frac_of_copy_ceiling": both_gbs / COPY_CEILING_GBS},
                 "others": others,
+                "others_timing": SECONDARY_TIMING,
             },
             "cpu_baseline": cpu,
             "cpu_baseline_model": cpu_model,          # the same record as models["tiny-train"]["cpu_baseline"]

@@ -61,10 +61,17 @@ template <typename A> __device__ __forceinline__ A wave_sum_dpp(A v) {
     v += dpp_or_zero<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
     return v;
 }
+// CONTRACT (every type): all 64 lanes of the wave are active and converged at the call (whole-wave callers only: a lane
+// that has nothing to add passes 0), and the sum comes back in EVERY lane.  float / double take the DPP scan below, whose
+// row_bcast controls exist on gfx9 only -- this library is gfx950 code and says so at compile time; any other type takes
+// the shuffle tree and broadcasts lane 0's total, so that the contract does not depend on the type.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "librubiks_hip is written for gfx950 (CDNA4): wave64, DPP row_bcast, global_load_lds_dwordx4"
+#endif
 template <typename A> __device__ __forceinline__ A wave_sum(A v) {
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
-    return v;
+    return __shfl(v, 0, kWave);
 }
 template <> __device__ __forceinline__ float wave_sum<float>(float v) {
     v = wave_sum_dpp(v);

@@ -393,6 +393,10 @@ class _BNReLUShift2DTrain(torch.autograd.Function):
         gy = gy.contiguous()
         if gy.dtype != z.dtype:
             gy = gy.to(z.dtype)
+        if gy.data_ptr() % 16:
+            # a contiguous VIEW at an odd storage offset: the fused kernels want 16-byte aligned planes, and by now bn2's
+            # running statistics are updated -- there is no unfused path to fall back to.  A fresh buffer is aligned.
+            gy = gy.clone()
         dz = torch.empty_like(z)
         gshift = torch.empty_like(shift)
         k12 = torch.empty(2, C, dtype=torch.float32, device=dev)

@@ -104,3 +104,31 @@ def test_other_planes_fall_back():
     assert fused_bn.bn_relu_shift2d(bn, asq, torch.randn(4, 8, 14, 14, device=DEV, requires_grad=True)) is None     # quantize
     assert fused_bn.bn_relu_shift2d(bn, as3, torch.randn(4, 8, 14, 14, device=DEV)) is not None
     assert fused_bn.bn_relu_shift2d(bn.eval(), as3, torch.randn(4, 8, 14, 14, device=DEV, requires_grad=True)) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_takes_an_upstream_gradient_at_an_odd_storage_offset(dtype):
+    """The fused backward kernels want 16-byte aligned planes; the upstream gradient autograd hands over can be a contiguous
+    VIEW into a bigger buffer at any element offset (round-5 advisor finding: RK_ERR_UNSUPPORTED mid-step, after bn2's
+    running statistics were already updated).  The backward copies such a gradient to a fresh buffer: same gradients as
+    with an aligned one, bit for bit."""
+    from rubiksnet_amd import fused_bn
+
+    z, bn, as3, gy = _setup(16, 10, dtype, "generic", 5)
+    big = torch.zeros(gy.numel() + 8, dtype=dtype, device=DEV)
+    off = 1 if dtype == torch.float32 else 3                          # 4 / 6 bytes past a 16-byte boundary
+    gy_odd = big[off:off + gy.numel()].view_as(gy)
+    gy_odd.copy_(gy)
+    assert gy_odd.is_contiguous() and gy_odd.data_ptr() % 16 != 0
+    grads = []
+    for g in (gy, gy_odd):
+        bn_c, as3_c = copy.deepcopy(bn), copy.deepcopy(as3)
+        zc = z.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = fused_bn.bn_relu_shift2d(bn_c, as3_c, zc)
+        assert y is not None
+        y.backward(g)
+        torch.cuda.synchronize()
+        grads.append((zc.grad, bn_c.weight.grad, bn_c.bias.grad, as3_c.shift.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
