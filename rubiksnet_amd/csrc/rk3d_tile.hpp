@@ -37,7 +37,7 @@ using namespace dma;
 struct TDims { int N, T, C; };
 
 namespace t14 {
-constexpr int kHW = 196, kTileB = 784, kStride = 800, kZ = 784, kRC = 4, kPieces = 49;
+constexpr int kHW = 196, kTileB = 784, kZ = 784, kZWords = 32, kStride = kTileB + 4 * kZWords, kRC = 4, kPieces = 49;
 constexpr int kSlotsBwd = 7;          // LDS slots of a backward wave: 3 gy + 3 x + the staging plane of d(x)
 template <int I> struct IC { static constexpr int value = I; };
 
@@ -47,20 +47,34 @@ __device__ __forceinline__ float uni(float v) {
 template <int OFFB> __device__ __forceinline__ float lds_at(unsigned a) {
     return *(__attribute__((address_space(3))) const float*)(size_t)(a + (unsigned)OFFB);
 }
-// absolute LDS byte addresses (slot 0) of the 4 taps of element p = lane + 64 * rc; outside the plane -> the zero word
+// A slot ends in kZWords = 32 zero words, one per LDS bank of a ds_read_b32 (bank = word mod 32 inside each half-wave): a lane
+// whose tap lies outside the plane reads the zero word in the SAME BANK its in-plane address would have had.  The taps of
+// the lanes of a half-wave are consecutive words (word = p + 14 flH + flW + const), i.e. 32 distinct banks, so a redirected
+// lane never lands on a bank another lane of its instruction uses -- with ONE zero word per slot (rounds 2-5) every tap
+// instruction that had an outside lane paid a 2-way conflict: SQ_LDS_BANK_CONFLICT was 18-50 % of the kernels' LDS cycles
+// (profiles/r05_tile14_pmc.csv).  Slots are kStride = 912 bytes apart, the same bank shift for every lane.
+__device__ __forceinline__ unsigned zero_word(unsigned slot0, int natural_word) {
+    const int zw = (int)((slot0 + kZ) >> 2);
+    return (unsigned)(zw + ((natural_word - zw) & (kZWords - 1))) << 2;
+}
+// absolute LDS byte addresses (slot 0) of the 4 taps of element p = lane + 64 * rc; outside the plane -> a zero word
 __device__ __forceinline__ void taps(unsigned (&rel)[4], unsigned slot0, int flH, int flW, int lane, int rc) {
     const int p = lane + kWave * rc;
     const bool live = p < kHW;
-    const int pc = live ? p : 0;
-    const int h = pc / 14, w = pc - h * 14;
+    const int h = p / 14, w = p - h * 14;                             // (p >= kHW: rows 14..18 -- only the bank matters)
     const int h0 = h + flH, w0 = w + flW;
     const bool mh0 = (unsigned)h0 < 14u, mh1 = (unsigned)(h0 + 1) < 14u;
     const bool mw0 = (unsigned)w0 < 14u, mw1 = (unsigned)(w0 + 1) < 14u;
-    const unsigned a = slot0 + (unsigned)((h0 * 14 + w0) * 4), Z = slot0 + kZ;
-    rel[0] = live && mh0 && mw0 ? a : Z;
-    rel[1] = live && mh0 && mw1 ? a + 4u : Z;
-    rel[2] = live && mh1 && mw0 ? a + 56u : Z;
-    rel[3] = live && mh1 && mw1 ? a + 60u : Z;
+    const int wn = (int)(slot0 >> 2) + h0 * 14 + w0;                  // the word tap (0, 0) has, or would have
+    const unsigned a = (unsigned)wn << 2;
+    rel[0] = live && mh0 && mw0 ? a : zero_word(slot0, wn);
+    rel[1] = live && mh0 && mw1 ? a + 4u : zero_word(slot0, wn + 1);
+    rel[2] = live && mh1 && mw0 ? a + 56u : zero_word(slot0, wn + 14);
+    rel[3] = live && mh1 && mw1 ? a + 60u : zero_word(slot0, wn + 15);
+}
+// every zero word of a wave's `slots` slots (8 float4 each), once per kernel
+__device__ __forceinline__ void zero_regions(char* ring, int slots, int lane) {
+    if (lane < 8 * slots) *reinterpret_cast<float4*>(ring + (lane >> 3) * kStride + kZ + (lane & 7) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_interp(const float* __restr
     if (id >= (long long)d.N * d.C) return;                          // whole wave; no barriers in this kernel
     const int n = (int)(id / d.C), c = (int)(id - (long long)n * d.C);
     char* ring = lds_raw + wave * (R * kStride);
-    if (lane < R) *reinterpret_cast<float4*>(ring + lane * kStride + kZ) = make_float4(0.f, 0.f, 0.f, 0.f);
+    zero_regions(ring, R, lane);
     float s0 = shift[c], s1 = shift[d.C + c], s2 = shift[2 * d.C + c];
     if (NEGATE) { s0 = -s0; s1 = -s1; s2 = -s2; }
     const Frac<float> fT = split_shift(s0), fH = split_shift(s1), fW = split_shift(s2);
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
         return;
     }
     char* ring = lds_raw + wave * (kSlotsBwd * kStride);              // slots 0..2: gy, 3..5: x, 6: the staging plane of d(x)
-    if (lane < 6) *reinterpret_cast<float4*>(ring + lane * kStride + kZ) = make_float4(0.f, 0.f, 0.f, 0.f);
+    zero_regions(ring, 6, lane);
     const Frac<float> fT = split_shift(-s0), fH = split_shift(-s1), fW = split_shift(-s2);   // fl', r' of the negated shift
     const float rT = uni(fT.r), rH = uni(fH.r), rW = uni(fW.r), uT = 1 - rT, uH = 1 - rH, uW = 1 - rW;
     const int f0 = __builtin_amdgcn_readfirstlane(fT.fl);
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k3d_tile14_backward(const float* __res
     for (int rc = 0; rc < kRC; ++rc) {
         taps(rel[rc], gaddr, flH, flW, lane, rc);
         const int p = lane + kWave * rc;
-        xoff[rc] = xaddr + (p < kHW ? (unsigned)(p * 4) : (unsigned)kZ);
+        xoff[rc] = p < kHW ? xaddr + (unsigned)(p * 4) : zero_word(xaddr, (int)(xaddr >> 2) + p);
     }
     int tg = f0, tx = 0;                                             // next gy / x planes to fetch
     const float* pg = gy + col0 + (long long)f0 * tstride;           // (never dereferenced out of range)
