@@ -1027,12 +1027,12 @@ static bool make_sdims(SDims& s, const Dims3& d, int M) {
 }
 static int halo_of(const SDims& s) { return s.W + 1 <= 8 ? 2 : 4; }
 template <int M, int HL, int RG> constexpr size_t lds_of() { return (size_t)(kBlock / kWave) * RG * Geo<M, HL>::kStride; }
-// planes a wave keeps in flight: 3 (forward: 16.6 / 18.2 / 21.8 us at 7x7x576 / 14x14x216 / 14x14x288 against 16.5 / 18.4 /
-// 23.3 with all 8) or all 8 (backward: 95 VGPRs against 111, i.e. 5 waves per SIMD without spills).  RK_SLAB_RG=3|8 forces one.
-static int ring_depth(int dflt) {
-    static const int v = [] { const char* e = getenv("RK_SLAB_RG"); const int r = e ? atoi(e) : 0; return r == 3 || r == 8 ? r : 0; }();
-    return v ? v : dflt;
-}
+// planes a wave keeps in flight: 3 in the forward (16.6 / 18.2 / 21.8 us at 7x7x576 / 14x14x216 / 14x14x288 against 16.5 /
+// 18.4 / 23.3 with all 8), all 8 in the backward (95 VGPRs, 5 waves per SIMD).  The backward with a ring of 3 needed 111 VGPRs
+// and SPILLED -- among other things the x values load_x2 had just requested, one instruction behind the load (the compiler
+// takes an asm load's result for ready): stale data, found by tools/asm_hazard_check.py in round 6.  That instantiation, only
+// reachable through the RK_SLAB_RG tuning switch, is gone together with the switch.
+constexpr int kRingFwd = 3, kRingBwd = kMaxT;
 
 bool launch_interp(bool negate, const float* src, const float* shift, float* dst, const Dims3& d, hipStream_t stream) {
     SDims s;
@@ -1040,7 +1040,7 @@ bool launch_interp(bool negate, const float* src, const float* shift, float* dst
     const unsigned grid = (unsigned)((long long)s.N * s.nchunks);
 #define RK_SLAB_FWD(NG, HL, RG) hipLaunchKernelGGL((k3d_slab_interp<NG, HL, RG>), dim3(grid), dim3(kBlock), \
                                                    (lds_of<4, HL, RG>()), stream, src, shift, dst, s, d)
-#define RK_SLAB_FWD_R(NG, HL) do { if (ring_depth(3) == 3) RK_SLAB_FWD(NG, HL, 3); else RK_SLAB_FWD(NG, HL, 8); } while (0)
+#define RK_SLAB_FWD_R(NG, HL) RK_SLAB_FWD(NG, HL, kRingFwd)
     if (halo_of(s) == 2) { if (negate) RK_SLAB_FWD_R(true, 2); else RK_SLAB_FWD_R(false, 2); }
     else { if (negate) RK_SLAB_FWD_R(true, 4); else RK_SLAB_FWD_R(false, 4); }
 #undef RK_SLAB_FWD_R
@@ -1062,7 +1062,7 @@ int launch_bwd(const float* x, const float* shift, const float* gy, float* gx, f
     fin.t_factor = t_factor;
 #define RK_SLAB_BWD(GX, FU, HL, RG) hipLaunchKernelGGL((k3d_slab_backward<GX, FU, HL, RG>), dim3(producers + (FU ? d.C : 0)), dim3(kBlock), \
                                                        (lds_of<2, HL, RG>() + 4 * kBlock * 2 * 4), stream, x, shift, gy, gx, ws, s, d, fin)
-#define RK_SLAB_BWD_R(GX, FU, HL) do { if (ring_depth(8) == 3) RK_SLAB_BWD(GX, FU, HL, 3); else RK_SLAB_BWD(GX, FU, HL, 8); } while (0)
+#define RK_SLAB_BWD_R(GX, FU, HL) RK_SLAB_BWD(GX, FU, HL, kRingBwd)
 #define RK_SLAB_BWD_H(GX, FU) do { if (halo_of(s) == 2) RK_SLAB_BWD_R(GX, FU, 2); else RK_SLAB_BWD_R(GX, FU, 4); } while (0)
     if (gshift) { if (gx) RK_SLAB_BWD_H(true, true); else RK_SLAB_BWD_H(false, true); }
     else { if (gx) RK_SLAB_BWD_H(true, false); else RK_SLAB_BWD_H(false, false); }
