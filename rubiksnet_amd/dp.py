@@ -49,10 +49,16 @@ def init_distributed(prefer_gpu=True):
     else:
         device = torch.device("cpu")
     backend = "nccl" if use_gpu else "gloo"
+    # RK_DIST_BACKEND=gloo: the exchange over gloo although the tensors live on a GPU -- a TEST arrangement: it lets N ranks
+    # share one device (RCCL refuses that), so that the whole N > 1 job -- launcher, rendezvous, DDP around the real kernels,
+    # the collective run-in, barrier + max-over-ranks timing -- runs on a one-GPU box (tests/test_dist_world2_gpu.py)
+    forced = os.environ.get("RK_DIST_BACKEND")
+    if forced in ("gloo", "nccl"):
+        backend = forced
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if use_gpu:
+        if use_gpu and backend == "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -73,7 +79,7 @@ def ensure_process_group(env):
             sock.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
-    if env.device.type == "cuda":
+    if env.device.type == "cuda" and env.backend == "nccl":
         dist.init_process_group(env.backend, rank=env.rank, world_size=env.world_size, device_id=env.device)
     else:
         dist.init_process_group(env.backend, rank=env.rank, world_size=env.world_size)
@@ -141,7 +147,7 @@ def train_step(model, optimizer, clips, labels, criterion=None):
 
 def barrier(env):
     if env.distributed:
-        if env.device.type == "cuda":
+        if env.device.type == "cuda" and env.backend == "nccl":
             dist.barrier(device_ids=[env.device.index])
         else:
             dist.barrier()

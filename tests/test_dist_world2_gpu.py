@@ -96,3 +96,35 @@ def test_two_ranks_on_one_gpu_average_the_per_replica_gradients(tmp_path, varian
             continue
         assert torch.equal(r0["state"][k], r1["state"][k]), k
     assert any(not torch.equal(r0["state"][k], r1["state"][k]) for k in r0["state"] if "running_mean" in k)
+
+
+def test_the_drivers_two_rank_bench_command_runs_on_one_gpu():
+    """The command the driver's SCALE run issues for N = 2 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W` -- end to end on the box's one GPU:
+    RK_DIST_BACKEND=gloo (dp.init_distributed) lets both ranks share the device, everything else is the real job -- the
+    operator leg on both ranks, barrier + max-over-ranks timing, the Tiny train-step leg under DDP with its collective run-in,
+    the all-reduce probe, rank-0-only legs ahead of the final barrier, ONE JSON line from rank 0."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RK_DIST_BACKEND"] = "gloo"
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--models", "tiny-train", "--model-steps", "2", "--no-legs"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 64 and out["config"]["per_gpu_batch"] == 32
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    # whole-job aggregate: the bytes of BOTH ranks over the slowest rank's time
+    assert abs(out["value"] - 2 * out["config"]["algorithmic_bytes_per_step"] / (out["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * out["value"]
+    assert out["cpu_baseline"] is None                                # the CPU column is a one-GPU-job leg
+    leg = out["models"]["tiny-train"]
+    assert "error" not in leg, leg
+    assert leg["global_batch"] == 64 and leg["parallelism"] == "dp2" and leg["ms_per_step"] > 0
+    assert out["allreduce_probe"]["ranks"] == 2 and out["allreduce_probe"]["backend"] == "gloo"
